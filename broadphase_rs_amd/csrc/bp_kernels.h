@@ -1,0 +1,138 @@
+// bp_kernels.h -- host-side launch interface of the gfx950 kernels (internal; the public
+// boundary is include/bp_layer.h).  Every launcher enqueues on `stream` and returns a hipError_t.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bp {
+
+// ---- index kinds (reference: src/index.rs:293-295) -------------------------------------------
+struct KindInfo {
+    uint32_t dim, bits, depth_bits, axis_bits;
+};
+inline KindInfo kind_info(int kind) {
+    switch (kind) {
+        case 0: return {2, 32, 4, 14};
+        case 1: return {2, 64, 5, 29};
+        default: return {3, 64, 5, 19};
+    }
+}
+
+// ---- device scalars shared by the kernels of one layer ------------------------------------------
+// Zeroed / initialised by the host before each phase, read back with one small D2H copy.
+struct DevScalars {
+    unsigned long long total;      // result of the last block-sum scan
+    unsigned long long key_or;     // OR / AND of every index value appended (digit planning)
+    unsigned long long key_and;
+    unsigned int id_or, id_and;    // OR / AND of the ids appended
+    unsigned int depth_mask;       // bit d set <=> an entry of depth d exists
+    unsigned int flags;            // EXT_* bits below
+    unsigned int err;              // KERR_* bits below
+    unsigned int n_invalid;        // objects outside the system bounds
+    unsigned int id_max;           // largest id handed to the last extend (valid or not)
+    unsigned int pad_;
+};
+enum : unsigned {
+    EXT_IDS_DECREASE = 1u,   // some id is smaller than its predecessor in append order
+    EXT_IDS_REPEAT = 2u,     // some id is <= its predecessor (ids not provably distinct)
+};
+enum : unsigned {
+    KERR_LOOKBACK_TIMEOUT = 1u,  // a decoupled look-back spin hit its bound
+    KERR_COUNT_OVERFLOW = 2u,    // an object expands to more cells than a launch can index
+};
+
+// per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
+struct BlockAux {
+    unsigned long long key_or, key_and;
+    unsigned int depth_mask, flags, err, n_invalid, id_or, id_and, id_max, pad_;
+};
+
+struct SysBounds {
+    float mn[3];
+    float mx[3];
+};
+
+// ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
+constexpr int ENC_THREADS = 256;
+inline size_t enc_blocks(size_t n) { return (n + ENC_THREADS - 1) / ENC_THREADS; }
+
+hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
+                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, uint32_t* counts,
+                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream);
+hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
+                              uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
+                              uint64_t* keys_out, uint32_t* ids_out, hipStream_t stream);
+
+// exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
+// partials are folded into *sc as well (single workgroup, no atomics)
+hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
+                                  hipStream_t stream);
+
+// OR/AND/depth-mask reduction over an existing tree (set_tree / append_entries)
+hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, DevScalars* sc,
+                              hipStream_t stream);
+
+// ---- radix sort (K4, K7): stands in for par_sort_unstable, src/layer.rs:149,516 ---------------
+constexpr int RS_THREADS = 512;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 8192 keys per workgroup
+constexpr int RS_BINS = 256;
+constexpr int RS_MAX_PASSES = 12;
+inline size_t rs_tiles(size_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+
+struct RadixPlan {
+    int n_passes;
+    int shift[RS_MAX_PASSES];
+    int from_val[RS_MAX_PASSES];  // 1: digit taken from the u32 payload (id) instead of the u64 key
+};
+// plan passes over the varying bits only; id passes (if any) come first (LSD order)
+RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned id_varying);
+
+// workspace layout for one sort: [hist: passes*256 u64][bin_base: passes*256 u64]
+// [tile counters: passes u32 (padded)][status: passes * tiles * 256 u64]
+size_t radix_workspace_bytes(size_t n, int n_passes);
+
+// Sorts n (key[,val]) records.  keys/vals are ping-pong buffers; *result_buf tells which holds
+// the result (0 or 1).  vals0 == nullptr: keys only.
+hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
+                      const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
+                      int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
+                      int class_hist, int class_sort);
+
+// ---- overlap scan (K5, K6): reference src/layer.rs:550-573 --------------------------------------
+constexpr int SCAN_THREADS = 256;
+inline size_t scan_blocks(size_t m) { return (m + SCAN_THREADS - 1) / SCAN_THREADS; }
+
+struct ScanParams {
+    const unsigned long long* keys;
+    const uint32_t* ids;
+    size_t m;
+    uint32_t depth_mask;    // present depths
+    uint32_t coarse_depth;  // shard mode: entries with depth < coarse_depth are "coarse"
+    int emit_coarse;        // emit pairs whose deeper entry is coarse
+    int general;            // ids may repeat: apply the reference's skip rule exactly
+    uint8_t* skip;          // [m] general mode only
+};
+hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream);
+hipError_t launch_scan_count(int kind, ScanParams p, uint32_t* counts, unsigned long long* block_sums,
+                             hipStream_t stream);
+hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, const unsigned long long* block_offs,
+                            uint64_t* pairs_out, hipStream_t stream);
+
+// ---- dedup (K8): reference src/layer.rs:474,517 --------------------------------------------------
+constexpr int UQ_THREADS = 256;
+constexpr int UQ_ITEMS = 8;
+constexpr int UQ_TILE = UQ_THREADS * UQ_ITEMS;
+inline size_t uq_blocks(size_t n) { return (n + UQ_TILE - 1) / UQ_TILE; }
+hipError_t launch_unique_count(const uint64_t* sorted, size_t n, unsigned long long* block_sums, hipStream_t stream);
+// writes each surviving packed pair (id << 32 | id_) as interleaved u32 (id, id_)
+hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned long long* block_offs,
+                              uint32_t* pairs_out, hipStream_t stream);
+
+// interleaved (id, id_) u32 pairs <-> packed u64 (id << 32 | id_)
+hipError_t launch_pack_pairs(const uint32_t* pairs, size_t n, uint64_t* packed, hipStream_t stream);
+hipError_t launch_unpack_pairs(const uint64_t* packed, size_t n, uint32_t* pairs, hipStream_t stream);
+
+}  // namespace bp

@@ -1,0 +1,896 @@
+// bp_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Layer extend -> sort -> scan
+// path.  Integer / bit-op work, HBM-bound: no MFMA.  Reference behaviour (file:line into
+// zvxryb/broadphase-rs) is cited at each kernel; the algorithms themselves are GPU-first:
+//   encode      count -> block-sum scan -> emit (deterministic append order)
+//   radix sort  one-sweep LSD, 8-bit digits, decoupled look-back across 8192-key tiles,
+//               wave64 ballot ranking, LDS-staged coalesced scatter, constant-bit digit skipping
+//   overlap scan closed form of the reference's stack sweep: ancestors-by-search, count -> emit
+//   dedup       adjacent-unique flag/compact
+#include "bp_kernels.h"
+#include "bp_device.h"
+
+namespace bp {
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u32 MAX_CELLS_PER_OBJECT = 1u << 20;
+
+// =================================================================================================
+// encode: Layer::extend (src/layer.rs:94-121)
+// =================================================================================================
+template <int KIND> struct Cells {
+    u32 depth;
+    u32 lo[3];   // first cell coordinate per axis (depth bits)
+    u32 n[3];    // cells per axis
+    u32 count;   // product (0 if the object is invalid or overflows)
+    bool valid, overflow;
+};
+
+// contains (src/geom.rs:121-128) + to_local (src/geom.rs:148-163) + indices() depth choice
+// (src/geom.rs:189-200 / 247-258) + the cell range of indices_at_depth (src/geom.rs:202-231 /
+// 260-297).  f32 arithmetic is evaluated exactly as written there: IEEE sub, div, mul, add with
+// no contraction (-ffp-contract=off) and a saturating cast.
+template <int KIND>
+__device__ __forceinline__ Cells<KIND> object_cells(const SysBounds& sb, const float* __restrict__ row, u32 min_depth) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB;
+    Cells<KIND> c;
+    c.valid = true;
+    c.overflow = false;
+    float bmin[3], bmax[3];
+#pragma unroll
+    for (u32 a = 0; a < DIM; ++a) {
+        bmin[a] = row[a];
+        bmax[a] = row[DIM + a];
+        if (sb.mn[a] > bmin[a] || sb.mx[a] < bmax[a]) c.valid = false;  // NaN passes, like the reference
+    }
+    u32 lmin[3], lmax[3], max_axis = 0;
+#pragma unroll
+    for (u32 a = 0; a < DIM; ++a) {
+        const float size = sb.mx[a] - sb.mn[a];
+        lmin[a] = f32_to_u32_sat((bmin[a] - sb.mn[a]) / size * 4294967040.0f + 0.0f);
+        lmax[a] = f32_to_u32_sat((bmax[a] - sb.mn[a]) / size * 4294967040.0f + 0.0f);
+        const u32 s = (lmax[a] - lmin[a]) + 1u;  // sizei(), wrapping like release-mode Rust
+        max_axis = s > max_axis ? s : max_axis;
+    }
+    const u32 ext = max_axis - 1u;
+    u32 depth = ext == 0 ? 32u : (u32)__clz(ext);
+    depth = depth < min_depth ? min_depth : depth;
+    depth = depth < AB ? depth : AB;  // clamp_depth (src/index.rs:93-95)
+    c.depth = depth;
+    u64 count = 1;
+#pragma unroll
+    for (u32 a = 0; a < 3; ++a) {
+        c.lo[a] = 0;
+        c.n[a] = 1;
+    }
+    if (depth != 0) {
+        const u32 sh = 32u - depth;
+#pragma unroll
+        for (u32 a = 0; a < DIM; ++a) {
+            const u32 lo = lmin[a] >> sh, hi = lmax[a] >> sh;
+            c.lo[a] = lo;
+            c.n[a] = hi >= lo ? hi - lo + 1u : 1u;  // the reference loop emits min once when min > max
+            count *= c.n[a];
+            if (count > MAX_CELLS_PER_OBJECT) {
+                c.overflow = true;
+                count = MAX_CELLS_PER_OBJECT + 1ull;
+            }
+        }
+    }
+    if (!c.valid || c.overflow) count = 0;
+    c.count = (u32)count;
+    return c;
+}
+
+// Index::default().set_depth(depth).set_origin(cell << (32-depth))  (src/index.rs:106-112, 230-250)
+template <int KIND>
+__device__ __forceinline__ u64 make_key(u32 depth, u32 cx, u32 cy, u32 cz) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+    const u32 up = AB - depth;  // cell coordinate -> top-AXIS_BITS coordinate
+    u64 morton = spread_bits<DIM>((u64)cx << up) | (spread_bits<DIM>((u64)cy << up) << 1);
+    if (DIM == 3) morton |= spread_bits<DIM>((u64)cz << up) << 2;
+    return (morton << DB) | (u64)depth;
+}
+
+// OR / AND of all integers in [lo, hi]
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u32 t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void range_or_and(u32 lo, u32 n, u32& o, u32& a) {
+    const u32 hi = lo + n - 1u;
+    const u32 x = lo ^ hi;
+    const u32 low = x == 0 ? 0u : (0xFFFFFFFFu >> __clz(x));
+    o = hi | low;
+    a = lo & ~low;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb, const float* __restrict__ bounds,
+                                                                  const u32* __restrict__ ids, size_t n,
+                                                                  u32 min_depth, int have_prev, u32 prev_id,
+                                                                  u32* __restrict__ counts, u64* __restrict__ block_sums,
+                                                                  BlockAux* __restrict__ aux, DevScalars* sc) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+    __shared__ u32 s_sum[ENC_THREADS / 64], s_dm[ENC_THREADS / 64], s_fl[ENC_THREADS / 64], s_er[ENC_THREADS / 64],
+        s_inv[ENC_THREADS / 64], s_ior[ENC_THREADS / 64], s_iand[ENC_THREADS / 64], s_imax[ENC_THREADS / 64];
+    __shared__ u64 s_kor[ENC_THREADS / 64], s_kand[ENC_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
+    u32 cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0;
+    u64 kor = 0, kand = ~0ull;
+    if (i < n) {
+        const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
+        const u32 id = ids[i];
+        u32 prev = prev_id;
+        bool hp = have_prev != 0;
+        if (i > 0) {
+            prev = ids[i - 1];
+            hp = true;
+        }
+        if (hp) {
+            if (id < prev) flags |= EXT_IDS_DECREASE | EXT_IDS_REPEAT;
+            else if (id == prev) flags |= EXT_IDS_REPEAT;
+        }
+        imax = id;
+        if (c.overflow && c.valid) err |= KERR_COUNT_OVERFLOW;
+        if (!c.valid) inv = 1;
+        cnt = c.count;
+        if (cnt > 0) {
+            dmask = 1u << c.depth;
+            ior = iand = id;
+            // OR / AND over this object's index values without enumerating its cells
+            u32 o[3] = {0, 0, 0}, a[3] = {0, 0, 0};
+#pragma unroll
+            for (u32 ax = 0; ax < DIM; ++ax) range_or_and(c.lo[ax], c.n[ax], o[ax], a[ax]);
+            const u32 up = AB - c.depth;
+            u64 mo = spread_bits<DIM>((u64)o[0] << up) | (spread_bits<DIM>((u64)o[1] << up) << 1);
+            u64 ma = spread_bits<DIM>((u64)a[0] << up) | (spread_bits<DIM>((u64)a[1] << up) << 1);
+            if (DIM == 3) {
+                mo |= spread_bits<DIM>((u64)o[2] << up) << 2;
+                ma |= spread_bits<DIM>((u64)a[2] << up) << 2;
+            }
+            kor = (mo << DB) | c.depth;
+            kand = (ma << DB) | c.depth;
+        }
+        counts[i] = cnt;
+    }
+    // workgroup reduction -> one BlockAux + one block sum per workgroup (no atomics)
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const u32 ws = wave_sum_u32(cnt), wd = wave_or_u32(dmask), wf = wave_or_u32(flags), we = wave_or_u32(err),
+              wi = wave_sum_u32(inv), wo = wave_or_u32(ior), wa = wave_and_u32(iand), wm = wave_max_u32(imax);
+    const u64 wko = wave_or_u64(kor), wka = wave_and_u64(kand);
+    if (lane == 0) {
+        s_sum[w] = ws; s_dm[w] = wd; s_fl[w] = wf; s_er[w] = we; s_inv[w] = wi; s_ior[w] = wo; s_iand[w] = wa; s_imax[w] = wm;
+        s_kor[w] = wko; s_kand[w] = wka;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 tot = 0;
+        BlockAux b;
+        b.key_or = 0; b.key_and = ~0ull; b.depth_mask = 0; b.flags = 0; b.err = 0; b.n_invalid = 0; b.id_or = 0;
+        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.pad_ = 0;
+        for (int k = 0; k < ENC_THREADS / 64; ++k) {
+            tot += s_sum[k];
+            b.key_or |= s_kor[k]; b.key_and &= s_kand[k]; b.depth_mask |= s_dm[k]; b.flags |= s_fl[k];
+            b.err |= s_er[k]; b.n_invalid += s_inv[k]; b.id_or |= s_ior[k]; b.id_and &= s_iand[k];
+            b.id_max = s_imax[k] > b.id_max ? s_imax[k] : b.id_max;
+        }
+        block_sums[blockIdx.x] = tot;
+        aux[blockIdx.x] = b;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
+                                                                 const u32* __restrict__ ids, size_t n, u32 min_depth,
+                                                                 const u32* __restrict__ counts,
+                                                                 const u64* __restrict__ block_offs,
+                                                                 u64* __restrict__ keys_out, u32* __restrict__ ids_out) {
+    constexpr u32 DIM = KT<KIND>::DIM;
+    __shared__ u32 s_ws[ENC_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
+    const u32 cnt = i < n ? counts[i] : 0u;
+    u32 total;
+    const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
+    if (cnt == 0) return;
+    const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
+    const u32 id = ids[i];
+    size_t pos = (size_t)block_offs[blockIdx.x] + excl;
+    if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
+        keys_out[pos] = 0ull;
+        ids_out[pos] = id;
+        return;
+    }
+    // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
+    for (u32 z = 0; z < c.n[2]; ++z)
+        for (u32 y = 0; y < c.n[1]; ++y)
+            for (u32 x = 0; x < c.n[0]; ++x) {
+                keys_out[pos] = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
+                ids_out[pos] = id;
+                ++pos;
+            }
+}
+
+// single-workgroup exclusive scan of per-block sums; folds the encode partials into *sc
+constexpr int SBS_THREADS = 1024;
+constexpr int SBS_ITEMS = 8;
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 lo = __shfl_up((u32)v, o, 64), hi = __shfl_up((u32)(v >> 32), o, 64);
+        if (lane >= o) v += ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+__global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __restrict__ sums, size_t n,
+                                                                     const BlockAux* __restrict__ aux, DevScalars* sc) {
+    __shared__ u64 s_wave[SBS_THREADS / 64];
+    __shared__ u64 s_carry;
+    __shared__ u64 r_kor[SBS_THREADS / 64], r_kand[SBS_THREADS / 64];
+    __shared__ u32 r_dm[SBS_THREADS / 64], r_fl[SBS_THREADS / 64], r_er[SBS_THREADS / 64], r_inv[SBS_THREADS / 64],
+        r_ior[SBS_THREADS / 64], r_iand[SBS_THREADS / 64], r_imax[SBS_THREADS / 64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n; base += (size_t)SBS_THREADS * SBS_ITEMS) {
+        const size_t i0 = base + (size_t)threadIdx.x * SBS_ITEMS;
+        u64 v[SBS_ITEMS], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < SBS_ITEMS; ++k) {
+            v[k] = (i0 + k) < n ? sums[i0 + k] : 0ull;
+            tsum += v[k];
+        }
+        const u64 incl = wave_incl_scan_u64(tsum);
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        u64 wbase = 0, tot = 0;
+        for (int k = 0; k < SBS_THREADS / 64; ++k) {
+            const u64 s = s_wave[k];
+            if (k < w) wbase += s;
+            tot += s;
+        }
+        const u64 carry = s_carry;
+        u64 run = carry + wbase + incl - tsum;
+#pragma unroll
+        for (int k = 0; k < SBS_ITEMS; ++k) {
+            if ((i0 + k) < n) sums[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (aux) {  // fold the per-workgroup partials of encode_count
+        u64 kor = 0, kand = ~0ull;
+        u32 dm = 0, fl = 0, er = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0;
+        for (size_t i = threadIdx.x; i < n; i += SBS_THREADS) {
+            const BlockAux b = aux[i];
+            kor |= b.key_or; kand &= b.key_and; dm |= b.depth_mask; fl |= b.flags; er |= b.err; inv += b.n_invalid;
+            ior |= b.id_or; iand &= b.id_and; imax = b.id_max > imax ? b.id_max : imax;
+        }
+        kor = wave_or_u64(kor); kand = wave_and_u64(kand); dm = wave_or_u32(dm); fl = wave_or_u32(fl);
+        er = wave_or_u32(er); inv = wave_sum_u32(inv); ior = wave_or_u32(ior); iand = wave_and_u32(iand);
+        imax = wave_max_u32(imax);
+        if (lane == 0) {
+            r_imax[w] = imax;
+            r_kor[w] = kor; r_kand[w] = kand; r_dm[w] = dm; r_fl[w] = fl; r_er[w] = er; r_inv[w] = inv;
+            r_ior[w] = ior; r_iand[w] = iand;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < SBS_THREADS / 64; ++k) {
+                sc->key_or |= r_kor[k]; sc->key_and &= r_kand[k]; sc->depth_mask |= r_dm[k]; sc->flags |= r_fl[k];
+                sc->err |= r_er[k]; sc->n_invalid += r_inv[k]; sc->id_or |= r_ior[k]; sc->id_and &= r_iand[k];
+                sc->id_max = r_imax[k] > sc->id_max ? r_imax[k] : sc->id_max;
+            }
+        }
+    }
+    if (threadIdx.x == 0) sc->total = s_carry;
+}
+
+// OR / AND / depth mask over an existing tree (set_tree, append_entries)
+template <int KIND>
+__global__ __launch_bounds__(256) void tree_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ ids,
+                                                          size_t m, DevScalars* sc) {
+    u64 kor = 0, kand = ~0ull;
+    u32 dm = 0, ior = 0, iand = 0xFFFFFFFFu;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
+        const u64 k = keys[i];
+        const u32 id = ids[i];
+        kor |= k; kand &= k; dm |= 1u << key_depth<KIND>(k); ior |= id; iand &= id;
+    }
+    kor = wave_or_u64(kor); kand = wave_and_u64(kand); dm = wave_or_u32(dm); ior = wave_or_u32(ior);
+    iand = wave_and_u32(iand);
+    if (lane_id() == 0) {
+        atomicOr(&sc->key_or, kor);
+        atomicAnd(&sc->key_and, kand);
+        atomicOr(&sc->depth_mask, dm);
+        atomicOr(&sc->id_or, ior);
+        atomicAnd(&sc->id_and, iand);
+    }
+}
+
+// =================================================================================================
+// radix sort: one-sweep LSD with decoupled look-back
+// =================================================================================================
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr u64 ST_FLAG_AGG = 1ull << 62;   // tile-local digit count published
+constexpr u64 ST_FLAG_PRE = 2ull << 62;   // inclusive prefix over tiles 0..t published
+constexpr u64 ST_VALUE = (1ull << 62) - 1ull;
+constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ void st_store(u64* p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 st_load(u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int HIST_THREADS = 512;
+constexpr int HIST_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __restrict__ keys,
+                                                                  const u32* __restrict__ vals, size_t n,
+                                                                  RadixPlan plan, u64* __restrict__ hist) {
+    __shared__ u32 h[RS_MAX_PASSES * RS_BINS];
+    const int np = plan.n_passes;
+    for (int j = threadIdx.x; j < np * RS_BINS; j += HIST_THREADS) h[j] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS) {
+        const u64 k = keys[i];
+        const u32 v = vals ? vals[i] : 0u;
+        for (int p = 0; p < np; ++p) {
+            const u32 dg = plan.from_val[p] ? ((v >> plan.shift[p]) & 0xFFu) : ((u32)(k >> plan.shift[p]) & 0xFFu);
+            atomicAdd(&h[p * RS_BINS + dg], 1u);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < np * RS_BINS; j += HIST_THREADS) {
+        const u32 c = h[j];
+        if (c) atomicAdd(&hist[j], (u64)c);
+    }
+}
+
+// per pass: exclusive scan of the 256 global digit counts -> bin_base
+__global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __restrict__ hist, u64* __restrict__ bin_base) {
+    __shared__ u64 s_wave[RS_BINS / 64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const u64 v = hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x];
+    const u64 incl = wave_incl_scan_u64(v);
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    u64 base = 0;
+    for (int k = 0; k < w; ++k) base += s_wave[k];
+    bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
+}
+
+template <typename T> struct StageBytes { static constexpr size_t value = sizeof(T); };
+struct NoVal {};
+template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
+
+// One radix pass over n records.  K: type carrying the digit (u64 index value / packed pair, or
+// u32 id); V: payload type (u32 id, u64 index value) or NoVal.  Stable.
+template <typename K, typename V>
+__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
+                                                                    const V* __restrict__ vals_in, V* __restrict__ vals_out,
+                                                                    size_t n, int shift, const u64* __restrict__ bin_base,
+                                                                    u64* status, u32* tile_counter, DevScalars* sc) {
+    constexpr bool HAS_VAL = StageBytes<V>::value != 0;
+    constexpr size_t STAGE = RS_TILE * (sizeof(K) > StageBytes<V>::value ? sizeof(K) : StageBytes<V>::value);
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE];
+    __shared__ u32 s_cnt[RS_WAVES][RS_BINS];
+    __shared__ u64 s_glob[RS_BINS];
+    __shared__ u32 s_ws[RS_WAVES];
+    __shared__ u32 s_tile;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);  // ticket: tile t only ever waits on tiles < t
+#pragma unroll
+    for (int j = tid; j < RS_WAVES * RS_BINS; j += RS_THREADS) (&s_cnt[0][0])[j] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    const size_t base = (size_t)tile * RS_TILE;
+    const u32 tile_n = (u32)((n - base) < (size_t)RS_TILE ? (n - base) : (size_t)RS_TILE);
+
+    // ---- load: wave w owns RS_ITEMS * 64 consecutive records, 64 per round (coalesced) ---------
+    K key[RS_ITEMS];
+    u32 packed[RS_ITEMS];  // digit | rank-in-(wave,digit) << 8
+    const u32 wbase = (u32)w * (64 * RS_ITEMS) + (u32)lane;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 li = wbase + (u32)r * 64u;
+        key[r] = li < tile_n ? keys_in[base + li] : (K)0;
+    }
+    // ---- rank: wave64 ballot match on the 8 digit bits; per-wave digit counters in LDS ----------
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 li = wbase + (u32)r * 64u;
+        const bool valid = li < tile_n;
+        const u32 dg = (u32)(key[r] >> shift) & 0xFFu;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(peers >> 32), __builtin_amdgcn_mbcnt_lo((u32)peers, 0u));
+        const u32 npeers = (u32)__popcll(peers);
+        u32 old = 0;
+        if (valid) old = s_cnt[w][dg];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) s_cnt[w][dg] = old + npeers;
+        __builtin_amdgcn_wave_barrier();
+        packed[r] = dg | ((old + below) << 8);
+    }
+    __syncthreads();
+
+    // ---- per digit: exclusive prefix over the waves, tile offset, look-back for the global base -
+    u32 total = 0;
+    if (tid < RS_BINS) {
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) {
+            const u32 c = s_cnt[ww][tid];
+            s_cnt[ww][tid] = total;
+            total += c;
+        }
+    }
+    u32 tile_total;
+    const u32 tile_off = block_excl_scan_u32<RS_THREADS>(total, s_ws, tile_total);
+    if (tid < RS_BINS) {
+        u64* my = status + (size_t)tile * RS_BINS + tid;
+        u64 excl = 0;
+        if (tile == 0) {
+            st_store(my, ST_FLAG_PRE | (u64)total);
+        } else {
+            st_store(my, ST_FLAG_AGG | (u64)total);
+            size_t p = tile;
+            u32 spins = 0;
+            while (p > 0) {
+                const u64 s = st_load(status + (p - 1) * RS_BINS + tid);
+                const u64 f = s >> 62;
+                if (f == 2) {
+                    excl += s & ST_VALUE;
+                    break;
+                } else if (f == 1) {
+                    excl += s & ST_VALUE;
+                    --p;
+                } else {
+                    if (++spins > LOOKBACK_SPIN_LIMIT) {  // never expected; keeps every wave finite
+                        atomicOr(&sc->err, KERR_LOOKBACK_TIMEOUT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            st_store(my, ST_FLAG_PRE | (excl + (u64)total));
+        }
+        s_glob[tid] = bin_base[tid] + excl - (u64)tile_off;
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) s_cnt[ww][tid] += tile_off;
+    }
+    __syncthreads();
+
+    // ---- keys: scatter into tile-sorted order in LDS, then stream out coalesced ------------------
+    K* stage_k = reinterpret_cast<K*>(s_stage);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 li = wbase + (u32)r * 64u;
+        if (li < tile_n) {
+            const u32 dg = packed[r] & 0xFFu;
+            const u32 pos = s_cnt[w][dg] + (packed[r] >> 8);
+            packed[r] = pos;  // keep the tile-local destination for the payload phase
+            stage_k[pos] = key[r];
+        }
+    }
+    __syncthreads();
+    u32 out_dg[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const u32 li = (u32)k * RS_THREADS + (u32)tid;
+        out_dg[k] = 0;
+        if (li < tile_n) {
+            const K kk = stage_k[li];
+            const u32 dg = (u32)(kk >> shift) & 0xFFu;
+            out_dg[k] = dg;
+            size_t g = (size_t)(s_glob[dg] + (u64)li);
+            if (g < n) keys_out[g] = kk;  // g < n always holds unless a look-back timed out
+        }
+    }
+    if constexpr (HAS_VAL) {
+        V val[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const u32 li = wbase + (u32)r * 64u;
+            if (li < tile_n) val[r] = vals_in[base + li];
+        }
+        __syncthreads();  // everyone is done reading stage_k
+        V* stage_v = reinterpret_cast<V*>(s_stage);
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const u32 li = wbase + (u32)r * 64u;
+            if (li < tile_n) stage_v[packed[r]] = val[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; ++k) {
+            const u32 li = (u32)k * RS_THREADS + (u32)tid;
+            if (li < tile_n) {
+                size_t g = (size_t)(s_glob[out_dg[k]] + (u64)li);
+                if (g < n) vals_out[g] = stage_v[li];
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// overlap scan: closed form of scan_impl (src/layer.rs:550-573)
+//
+// In a tree sorted by (index, id) the stack when entry i arrives is exactly the not-skipped
+// entries j < i whose cell contains cell i.  For every depth dd <= depth(i)
+// that occurs in the tree, those entries are the run of keys equal to
+//     T(dd) = (key_i & level_mask(dd)) | dd
+// that lies before i; runs are visited deepest first, so each search range ends where the
+// previous one began.  Emission order inside an entry (stack bottom -> top) is ascending j.
+// =================================================================================================
+template <int KIND, class Visit>
+__device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, size_t i, u64 key, u32 present, Visit&& visit) {
+    const u32 d = key_depth<KIND>(key);
+    u32 todo = present & (d >= 31u ? 0xFFFFFFFFu : ((2u << d) - 1u));
+    size_t end = i;  // every entry in [end, i) is a visited ancestor or irrelevant; search [0, end)
+    while (todo != 0 && end > 0) {
+        const u32 dd = 31u - (u32)__clz(todo);
+        todo &= ~(1u << dd);
+        const u64 target = (key & level_mask<KIND>(dd)) | (u64)dd;
+        size_t hi = end;  // first index in [0, end) whose key is > target
+        if (dd != d) {
+            // gallop backwards from `end`, then bisect
+            size_t hb = end, lb = 0, step = 1;
+            for (;;) {
+                if (step > hb) { lb = 0; break; }
+                const size_t p = hb - step;
+                if (keys[p] > target) { hb = p; step <<= 1; }
+                else { lb = p + 1; break; }
+            }
+            while (lb < hb) {
+                const size_t mid = lb + ((hb - lb) >> 1);
+                if (keys[mid] > target) hb = mid;
+                else lb = mid + 1;
+            }
+            hi = lb;
+        }
+        size_t j = hi;
+        while (j > 0 && keys[j - 1] == target) {
+            --j;
+            visit(j);
+        }
+        end = j;
+    }
+}
+
+// general mode only: skipped(i) <=> some ancestor carries the same id (src/layer.rs:563-565)
+template <int KIND>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_skipflags_kernel(ScanParams p) {
+    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    if (i >= p.m) return;
+    const u64 key = p.keys[i];
+    const u32 id = p.ids[i];
+    bool sk = false;
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) { sk = sk || (p.ids[j] == id); });
+    p.skip[i] = sk ? 1 : 0;
+}
+
+template <int KIND, bool GENERAL>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_count_kernel(ScanParams p, u32* __restrict__ counts,
+                                                                  u64* __restrict__ block_sums) {
+    __shared__ u32 s_sum[SCAN_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    u32 cnt = 0;
+    if (i < p.m) {
+        const u64 key = p.keys[i];
+        const bool active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        if (active) {
+            if (GENERAL) {
+                if (!p.skip[i]) walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) { cnt += p.skip[j] ? 0u : 1u; });
+            } else {
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t) { ++cnt; });
+            }
+        }
+        counts[i] = cnt;
+    }
+    const u32 ws = wave_sum_u32(cnt);
+    if (lane_id() == 0) s_sum[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (int k = 0; k < SCAN_THREADS / 64; ++k) t += s_sum[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+template <int KIND, bool GENERAL>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, const u32* __restrict__ counts,
+                                                                 const u64* __restrict__ block_offs,
+                                                                 u64* __restrict__ out) {
+    __shared__ u32 s_ws[SCAN_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    const u32 cnt = i < p.m ? counts[i] : 0u;
+    u32 total;
+    const u32 excl = block_excl_scan_u32<SCAN_THREADS>(cnt, s_ws, total);
+    if (cnt == 0) return;
+    const u64 key = p.keys[i];
+    const u64 hi_id = (u64)p.ids[i] << 32;
+    // ancestors are visited deepest-first / descending j; filling the slot backwards leaves them in
+    // ascending j = the reference's stack order (src/layer.rs:566-570)
+    size_t pos = (size_t)block_offs[blockIdx.x] + excl + cnt;
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) {
+        if (GENERAL && p.skip[j]) return;
+        --pos;
+        out[pos] = hi_id | (u64)p.ids[j];
+    });
+}
+
+// =================================================================================================
+// dedup: Vec::dedup on the sorted pair list (src/layer.rs:474, 517)
+// =================================================================================================
+__global__ __launch_bounds__(UQ_THREADS) void unique_count_kernel(const u64* __restrict__ a, size_t n,
+                                                                  u64* __restrict__ block_sums) {
+    __shared__ u32 s_sum[UQ_THREADS / 64];
+    const size_t base = (size_t)blockIdx.x * UQ_TILE;
+    u32 cnt = 0;
+#pragma unroll
+    for (int k = 0; k < UQ_ITEMS; ++k) {
+        const size_t i = base + (size_t)k * UQ_THREADS + threadIdx.x;
+        if (i < n) cnt += (i == 0 || a[i] != a[i - 1]) ? 1u : 0u;
+    }
+    const u32 ws = wave_sum_u32(cnt);
+    if (lane_id() == 0) s_sum[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (int k = 0; k < UQ_THREADS / 64; ++k) t += s_sum[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(UQ_THREADS) void unique_emit_kernel(const u64* __restrict__ a, size_t n,
+                                                                 const u64* __restrict__ block_offs,
+                                                                 uint2* __restrict__ out) {
+    __shared__ u32 s_ws[UQ_THREADS / 64];
+    const size_t base = (size_t)blockIdx.x * UQ_TILE;
+    size_t run = (size_t)block_offs[blockIdx.x];
+    // rounds of UQ_THREADS consecutive elements keep both the reads and the compacted writes coalesced
+    for (int k = 0; k < UQ_ITEMS; ++k) {
+        const size_t i = base + (size_t)k * UQ_THREADS + threadIdx.x;
+        u64 v = 0;
+        u32 keep = 0;
+        if (i < n) {
+            v = a[i];
+            keep = (i == 0 || v != a[i - 1]) ? 1u : 0u;
+        }
+        u32 total;
+        const u32 excl = block_excl_scan_u32<UQ_THREADS>(keep, s_ws, total);
+        if (keep) out[run + excl] = make_uint2((u32)(v >> 32), (u32)v);  // memory order: id, id_
+        run += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2* __restrict__ in, size_t n, u64* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint2 v = in[i];
+        out[i] = ((u64)v.x << 32) | (u64)v.y;
+    }
+}
+__global__ __launch_bounds__(256) void unpack_pairs_kernel(const u64* __restrict__ in, size_t n, uint2* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const u64 v = in[i];
+        out[i] = make_uint2((u32)(v >> 32), (u32)v);
+    }
+}
+
+inline unsigned grid_for(size_t n, int threads, unsigned cap) {
+    size_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+#define BP_DISPATCH_KIND(kind, EXPR)                 \
+    switch (kind) {                                  \
+        case 0: { constexpr int K = 0; EXPR; } break;  \
+        case 1: { constexpr int K = 1; EXPR; } break;  \
+        default: { constexpr int K = 2; EXPR; } break; \
+    }
+
+hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
+                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, uint32_t* counts,
+                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)enc_blocks(n);
+    BP_DISPATCH_KIND(kind, (encode_count_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, have_prev_id,
+                                                                                  prev_id, counts, block_sums, aux, sc)));
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
+                              uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
+                              uint64_t* keys_out, uint32_t* ids_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)enc_blocks(n);
+    BP_DISPATCH_KIND(kind, (encode_emit_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
+                                                                                 block_offs, (u64*)keys_out, ids_out)));
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
+                                  hipStream_t stream) {
+    scan_block_sums_kernel<<<1, SBS_THREADS, 0, stream>>>(sums, n, aux, sc);
+    return hipGetLastError();
+}
+
+hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, DevScalars* sc,
+                              hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    const unsigned g = grid_for(m, 256, 1024);
+    BP_DISPATCH_KIND(kind, (tree_reduce_kernel<K><<<g, 256, 0, stream>>>((const u64*)keys, ids, m, sc)));
+    return hipGetLastError();
+}
+
+RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned id_varying) {
+    RadixPlan plan;
+    plan.n_passes = 0;
+    for (int i = 0; i < RS_MAX_PASSES; ++i) plan.shift[i] = plan.from_val[i] = 0;
+    if (use_ids) {
+        unsigned v = id_varying;
+        while (v && plan.n_passes < RS_MAX_PASSES) {
+            const int s = __builtin_ctz(v);
+            plan.shift[plan.n_passes] = s;
+            plan.from_val[plan.n_passes] = 1;
+            ++plan.n_passes;
+            v = s + 8 >= 32 ? 0u : (v >> (s + 8)) << (s + 8);
+        }
+    }
+    unsigned long long v = key_varying;
+    while (v && plan.n_passes < RS_MAX_PASSES) {
+        const int s = __builtin_ctzll(v);
+        plan.shift[plan.n_passes] = s;
+        plan.from_val[plan.n_passes] = 0;
+        ++plan.n_passes;
+        v = s + 8 >= 64 ? 0ull : (v >> (s + 8)) << (s + 8);
+    }
+    return plan;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t radix_workspace_bytes(size_t n, int n_passes) {
+    const size_t np = (size_t)(n_passes > 0 ? n_passes : 1);
+    size_t b = 0;
+    b += np * RS_BINS * sizeof(u64);                      // hist
+    b += np * RS_BINS * sizeof(u64);                      // bin_base
+    b += align_up(np * sizeof(u32), 256);                 // tile counters
+    b += np * rs_tiles(n) * RS_BINS * sizeof(u64);        // status
+    return align_up(b, 256);
+}
+
+hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
+                      const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
+                      int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
+                      int class_hist, int class_sort) {
+    *result_buf = 0;
+    const int np = plan.n_passes;
+    if (n == 0 || np == 0) return hipSuccess;
+    if (radix_workspace_bytes(n, np) > workspace_bytes) return hipErrorInvalidValue;
+    unsigned char* ws = (unsigned char*)workspace;
+    u64* hist = (u64*)ws;
+    u64* bin_base = hist + (size_t)np * RS_BINS;
+    u32* counters = (u32*)(bin_base + (size_t)np * RS_BINS);
+    u64* status = (u64*)((unsigned char*)counters + align_up((size_t)np * sizeof(u32), 256));
+    const size_t tiles = rs_tiles(n);
+    hipError_t e;
+
+    if (mark) mark(mark_ctx, class_hist);
+    e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(n, np), stream);
+    if (e != hipSuccess) return e;
+    radix_hist_kernel<<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
+        (const u64*)keys0, vals0, n, plan, hist);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    radix_binbase_kernel<<<np, RS_BINS, 0, stream>>>(hist, bin_base);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (mark) mark(mark_ctx, -1);
+
+    u64* kb[2] = {(u64*)keys0, (u64*)keys1};
+    u32* vb[2] = {vals0, vals1};
+    int cur = 0;
+    for (int p = 0; p < np; ++p) {
+        if (mark) mark(mark_ctx, class_sort);  // one timed region per pass = per kernel launch
+        const u64* bb = bin_base + (size_t)p * RS_BINS;
+        u64* st = status + (size_t)p * tiles * RS_BINS;
+        u32* tc = counters + p;
+        if (!vals0) {
+            radix_onesweep_kernel<u64, NoVal><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
+                kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, plan.shift[p], bb, st, tc, sc);
+        } else if (plan.from_val[p]) {
+            radix_onesweep_kernel<u32, u64><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
+                vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc);
+        } else {
+            radix_onesweep_kernel<u64, u32><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
+                kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (mark) mark(mark_ctx, -1);
+        cur ^= 1;
+    }
+    *result_buf = cur;
+    return hipSuccess;
+}
+
+hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream) {
+    if (p.m == 0) return hipSuccess;
+    const unsigned g = (unsigned)scan_blocks(p.m);
+    BP_DISPATCH_KIND(kind, (scan_skipflags_kernel<K><<<g, SCAN_THREADS, 0, stream>>>(p)));
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_count(int kind, ScanParams p, uint32_t* counts, unsigned long long* block_sums,
+                             hipStream_t stream) {
+    if (p.m == 0) return hipSuccess;
+    const unsigned g = (unsigned)scan_blocks(p.m);
+    if (p.general) {
+        BP_DISPATCH_KIND(kind, (scan_count_kernel<K, true><<<g, SCAN_THREADS, 0, stream>>>(p, counts, block_sums)));
+    } else {
+        BP_DISPATCH_KIND(kind, (scan_count_kernel<K, false><<<g, SCAN_THREADS, 0, stream>>>(p, counts, block_sums)));
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, const unsigned long long* block_offs,
+                            uint64_t* pairs_out, hipStream_t stream) {
+    if (p.m == 0) return hipSuccess;
+    const unsigned g = (unsigned)scan_blocks(p.m);
+    if (p.general) {
+        BP_DISPATCH_KIND(kind, (scan_emit_kernel<K, true><<<g, SCAN_THREADS, 0, stream>>>(p, counts, block_offs, (u64*)pairs_out)));
+    } else {
+        BP_DISPATCH_KIND(kind, (scan_emit_kernel<K, false><<<g, SCAN_THREADS, 0, stream>>>(p, counts, block_offs, (u64*)pairs_out)));
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_unique_count(const uint64_t* sorted, size_t n, unsigned long long* block_sums, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unique_count_kernel<<<(unsigned)uq_blocks(n), UQ_THREADS, 0, stream>>>((const u64*)sorted, n, block_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned long long* block_offs,
+                              uint32_t* pairs_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unique_emit_kernel<<<(unsigned)uq_blocks(n), UQ_THREADS, 0, stream>>>((const u64*)sorted, n, block_offs, (uint2*)pairs_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_pairs(const uint32_t* pairs, size_t n, uint64_t* packed, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    pack_pairs_kernel<<<grid_for(n, 256, 4096), 256, 0, stream>>>((const uint2*)pairs, n, (u64*)packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_pairs(const uint64_t* packed, size_t n, uint32_t* pairs, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    unpack_pairs_kernel<<<grid_for(n, 256, 4096), 256, 0, stream>>>((const u64*)packed, n, (uint2*)pairs);
+    return hipGetLastError();
+}
+
+}  // namespace bp

@@ -1,0 +1,855 @@
+// bp_layer.hip -- the C ABI of include/bp_layer.h over the gfx950 kernels (host code only).
+//
+// One bp_layer owns: one HIP stream, the device-resident tree (SoA ping-pong buffers), all scan
+// temporaries, and pinned host mirrors for the host-visible views.  There is no CPU fallback:
+// every entry point fails with BP_ERR_NO_DEVICE / BP_ERR_HIP if the device path is unusable.
+#include "bp_layer.h"
+#include "bp_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace bp;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;  // bytes
+};
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct bp_layer {
+    int kind = BP_INDEX64_3D;
+    int device = 0;
+    uint32_t min_depth = 0;
+    hipStream_t stream = nullptr;
+
+    // persistent state: tree (src/layer.rs:49-50)
+    DevBuf keys[2], ids[2];
+    int cur = 0;
+    size_t m = 0;
+    bool sorted = true;
+
+    // facts about the tree that steer kernel selection (never change results)
+    bool have_ids = false;      // anything appended since the last clear
+    bool order_ok = true;       // equal keys are already id-ascending in current order
+    bool ids_distinct = true;   // no id occurs on two objects (skip rule cannot fire)
+    uint32_t max_id = 0;
+    uint64_t key_or = 0, key_and = ~0ull;
+    uint32_t id_or = 0, id_and = 0xFFFFFFFFu;
+    uint32_t depth_mask = 0;
+
+    // temporaries
+    DevBuf in_bounds, in_ids;           // staging for host inputs
+    DevBuf counts, block_sums, aux, skip;
+    DevBuf pairs[2];                    // packed raw pairs (ping-pong for the pair sort)
+    DevBuf out_pairs;                   // final interleaved (id, id_) list
+    DevBuf radix_ws;
+    DevBuf d_sc;                        // DevScalars
+    HostBuf h_sc, h_pairs, h_keys, h_ids, h_raw;
+    size_t n_raw = 0, n_pairs = 0;
+
+    bp_stats stats{};
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    int prof_open = -1;
+    hipEvent_t prof_open_ev = nullptr;
+    double prof_ms[BP_K_COUNT] = {0};
+    uint64_t prof_n[BP_K_COUNT] = {0};
+
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_last_global_error;
+
+int fail(bp_layer* L, int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (L) L->err = buf;
+    g_last_global_error = buf;
+    return code;
+}
+
+#define HIP_TRY(L, call)                                                    \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return fail((L), e__ == hipErrorOutOfMemory ? BP_ERR_OOM : BP_ERR_HIP, #call, e__); \
+    } while (0)
+
+#define BP_TRY(call)               \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != BP_OK) return rc__; \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int now = -1;
+        if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    }
+};
+
+// grow-only device buffer; preserve keeps the first keep_bytes bytes
+int ensure_dev(bp_layer* L, DevBuf& b, size_t bytes, size_t keep_bytes = 0) {
+    if (bytes <= b.cap) return BP_OK;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    want = (want + 255) / 256 * 256;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) {
+        // retry with the exact size before giving up
+        want = (bytes + 255) / 256 * 256;
+        e = hipMalloc(&q, want);
+        if (e != hipSuccess) return fail(L, BP_ERR_OOM, "hipMalloc", e);
+    }
+    if (keep_bytes && b.p) {
+        e = hipMemcpyAsync(q, b.p, keep_bytes, hipMemcpyDeviceToDevice, L->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+        if (e != hipSuccess) { (void)hipFree(q); return fail(L, BP_ERR_HIP, "grow copy", e); }
+    } else if (b.p) {
+        e = hipStreamSynchronize(L->stream);  // nothing in flight may still use the old block
+        if (e != hipSuccess) { (void)hipFree(q); return fail(L, BP_ERR_HIP, "hipStreamSynchronize", e); }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = q;
+    b.cap = want;
+    return BP_OK;
+}
+
+int ensure_host(bp_layer* L, HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return BP_OK;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(L, BP_ERR_OOM, "hipHostMalloc", e);
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = q;
+    b.cap = want;
+    return BP_OK;
+}
+
+void free_dev(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+void free_host(HostBuf& b) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// ---- profiling: HIP events on the layer's own stream ---------------------------------------------
+hipEvent_t prof_event(bp_layer* L) {
+    if (!L->prof_pool.empty()) {
+        hipEvent_t e = L->prof_pool.back();
+        L->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+// cls >= 0 opens a timed region of that class, cls < 0 closes the open one
+void prof_mark(void* ctx, int cls) {
+    bp_layer* L = (bp_layer*)ctx;
+    if (!L->prof_on) return;
+    if (cls >= 0) {
+        L->prof_open = cls;
+        L->prof_open_ev = prof_event(L);
+        if (L->prof_open_ev) (void)hipEventRecord(L->prof_open_ev, L->stream);
+    } else if (L->prof_open >= 0) {
+        hipEvent_t b = prof_event(L);
+        if (b && L->prof_open_ev) {
+            (void)hipEventRecord(b, L->stream);
+            L->prof_pending.push_back({L->prof_open, L->prof_open_ev, b});
+        }
+        L->prof_open = -1;
+        L->prof_open_ev = nullptr;
+    }
+}
+void prof_collect(bp_layer* L) {  // call after the stream has been synchronised
+    for (auto& r : L->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            L->prof_ms[r.cls] += ms;
+            L->prof_n[r.cls] += 1;
+        }
+        L->prof_pool.push_back(r.a);
+        L->prof_pool.push_back(r.b);
+    }
+    L->prof_pending.clear();
+}
+struct ProfScope {
+    bp_layer* L;
+    ProfScope(bp_layer* l, int cls) : L(l) { prof_mark(L, cls); }
+    ~ProfScope() { prof_mark(L, -1); }
+};
+
+int sync_stream(bp_layer* L) {
+    HIP_TRY(L, hipStreamSynchronize(L->stream));
+    prof_collect(L);
+    return BP_OK;
+}
+
+// ---- device scalars ---------------------------------------------------------------------------------
+int sc_reset(bp_layer* L) {  // neutral elements for every reduction
+    DevScalars* h = (DevScalars*)L->h_sc.p;
+    std::memset(h, 0, sizeof(DevScalars));
+    h->key_and = ~0ull;
+    h->id_and = 0xFFFFFFFFu;
+    HIP_TRY(L, hipMemcpyAsync(L->d_sc.p, h, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
+    return BP_OK;
+}
+int sc_fetch(bp_layer* L, DevScalars* out) {  // D2H + sync
+    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+    BP_TRY(sync_stream(L));
+    *out = *(DevScalars*)L->h_sc.p;
+    if (out->err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+    if (out->err & KERR_COUNT_OVERFLOW)
+        return fail(L, BP_ERR_TOO_LARGE, "an object expands to more than 2^20 cells (min_depth too high for its size)");
+    return BP_OK;
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory is reported as an error by some runtimes
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+void reset_tree_facts(bp_layer* L) {
+    L->have_ids = false;
+    L->order_ok = true;
+    L->ids_distinct = true;
+    L->max_id = 0;
+    L->key_or = 0; L->key_and = ~0ull;
+    L->id_or = 0; L->id_and = 0xFFFFFFFFu;
+    L->depth_mask = 0;
+}
+
+uint64_t* cur_keys(bp_layer* L) { return (uint64_t*)L->keys[L->cur].p; }
+uint32_t* cur_ids(bp_layer* L) { return (uint32_t*)L->ids[L->cur].p; }
+
+int ensure_tree_capacity(bp_layer* L, size_t entries) {
+    BP_TRY(ensure_dev(L, L->keys[L->cur], entries * sizeof(uint64_t), L->m * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->ids[L->cur], entries * sizeof(uint32_t), L->m * sizeof(uint32_t)));
+    return BP_OK;
+}
+
+// ---- extend -------------------------------------------------------------------------------------------
+int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const float* d_bounds,
+                  const uint32_t* d_ids, size_t n) {
+    if (n == 0) return BP_OK;
+    if (n > 0x7FFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "extend: more than 2^31-1 objects in one call");
+    const KindInfo ki = kind_info(L->kind);
+    SysBounds sb;
+    for (uint32_t a = 0; a < 3; ++a) {
+        sb.mn[a] = a < ki.dim ? sys_min[a] : 0.f;
+        sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
+    }
+    const size_t nb = enc_blocks(n);
+    BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
+    BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_ENCODE);
+        HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, L->have_ids ? 1 : 0, L->max_id,
+                                       (uint32_t*)L->counts.p, (unsigned long long*)L->block_sums.p,
+                                       (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p,
+                                          (DevScalars*)L->d_sc.p, L->stream));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    const size_t add = (size_t)sc.total;
+    L->stats.objects_invalid += sc.n_invalid;
+    L->stats.objects_valid += n - sc.n_invalid;
+    // ordering facts are judged on every id handed in, valid or not (conservative)
+    if (sc.flags & EXT_IDS_DECREASE) L->order_ok = false;
+    if (sc.flags & EXT_IDS_REPEAT) L->ids_distinct = false;
+    L->have_ids = true;
+    L->max_id = std::max(L->max_id, sc.id_max);
+    if (add == 0) return BP_OK;
+    BP_TRY(ensure_tree_capacity(L, L->m + add));
+    {
+        ProfScope ps(L, BP_K_ENCODE);
+        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
+                                      (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
+                                      L->stream));
+    }
+    BP_TRY(sync_stream(L));
+    L->m += add;
+    L->sorted = false;  // src/layer.rs:119 (at least one valid object was appended)
+    L->key_or |= sc.key_or; L->key_and &= sc.key_and;
+    L->id_or |= sc.id_or; L->id_and &= sc.id_and;
+    L->depth_mask |= sc.depth_mask;
+    L->stats.entries = L->m;
+    return BP_OK;
+}
+
+// fold facts about raw entries appended from outside (merge / set_tree / append_entries)
+int absorb_raw_entries(bp_layer* L, const uint64_t* d_keys, const uint32_t* d_ids, size_t m) {
+    if (m == 0) return BP_OK;
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_tree_reduce(L->kind, d_keys, d_ids, m, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    L->key_or |= sc.key_or; L->key_and &= sc.key_and;
+    L->id_or |= sc.id_or; L->id_and &= sc.id_and;
+    L->depth_mask |= sc.depth_mask;
+    // nothing is known about the order or uniqueness of foreign ids: take the general paths
+    L->order_ok = false;
+    L->ids_distinct = false;
+    L->have_ids = true;
+    L->max_id = 0xFFFFFFFFu;
+    return BP_OK;
+}
+
+// ---- sort -----------------------------------------------------------------------------------------------
+int sort_tree(bp_layer* L) {
+    if (L->sorted) return BP_OK;  // src/layer.rs:148, 161
+    if (L->m > 1) {
+        const RadixPlan plan = make_radix_plan(L->key_or ^ L->key_and, L->order_ok ? 0 : 1, L->id_or ^ L->id_and);
+        L->stats.tree_sort_passes = (uint32_t)plan.n_passes;
+        if (plan.n_passes > 0) {
+            const int other = L->cur ^ 1;
+            BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
+            BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
+            const size_t wsb = radix_workspace_bytes(L->m, plan.n_passes);
+            BP_TRY(ensure_dev(L, L->radix_ws, wsb));
+            BP_TRY(sc_reset(L));
+            int res = 0;
+            uint64_t* k0 = (uint64_t*)L->keys[L->cur].p; uint64_t* k1 = (uint64_t*)L->keys[other].p;
+            uint32_t* v0 = (uint32_t*)L->ids[L->cur].p;  uint32_t* v1 = (uint32_t*)L->ids[other].p;
+            HIP_TRY(L, radix_sort(k0, k1, v0, v1, L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res,
+                                  L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT));
+            DevScalars sc;
+            BP_TRY(sc_fetch(L, &sc));
+            if (res) L->cur = other;
+        }
+    }
+    L->sorted = true;
+    L->order_ok = true;  // a (key, id)-sorted array satisfies the stable-sort precondition again
+    return BP_OK;
+}
+
+// ---- scan ------------------------------------------------------------------------------------------------
+// produces the raw pair stream (packed id << 32 | id_) in L->pairs[0], in scan_impl emission order
+int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
+    BP_TRY(sort_tree(L));  // src/layer.rs:465, 499
+    L->n_raw = 0;
+    if (L->m == 0) return BP_OK;
+    const size_t nb = scan_blocks(L->m);
+    BP_TRY(ensure_dev(L, L->counts, L->m * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
+    ScanParams p;
+    p.keys = (const unsigned long long*)cur_keys(L);
+    p.ids = cur_ids(L);
+    p.m = L->m;
+    p.depth_mask = L->depth_mask;
+    p.coarse_depth = coarse_depth;
+    p.emit_coarse = emit_coarse;
+    p.general = L->ids_distinct ? 0 : 1;
+    p.skip = nullptr;
+    if (p.general) {
+        BP_TRY(ensure_dev(L, L->skip, L->m));
+        p.skip = (uint8_t*)L->skip.p;
+    }
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_SCAN_COUNT);
+        if (p.general) HIP_TRY(L, launch_scan_skipflags(L->kind, p, L->stream));
+        HIP_TRY(L, launch_scan_count(L->kind, p, (uint32_t*)L->counts.p, (unsigned long long*)L->block_sums.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, nullptr, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    const size_t n_raw = (size_t)sc.total;
+    L->n_raw = n_raw;
+    L->stats.raw_pairs = n_raw;
+    if (n_raw == 0) return BP_OK;
+    BP_TRY(ensure_dev(L, L->pairs[0], n_raw * sizeof(uint64_t)));
+    {
+        ProfScope ps(L, BP_K_SCAN_EMIT);
+        HIP_TRY(L, launch_scan_emit(L->kind, p, (const uint32_t*)L->counts.p, (const unsigned long long*)L->block_sums.p,
+                                    (uint64_t*)L->pairs[0].p, L->stream));
+    }
+    return BP_OK;
+}
+
+// sort + dedup of n packed pairs sitting in L->pairs[0] -> L->out_pairs (interleaved), L->n_pairs
+int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying) {
+    L->n_pairs = 0;
+    L->stats.pairs = 0;
+    if (n == 0) return BP_OK;
+    const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
+    const RadixPlan plan = make_radix_plan(varying, 0, 0);
+    L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
+    int res = 0;
+    if (plan.n_passes > 0 && n > 1) {
+        BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+        const size_t wsb = radix_workspace_bytes(n, plan.n_passes);
+        BP_TRY(ensure_dev(L, L->radix_ws, wsb));
+        BP_TRY(sc_reset(L));
+        HIP_TRY(L, radix_sort((uint64_t*)L->pairs[0].p, (uint64_t*)L->pairs[1].p, nullptr, nullptr, n, plan, L->radix_ws.p,
+                              L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST,
+                              BP_K_PAIR_SORT));
+    } else {
+        BP_TRY(sc_reset(L));
+    }
+    const uint64_t* sorted = (const uint64_t*)L->pairs[res].p;
+    const size_t nb = uq_blocks(n);
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_unique_count(sorted, n, (unsigned long long*)L->block_sums.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, nullptr, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));  // also surfaces a look-back timeout of the pair sort
+    const size_t np = (size_t)sc.total;
+    BP_TRY(ensure_dev(L, L->out_pairs, np * 2 * sizeof(uint32_t)));
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_unique_emit(sorted, n, (const unsigned long long*)L->block_sums.p, (uint32_t*)L->out_pairs.p, L->stream));
+    }
+    BP_TRY(sync_stream(L));
+    L->n_pairs = np;
+    L->stats.pairs = np;
+    return BP_OK;
+}
+
+int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
+    BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
+    BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and));
+    if (L->n_raw == 0) BP_TRY(sync_stream(L));
+    return BP_OK;
+}
+
+int pairs_to_host(bp_layer* L, const uint32_t** pairs, size_t* n_pairs) {
+    const size_t bytes = L->n_pairs * 2 * sizeof(uint32_t);
+    BP_TRY(ensure_host(L, L->h_pairs, std::max<size_t>(bytes, 8)));
+    if (bytes) {
+        HIP_TRY(L, hipMemcpyAsync(L->h_pairs.p, L->out_pairs.p, bytes, hipMemcpyDeviceToHost, L->stream));
+        BP_TRY(sync_stream(L));
+    }
+    *pairs = (const uint32_t*)L->h_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+bool valid_kind(int k) { return k >= 0 && k <= 2; }
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+const char* bp_version(void) { return "broadphase_amd 0.1 gfx950"; }
+
+const char* bp_status_string(int status) {
+    switch (status) {
+        case BP_OK: return "BP_OK";
+        case BP_ERR_INVALID_ARG: return "BP_ERR_INVALID_ARG";
+        case BP_ERR_NO_DEVICE: return "BP_ERR_NO_DEVICE";
+        case BP_ERR_HIP: return "BP_ERR_HIP";
+        case BP_ERR_OOM: return "BP_ERR_OOM";
+        case BP_ERR_TOO_LARGE: return "BP_ERR_TOO_LARGE";
+        case BP_ERR_KERNEL: return "BP_ERR_KERNEL";
+        case BP_ERR_COMM: return "BP_ERR_COMM";
+        default: return "BP_ERR_UNKNOWN";
+    }
+}
+
+const char* bp_layer_last_error(const bp_layer_t* layer) {
+    return layer ? layer->err.c_str() : g_last_global_error.c_str();
+}
+
+int bp_layer_create(bp_layer_t** out, int index_kind, uint32_t min_depth, size_t index_capacity,
+                    size_t collision_capacity, int device) {
+    if (!out || !valid_kind(index_kind)) return fail(nullptr, BP_ERR_INVALID_ARG, "bp_layer_create: bad argument");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(nullptr, BP_ERR_NO_DEVICE, "no HIP device available (no CPU fallback exists)", e);
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return fail(nullptr, BP_ERR_NO_DEVICE, "hipGetDevice failed");
+    }
+    if (device >= count) return fail(nullptr, BP_ERR_INVALID_ARG, "bp_layer_create: device ordinal out of range");
+    bp_layer* L = new (std::nothrow) bp_layer();
+    if (!L) return fail(nullptr, BP_ERR_OOM, "out of host memory");
+    L->kind = index_kind;
+    L->min_depth = min_depth;
+    L->device = device;
+    DeviceGuard g(device);
+    if (!g.ok) { delete L; return fail(nullptr, BP_ERR_NO_DEVICE, "hipSetDevice failed"); }
+    e = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete L; return fail(nullptr, BP_ERR_HIP, "hipStreamCreateWithFlags", e); }
+    int rc = ensure_dev(L, L->d_sc, sizeof(DevScalars));
+    if (rc == BP_OK) rc = ensure_host(L, L->h_sc, sizeof(DevScalars));
+    if (rc == BP_OK && index_capacity) {
+        rc = ensure_dev(L, L->keys[0], index_capacity * sizeof(uint64_t));
+        if (rc == BP_OK) rc = ensure_dev(L, L->ids[0], index_capacity * sizeof(uint32_t));
+    }
+    if (rc == BP_OK && collision_capacity) rc = ensure_dev(L, L->out_pairs, collision_capacity * 2 * sizeof(uint32_t));
+    if (rc != BP_OK) {
+        g_last_global_error = L->err;
+        bp_layer_destroy(L);
+        return rc;
+    }
+    *out = L;
+    return BP_OK;
+}
+
+int bp_layer_destroy(bp_layer_t* L) {
+    if (!L) return BP_OK;
+    DeviceGuard g(L->device);
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
+    prof_collect(L);
+    for (auto e : L->prof_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { free_dev(L->keys[i]); free_dev(L->ids[i]); free_dev(L->pairs[i]); }
+    free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
+    free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
+    free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    delete L;
+    return BP_OK;
+}
+
+int bp_layer_clear(bp_layer_t* L) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    L->m = 0;
+    L->sorted = true;  // src/layer.rs:84-88
+    reset_tree_facts(L);
+    L->stats.entries = 0;
+    L->stats.objects_valid = L->stats.objects_invalid = 0;
+    return BP_OK;
+}
+
+int bp_layer_extend_device(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* d_bounds,
+                           const uint32_t* d_ids, size_t n) {
+    if (!L || !sys_min || !sys_max || (n && (!d_bounds || !d_ids))) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_extend: null argument");
+    DeviceGuard g(L->device);
+    return extend_device(L, sys_min, sys_max, d_bounds, d_ids, n);
+}
+
+int bp_layer_extend_host(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* bounds,
+                         const uint32_t* ids, size_t n) {
+    if (!L || !sys_min || !sys_max || (n && (!bounds || !ids))) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_extend: null argument");
+    if (n == 0) return BP_OK;
+    DeviceGuard g(L->device);
+    const KindInfo ki = kind_info(L->kind);
+    const size_t bb = n * 2 * ki.dim * sizeof(float), ib = n * sizeof(uint32_t);
+    BP_TRY(ensure_dev(L, L->in_bounds, bb));
+    BP_TRY(ensure_dev(L, L->in_ids, ib));
+    HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, bounds, bb, hipMemcpyHostToDevice, L->stream));
+    HIP_TRY(L, hipMemcpyAsync(L->in_ids.p, ids, ib, hipMemcpyHostToDevice, L->stream));
+    return extend_device(L, sys_min, sys_max, (const float*)L->in_bounds.p, (const uint32_t*)L->in_ids.p, n);
+}
+
+int bp_layer_extend(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* bounds,
+                    const uint32_t* ids, size_t n) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    if (n == 0) return BP_OK;
+    DeviceGuard g(L->device);
+    const bool db = is_device_ptr(bounds), di = is_device_ptr(ids);
+    if (db != di) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_extend: bounds and ids must both be host or both be device pointers");
+    return db ? bp_layer_extend_device(L, sys_min, sys_max, bounds, ids, n)
+              : bp_layer_extend_host(L, sys_min, sys_max, bounds, ids, n);
+}
+
+int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t* ids, size_t m) {
+    if (!L || (m && (!keys || !ids))) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_append_entries: null argument");
+    if (m == 0) return BP_OK;
+    DeviceGuard g(L->device);
+    const bool dk = is_device_ptr(keys), di = is_device_ptr(ids);
+    if (dk != di) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_append_entries: keys and ids must live in the same memory space");
+    BP_TRY(ensure_tree_capacity(L, L->m + m));
+    const hipMemcpyKind kind = dk ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, keys, m * sizeof(uint64_t), kind, L->stream));
+    HIP_TRY(L, hipMemcpyAsync(cur_ids(L) + L->m, ids, m * sizeof(uint32_t), kind, L->stream));
+    BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
+    L->m += m;
+    L->sorted = false;
+    L->stats.entries = L->m;
+    return BP_OK;
+}
+
+int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
+    if (!L || !other) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_merge: null argument");
+    if (L->kind != other->kind) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_merge: index kinds differ");
+    if (L->device != other->device) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_merge: layers live on different devices");
+    DeviceGuard g(L->device);
+    if (other->min_depth < L->min_depth) {  // src/layer.rs:131-134 (warn! + lower)
+        fprintf(stderr, "[broadphase_amd] warning: merging layer of lesser min_depth (lhs: %u, rhs: %u)\n", L->min_depth,
+                other->min_depth);
+        L->min_depth = other->min_depth;
+    }
+    const size_t m = other->m;
+    if (m) {
+        (void)hipStreamSynchronize(other->stream);
+        BP_TRY(ensure_tree_capacity(L, L->m + m));
+        const int oc = other->cur;
+        HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, other->keys[oc].p, m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(cur_ids(L) + L->m, other->ids[oc].p, m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        BP_TRY(sync_stream(L));
+        // facts: the union keeps whatever both sides can still prove
+        const bool was_empty = (L->m == 0);
+        L->key_or |= other->key_or; L->key_and &= other->key_and;
+        L->id_or |= other->id_or; L->id_and &= other->id_and;
+        L->depth_mask |= other->depth_mask;
+        if (was_empty) {
+            L->order_ok = other->order_ok; L->ids_distinct = other->ids_distinct; L->max_id = other->max_id;
+            L->have_ids = other->have_ids;
+        } else {
+            L->order_ok = false;
+            L->ids_distinct = false;
+            L->max_id = std::max(L->max_id, other->max_id);
+            L->have_ids = true;
+        }
+        L->m += m;
+    }
+    L->sorted = false;  // unconditional: src/layer.rs:137
+    L->stats.entries = L->m;
+    return BP_OK;
+}
+
+int bp_layer_sort(bp_layer_t* L) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    DeviceGuard g(L->device);
+    return sort_tree(L);
+}
+int bp_layer_par_sort(bp_layer_t* L) { return bp_layer_sort(L); }
+
+int bp_layer_scan_device(bp_layer_t* L, const uint32_t** d_pairs, size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_device(L, 0, 1));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_scan_shard_device(bp_layer_t* L, uint32_t coarse_depth, int emit_coarse, const uint32_t** d_pairs,
+                               size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_shard: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_device(L, coarse_depth, emit_coarse));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_scan(bp_layer_t* L, const uint32_t** pairs, size_t* n_pairs) {
+    if (!L || !pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_device(L, 0, 1));
+    return pairs_to_host(L, pairs, n_pairs);
+}
+int bp_layer_par_scan(bp_layer_t* L, const uint32_t** pairs, size_t* n_pairs) { return bp_layer_scan(L, pairs, n_pairs); }
+
+int bp_layer_scan_raw(bp_layer_t* L, const uint32_t** pairs, size_t* n_raw) {
+    if (!L || !pairs || !n_raw) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_raw: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_raw_device(L, 0, 1));
+    const size_t n = L->n_raw;
+    BP_TRY(ensure_host(L, L->h_raw, std::max<size_t>(n * 2 * sizeof(uint32_t), 8)));
+    if (n) {
+        // unpack into the (not yet needed) second pair buffer as interleaved u32, then copy out
+        BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+        HIP_TRY(L, launch_unpack_pairs((const uint64_t*)L->pairs[0].p, n, (uint32_t*)L->pairs[1].p, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, L->pairs[1].p, n * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+    }
+    BP_TRY(sync_stream(L));
+    *pairs = (const uint32_t*)L->h_raw.p;
+    *n_raw = n;
+    return BP_OK;
+}
+
+int bp_layer_scan_filtered(bp_layer_t* L, bp_filter_fn filter, void* user, const uint32_t** pairs, size_t* n_pairs) {
+    if (!L || !pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered: null argument");
+    if (!filter) return bp_layer_scan(L, pairs, n_pairs);
+    DeviceGuard g(L->device);
+    const uint32_t* raw = nullptr;
+    size_t n = 0;
+    BP_TRY(bp_layer_scan_raw(L, &raw, &n));
+    // the filter runs on the host over the raw stream, in the reference's call order (src/layer.rs:566-570)
+    uint32_t* w = (uint32_t*)L->h_raw.p;
+    size_t kept = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t a = raw[2 * i], b = raw[2 * i + 1];
+        if (filter(a, b, user)) {
+            w[2 * kept] = a;
+            w[2 * kept + 1] = b;
+            ++kept;
+        }
+    }
+    if (kept) {
+        BP_TRY(ensure_dev(L, L->pairs[1], kept * sizeof(uint64_t)));
+        HIP_TRY(L, hipMemcpyAsync(L->pairs[1].p, w, kept * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, L->stream));
+        BP_TRY(ensure_dev(L, L->pairs[0], kept * sizeof(uint64_t)));
+        HIP_TRY(L, launch_pack_pairs((const uint32_t*)L->pairs[1].p, kept, (uint64_t*)L->pairs[0].p, L->stream));
+    }
+    L->n_raw = kept;
+    BP_TRY(sort_unique_pairs(L, kept, L->id_or ^ L->id_and));
+    if (kept == 0) BP_TRY(sync_stream(L));
+    return pairs_to_host(L, pairs, n_pairs);
+}
+int bp_layer_par_scan_filtered(bp_layer_t* L, bp_filter_fn filter, void* user, const uint32_t** pairs, size_t* n_pairs) {
+    return bp_layer_scan_filtered(L, filter, user, pairs, n_pairs);
+}
+
+int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in, size_t n, const uint32_t** d_pairs,
+                                      size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs || (n && !d_pairs_in)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_unique_pairs: null argument");
+    DeviceGuard g(L->device);
+    if (n) {
+        BP_TRY(ensure_dev(L, L->pairs[0], n * sizeof(uint64_t)));
+        HIP_TRY(L, launch_pack_pairs(d_pairs_in, n, (uint64_t*)L->pairs[0].p, L->stream));
+    }
+    L->n_raw = n;
+    BP_TRY(sort_unique_pairs(L, n, 0xFFFFFFFFu));  // nothing is known about foreign ids: all 64 bits vary
+    if (n == 0) BP_TRY(sync_stream(L));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_tree_device(bp_layer_t* L, const uint64_t** d_keys, const uint32_t** d_ids, size_t* m, int* sorted) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    if (d_keys) *d_keys = cur_keys(L);
+    if (d_ids) *d_ids = cur_ids(L);
+    if (m) *m = L->m;
+    if (sorted) *sorted = L->sorted ? 1 : 0;
+    return BP_OK;
+}
+
+int bp_layer_tree(bp_layer_t* L, const uint64_t** keys, const uint32_t** ids, size_t* m, int* sorted) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    DeviceGuard g(L->device);
+    BP_TRY(ensure_host(L, L->h_keys, std::max<size_t>(L->m * sizeof(uint64_t), 8)));
+    BP_TRY(ensure_host(L, L->h_ids, std::max<size_t>(L->m * sizeof(uint32_t), 8)));
+    if (L->m) {
+        HIP_TRY(L, hipMemcpyAsync(L->h_keys.p, cur_keys(L), L->m * sizeof(uint64_t), hipMemcpyDeviceToHost, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(L->h_ids.p, cur_ids(L), L->m * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+        BP_TRY(sync_stream(L));
+    }
+    if (keys) *keys = (const uint64_t*)L->h_keys.p;
+    if (ids) *ids = (const uint32_t*)L->h_ids.p;
+    if (m) *m = L->m;
+    if (sorted) *sorted = L->sorted ? 1 : 0;
+    return BP_OK;
+}
+
+int bp_layer_set_tree(bp_layer_t* L, uint32_t min_depth, const uint64_t* keys, const uint32_t* ids, size_t m, int sorted) {
+    if (!L || (m && (!keys || !ids))) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_set_tree: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(bp_layer_clear(L));
+    L->min_depth = min_depth;
+    if (m) BP_TRY(bp_layer_append_entries(L, keys, ids, m));
+    L->sorted = sorted != 0;
+    if (L->sorted) L->order_ok = true;
+    return BP_OK;
+}
+
+int bp_layer_clone(const bp_layer_t* src, bp_layer_t** out) {
+    if (!src || !out) return BP_ERR_INVALID_ARG;
+    BP_TRY(bp_layer_create(out, src->kind, src->min_depth, src->m, 0, src->device));
+    bp_layer* L = *out;
+    DeviceGuard g(L->device);
+    if (src->m) {
+        (void)hipStreamSynchronize(src->stream);
+        HIP_TRY(L, hipMemcpyAsync(L->keys[0].p, src->keys[src->cur].p, src->m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(L->ids[0].p, src->ids[src->cur].p, src->m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        BP_TRY(sync_stream(L));
+    }
+    L->m = src->m; L->sorted = src->sorted;
+    L->have_ids = src->have_ids; L->order_ok = src->order_ok; L->ids_distinct = src->ids_distinct; L->max_id = src->max_id;
+    L->key_or = src->key_or; L->key_and = src->key_and; L->id_or = src->id_or; L->id_and = src->id_and;
+    L->depth_mask = src->depth_mask;
+    L->stats.entries = L->m;
+    return BP_OK;
+}
+
+int bp_layer_equals(const bp_layer_t* a, const bp_layer_t* b, int* equal) {
+    if (!a || !b || !equal) return BP_ERR_INVALID_ARG;
+    *equal = 0;
+    if (a->kind != b->kind || a->min_depth != b->min_depth || a->m != b->m || a->sorted != b->sorted) return BP_OK;
+    if (a->m == 0) { *equal = 1; return BP_OK; }
+    const uint64_t *ka, *kb;
+    const uint32_t *ia, *ib;
+    size_t m;
+    BP_TRY(bp_layer_tree((bp_layer_t*)a, &ka, &ia, &m, nullptr));
+    BP_TRY(bp_layer_tree((bp_layer_t*)b, &kb, &ib, &m, nullptr));
+    *equal = (std::memcmp(ka, kb, m * sizeof(uint64_t)) == 0 && std::memcmp(ia, ib, m * sizeof(uint32_t)) == 0) ? 1 : 0;
+    return BP_OK;
+}
+
+int bp_layer_len(const bp_layer_t* L, size_t* m) { if (!L || !m) return BP_ERR_INVALID_ARG; *m = L->m; return BP_OK; }
+int bp_layer_is_sorted(const bp_layer_t* L, int* s) { if (!L || !s) return BP_ERR_INVALID_ARG; *s = L->sorted ? 1 : 0; return BP_OK; }
+int bp_layer_min_depth(const bp_layer_t* L, uint32_t* d) { if (!L || !d) return BP_ERR_INVALID_ARG; *d = L->min_depth; return BP_OK; }
+int bp_layer_index_kind(const bp_layer_t* L, int* k) { if (!L || !k) return BP_ERR_INVALID_ARG; *k = L->kind; return BP_OK; }
+int bp_layer_device(const bp_layer_t* L, int* d) { if (!L || !d) return BP_ERR_INVALID_ARG; *d = L->device; return BP_OK; }
+
+int bp_layer_stats(const bp_layer_t* L, bp_stats* out) {
+    if (!L || !out) return BP_ERR_INVALID_ARG;
+    *out = L->stats;
+    out->entries = L->m;
+    out->depth_mask = L->depth_mask;
+    out->flags = (L->order_ok ? 1u : 0u) | (L->ids_distinct ? 2u : 0u);
+    return BP_OK;
+}
+
+int bp_layer_profile_enable(bp_layer_t* L, int on) { if (!L) return BP_ERR_INVALID_ARG; L->prof_on = on != 0; return BP_OK; }
+int bp_layer_profile_reset(bp_layer_t* L) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    for (int i = 0; i < BP_K_COUNT; ++i) { L->prof_ms[i] = 0; L->prof_n[i] = 0; }
+    return BP_OK;
+}
+int bp_layer_profile_get(bp_layer_t* L, int cls, double* total_ms, uint64_t* launches) {
+    if (!L || cls < 0 || cls >= BP_K_COUNT) return BP_ERR_INVALID_ARG;
+    if (total_ms) *total_ms = L->prof_ms[cls];
+    if (launches) *launches = L->prof_n[cls];
+    return BP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,427 @@
+"""ctypes mirror of the reference's `Layer<Index, ID>` / `LayerBuilder` (src/layer.rs:42-68, 619-696)
+over the C ABI of include/bp_layer.h.  Same method names, argument meaning and error behaviour:
+out-of-bounds objects are skipped silently, results are borrowed until the next mutating call,
+`par_*` are aliases of the serial names (one device implementation).
+
+numpy arrays are host inputs; anything exposing `data_ptr()` and `is_cuda` (a torch tensor on the
+GPU) is passed through as a device pointer without a copy.
+"""
+import ctypes as C
+import os
+import subprocess
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libbroadphase_amd.so")
+
+Bounds = namedtuple("Bounds", ["min", "max"])  # src/geom.rs:84-87 (inclusive)
+
+
+class _IndexKind:
+    def __init__(self, name, kind, dim, bits, depth_bits, axis_bits):
+        self.name, self.kind, self.dim, self.bits = name, kind, dim, bits
+        self.depth_bits, self.axis_bits = depth_bits, axis_bits
+
+    def __repr__(self):
+        return self.name
+
+
+# src/index.rs:293-295
+Index32_2D = _IndexKind("Index32_2D", 0, 2, 32, 4, 14)
+Index64_2D = _IndexKind("Index64_2D", 1, 2, 64, 5, 29)
+Index64_3D = _IndexKind("Index64_3D", 2, 3, 64, 5, 19)
+_KINDS = {0: Index32_2D, 1: Index64_2D, 2: Index64_3D}
+
+KERNEL_CLASSES = ("encode", "tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist", "pair_sort",
+                  "dedup", "misc")
+
+
+class BroadphaseError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (status, message))
+        self.status = status
+
+
+class _Stats(C.Structure):
+    _fields_ = [("objects_valid", C.c_uint64), ("objects_invalid", C.c_uint64), ("entries", C.c_uint64),
+                ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("tree_sort_passes", C.c_uint32),
+                ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32)]
+
+
+FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)
+
+_lib = None
+
+# every symbol include/bp_layer.h declares
+EXPORTS = [
+    "bp_status_string", "bp_layer_last_error", "bp_layer_create", "bp_layer_destroy", "bp_layer_clone",
+    "bp_layer_equals", "bp_layer_clear", "bp_layer_extend", "bp_layer_extend_host", "bp_layer_extend_device",
+    "bp_layer_merge", "bp_layer_sort", "bp_layer_par_sort", "bp_layer_scan", "bp_layer_par_scan",
+    "bp_layer_scan_device", "bp_layer_scan_filtered", "bp_layer_par_scan_filtered", "bp_layer_scan_raw",
+    "bp_layer_tree", "bp_layer_tree_device", "bp_layer_set_tree", "bp_layer_append_entries", "bp_layer_len",
+    "bp_layer_is_sorted", "bp_layer_min_depth", "bp_layer_index_kind", "bp_layer_device",
+    "bp_layer_scan_shard_device", "bp_layer_sort_unique_pairs_device", "bp_layer_stats",
+    "bp_layer_profile_enable", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
+]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)]
+    srcs.append(os.path.join(_HERE, "..", "include", "bp_layer.h"))
+    if (not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.check_call(["make", "-C", src_dir, "-s", "all"])
+    return _LIB
+
+
+def load_library():
+    """dlopen the in-tree HIP library.  Fails loudly: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise BroadphaseError("BP_ERR_NO_LIBRARY", "HIP library %s is missing -- run "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)" % _LIB)
+    L = C.CDLL(_LIB)
+    vp, u32p, u64p, f32p, szp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float), \
+        C.POINTER(C.c_size_t)
+    ip = C.POINTER(C.c_int)
+    L.bp_version.restype = C.c_char_p
+    L.bp_status_string.restype = C.c_char_p
+    L.bp_status_string.argtypes = [C.c_int]
+    L.bp_layer_last_error.restype = C.c_char_p
+    L.bp_layer_last_error.argtypes = [vp]
+    L.bp_layer_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_size_t, C.c_size_t, C.c_int]
+    L.bp_layer_destroy.argtypes = [vp]
+    L.bp_layer_clone.argtypes = [vp, C.POINTER(vp)]
+    L.bp_layer_equals.argtypes = [vp, vp, ip]
+    L.bp_layer_clear.argtypes = [vp]
+    for name in ("bp_layer_extend", "bp_layer_extend_host", "bp_layer_extend_device"):
+        getattr(L, name).argtypes = [vp, f32p, f32p, vp, vp, C.c_size_t]
+    L.bp_layer_merge.argtypes = [vp, vp]
+    L.bp_layer_sort.argtypes = [vp]
+    L.bp_layer_par_sort.argtypes = [vp]
+    for name in ("bp_layer_scan", "bp_layer_par_scan", "bp_layer_scan_device", "bp_layer_scan_raw"):
+        getattr(L, name).argtypes = [vp, C.POINTER(vp), szp]
+    for name in ("bp_layer_scan_filtered", "bp_layer_par_scan_filtered"):
+        getattr(L, name).argtypes = [vp, FILTER_FN, vp, C.POINTER(vp), szp]
+    L.bp_layer_tree.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), szp, ip]
+    L.bp_layer_tree_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), szp, ip]
+    L.bp_layer_set_tree.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, C.c_int]
+    L.bp_layer_append_entries.argtypes = [vp, vp, vp, C.c_size_t]
+    L.bp_layer_len.argtypes = [vp, szp]
+    L.bp_layer_is_sorted.argtypes = [vp, ip]
+    L.bp_layer_min_depth.argtypes = [vp, u32p]
+    L.bp_layer_index_kind.argtypes = [vp, ip]
+    L.bp_layer_device.argtypes = [vp, ip]
+    L.bp_layer_scan_shard_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp]
+    L.bp_layer_sort_unique_pairs_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
+    L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.bp_layer_profile_enable.argtypes = [vp, C.c_int]
+    L.bp_layer_profile_reset.argtypes = [vp]
+    L.bp_layer_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
+    for name in EXPORTS:
+        if name not in ("bp_version", "bp_status_string", "bp_layer_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and bool(getattr(x, "is_cuda", False))
+
+
+class DeviceArray:
+    """Borrowed view of device memory owned by a Layer (valid until its next mutating call)."""
+
+    def __init__(self, ptr, shape, dtype, owner):
+        self.ptr, self.shape, self.dtype, self._owner = ptr, tuple(shape), np.dtype(dtype), owner
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr or 0, True), "version": 2}
+
+    def __len__(self):
+        return self.shape[0]
+
+    def to_numpy(self):
+        """synchronous D2H copy (hipMemcpy through the HIP runtime this process already loaded)"""
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            hip = C.CDLL("libamdhip64.so.7")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), out.nbytes, 2)
+            if rc != 0:
+                raise BroadphaseError("BP_ERR_HIP", "hipMemcpy D2H failed with %d" % rc)
+        return out
+
+    def as_torch(self):
+        """zero-copy torch view (signed dtype of the same width: torch has no full uint32/uint64)"""
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        signed = {4: "<i4", 8: "<i8"}[self.dtype.itemsize]
+        v.__cuda_array_interface__ = {"shape": self.shape, "typestr": signed, "data": (self.ptr or 0, True), "version": 2}
+        if int(np.prod(self.shape)) == 0:
+            return torch.empty(self.shape, dtype={4: torch.int32, 8: torch.int64}[self.dtype.itemsize], device="cuda")
+        return torch.as_tensor(v, device="cuda")
+
+
+class LayerBuilder:
+    """src/layer.rs:619-696"""
+
+    def __init__(self):
+        self._min_depth, self._index_capacity, self._collision_capacity, self._test_capacity = 0, 0, 0, 0
+        self._device = -1
+
+    @staticmethod
+    def new():
+        return LayerBuilder()
+
+    def with_min_depth(self, depth):
+        self._min_depth = int(depth)
+        return self
+
+    def with_index_capacity(self, capacity):
+        self._index_capacity = int(capacity)
+        return self
+
+    def with_collision_capacity(self, capacity):
+        self._collision_capacity = int(capacity)
+        return self
+
+    def with_test_capacity(self, capacity):  # query path (Layer::test/pick) is out of scope; accepted, unused
+        self._test_capacity = int(capacity)
+        return self
+
+    def with_device(self, device):  # not in the reference: which GPU the layer lives on
+        self._device = int(device)
+        return self
+
+    def build(self, index=Index64_3D):
+        return Layer(index, self._min_depth, self._index_capacity, self._collision_capacity, self._device)
+
+
+class Layer:
+    """Layer<Index, u32> (src/layer.rs:42-68): device-resident tree + scan temporaries."""
+
+    def __init__(self, index=Index64_3D, min_depth=0, index_capacity=0, collision_capacity=0, device=-1, _handle=None):
+        self._L = load_library()
+        self.index = index
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        rc = self._L.bp_layer_create(C.byref(h), index.kind, min_depth, index_capacity, collision_capacity, device)
+        if rc != 0:
+            raise BroadphaseError(self._L.bp_status_string(rc).decode(),
+                                  (self._L.bp_layer_last_error(None) or b"").decode())
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.bp_layer_destroy(h)
+            self._h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BroadphaseError(self._L.bp_status_string(rc).decode(),
+                                  (self._L.bp_layer_last_error(self._h) or b"").decode())
+
+    # ---- reference methods ------------------------------------------------------------------------
+    def clear(self):  # src/layer.rs:84-88
+        self._check(self._L.bp_layer_clear(self._h))
+
+    def extend(self, system_bounds, bounds, ids):
+        """src/layer.rs:94-121.  bounds: (n, 2*dim) f32 rows [min.., max..]; ids: (n,) u32."""
+        dim = self.index.dim
+        smin = np.ascontiguousarray(np.asarray(system_bounds[0], dtype=np.float32).reshape(dim))
+        smax = np.ascontiguousarray(np.asarray(system_bounds[1], dtype=np.float32).reshape(dim))
+        f32p = C.POINTER(C.c_float)
+        if _is_device_tensor(bounds) or _is_device_tensor(ids):
+            if not (_is_device_tensor(bounds) and _is_device_tensor(ids)):
+                raise ValueError("bounds and ids must both be device tensors or both be host arrays")
+            n = int(ids.numel())
+            if int(bounds.numel()) != n * 2 * dim or bounds.element_size() != 4 or ids.element_size() != 4:
+                raise ValueError("bounds must be f32 (n, 2*dim) and ids 32-bit (n,)")
+            if not (bounds.is_contiguous() and ids.is_contiguous()):
+                raise ValueError("device tensors must be contiguous")
+            self._check(self._L.bp_layer_extend_device(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p),
+                                                       C.c_void_p(bounds.data_ptr()), C.c_void_p(ids.data_ptr()), n))
+            return
+        b = np.ascontiguousarray(np.asarray(bounds, dtype=np.float32).reshape(-1, 2 * dim))
+        i = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32).reshape(-1))
+        if len(b) != len(i):
+            raise ValueError("bounds and ids differ in length")
+        self._check(self._L.bp_layer_extend_host(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p),
+                                                 C.c_void_p(b.ctypes.data), C.c_void_p(i.ctypes.data), len(i)))
+
+    def merge(self, other):  # src/layer.rs:127-138
+        self._check(self._L.bp_layer_merge(self._h, other._h))
+
+    def sort(self):  # src/layer.rs:159-165
+        self._check(self._L.bp_layer_sort(self._h))
+
+    def par_sort(self):  # src/layer.rs:146-152
+        self._check(self._L.bp_layer_par_sort(self._h))
+
+    def _host_pairs(self, p, n):
+        n = n.value
+        if n == 0:
+            return np.zeros((0, 2), dtype=np.uint32)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n, 2))
+        return arr  # borrowed: valid until the next mutating call on this layer
+
+    def scan(self):  # src/layer.rs:449-453
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan(self._h, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def par_scan(self):  # src/layer.rs:482-488
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_par_scan(self._h, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def _filtered(self, fn_name, filt):
+        p, n = C.c_void_p(), C.c_size_t()
+        cb = FILTER_FN(lambda a, b, _u: 1 if filt(a, b) else 0)
+        self._check(getattr(self._L, fn_name)(self._h, cb, None, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def scan_filtered(self, filt):  # src/layer.rs:460-477
+        return self._filtered("bp_layer_scan_filtered", filt)
+
+    def par_scan_filtered(self, filt):  # src/layer.rs:493-520
+        return self._filtered("bp_layer_par_scan_filtered", filt)
+
+    def iter(self):  # src/layer.rs:79-81
+        keys, ids = self.tree()
+        return zip(keys.tolist(), ids.tolist())
+
+    # ---- device-resident variants and views ---------------------------------------------------------
+    def scan_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_device(self._h, C.byref(p), C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    def scan_shard_device(self, coarse_depth, emit_coarse):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+                                                       C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    def sort_unique_pairs_device(self, pairs_ptr, n):
+        p, m = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_sort_unique_pairs_device(self._h, C.c_void_p(pairs_ptr), n, C.byref(p), C.byref(m)))
+        return DeviceArray(p.value, (m.value, 2), np.uint32, self)
+
+    def scan_raw(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_raw(self._h, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def tree(self):
+        """(keys u64[m], ids u32[m]) in current order -- the serde view of the persistent state"""
+        k, i, m, s = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
+        self._check(self._L.bp_layer_tree(self._h, C.byref(k), C.byref(i), C.byref(m), C.byref(s)))
+        if m.value == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+        keys = np.ctypeslib.as_array(C.cast(k, C.POINTER(C.c_uint64)), shape=(m.value,)).copy()
+        ids = np.ctypeslib.as_array(C.cast(i, C.POINTER(C.c_uint32)), shape=(m.value,)).copy()
+        return keys, ids
+
+    def tree_device(self):
+        k, i, m, s = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
+        self._check(self._L.bp_layer_tree_device(self._h, C.byref(k), C.byref(i), C.byref(m), C.byref(s)))
+        return (DeviceArray(k.value, (m.value,), np.uint64, self), DeviceArray(i.value, (m.value,), np.uint32, self))
+
+    def set_tree(self, min_depth, keys, ids, sorted_):
+        if _is_device_tensor(keys):
+            kp, ip, m = keys.data_ptr(), ids.data_ptr(), int(keys.numel())
+        else:
+            keys = np.ascontiguousarray(keys, dtype=np.uint64)
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            kp, ip, m = keys.ctypes.data, ids.ctypes.data, len(keys)
+        self._check(self._L.bp_layer_set_tree(self._h, min_depth, C.c_void_p(kp), C.c_void_p(ip), m, 1 if sorted_ else 0))
+
+    def append_entries(self, keys, ids, count=None):
+        if _is_device_tensor(keys):
+            kp, ip, m = keys.data_ptr(), ids.data_ptr(), int(keys.numel())
+        elif isinstance(keys, int):
+            kp, ip, m = keys, ids, int(count)
+        else:
+            keys = np.ascontiguousarray(keys, dtype=np.uint64)
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            kp, ip, m = keys.ctypes.data, ids.ctypes.data, len(keys)
+        self._check(self._L.bp_layer_append_entries(self._h, C.c_void_p(kp), C.c_void_p(ip), m))
+
+    def clone(self):  # impl Clone, src/layer.rs:595-616
+        h = C.c_void_p()
+        self._check(self._L.bp_layer_clone(self._h, C.byref(h)))
+        return Layer(self.index, _handle=h)
+
+    def __eq__(self, other):  # impl PartialEq, src/layer.rs:576-586
+        if not isinstance(other, Layer):
+            return NotImplemented
+        eq = C.c_int()
+        self._check(self._L.bp_layer_equals(self._h, other._h, C.byref(eq)))
+        return bool(eq.value)
+
+    def __len__(self):
+        m = C.c_size_t()
+        self._check(self._L.bp_layer_len(self._h, C.byref(m)))
+        return m.value
+
+    @property
+    def sorted(self):
+        s = C.c_int()
+        self._check(self._L.bp_layer_is_sorted(self._h, C.byref(s)))
+        return bool(s.value)
+
+    @property
+    def min_depth(self):
+        d = C.c_uint32()
+        self._check(self._L.bp_layer_min_depth(self._h, C.byref(d)))
+        return d.value
+
+    @property
+    def device(self):
+        d = C.c_int()
+        self._check(self._L.bp_layer_device(self._h, C.byref(d)))
+        return d.value
+
+    def stats(self):
+        s = _Stats()
+        self._check(self._L.bp_layer_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in _Stats._fields_}
+
+    # ---- measurement ------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._L.bp_layer_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._L.bp_layer_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel class: (total device ms, timed regions)} from HIP events on the layer's stream"""
+        out = {}
+        for cls, name in enumerate(KERNEL_CLASSES):
+            ms, n = C.c_double(), C.c_uint64()
+            self._check(self._L.bp_layer_profile_get(self._h, cls, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out

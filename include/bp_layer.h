@@ -1,0 +1,176 @@
+/*
+ * bp_layer.h -- C ABI of the MI355X-native broadphase Layer (extend -> sort -> scan).
+ *
+ * This is the drop-in boundary for the hot path of zvxryb/broadphase-rs: the reference has no FFI
+ * layer of its own -- its public surface for this path is the Rust type `Layer<Index, ID>`
+ * (re-exported at src/lib.rs:80-82).  Each entry point below replaces one `Layer` /
+ * `LayerBuilder` method; the Rust shim a maintainer would add on top is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns BP_OK (0) or a negative bp_status; bp_status_string() names it and
+ *     bp_layer_last_error() gives the detailed message of the last failure on a handle;
+ *   - a handle is NOT thread-safe (it mirrors `&mut self`); each handle owns one HIP stream and
+ *     all its device and pinned-host buffers; every call is complete when it returns;
+ *   - returned pointers are BORROWED: valid until the next mutating call on the same handle
+ *     (the reference returns `&'a Vec<(ID, ID)>` tied to `&'a mut self`, src/layer.rs:449-451);
+ *   - ID is u32.  Index values travel as u64 for every index kind (Index32_2D is zero-extended);
+ *   - no CPU fallback exists: without a usable HIP device every call fails with BP_ERR_NO_DEVICE.
+ */
+#ifndef BP_LAYER_H
+#define BP_LAYER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bp_status {
+    BP_OK = 0,
+    BP_ERR_INVALID_ARG = -1,
+    BP_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init            */
+    BP_ERR_HIP = -3,         /* a HIP call failed (see bp_layer_last_error)            */
+    BP_ERR_OOM = -4,         /* device or pinned-host allocation failed                */
+    BP_ERR_TOO_LARGE = -5,   /* an intermediate size exceeds what the kernels index    */
+    BP_ERR_KERNEL = -6,      /* a kernel reported an internal error (bounded spin hit) */
+    BP_ERR_COMM = -7         /* multi-GPU exchange failed                              */
+} bp_status;
+
+/* SpatialIndex implementations: src/index.rs:293-295 */
+typedef enum bp_index_kind {
+    BP_INDEX32_2D = 0, /* 4 depth bits + 2 x 14 origin bits in a u32 */
+    BP_INDEX64_2D = 1, /* 5 depth bits + 2 x 29 origin bits in a u64 */
+    BP_INDEX64_3D = 2  /* 5 depth bits + 3 x 19 origin bits in a u64 */
+} bp_index_kind;
+
+typedef struct bp_layer bp_layer_t; /* opaque: Layer<Index, u32>  (src/layer.rs:42-68) */
+
+/* scan_filtered's `F: FnMut(ID, ID) -> bool` (src/layer.rs:460-464): return non-zero to keep */
+typedef int (*bp_filter_fn)(uint32_t id, uint32_t id_, void *user);
+
+const char *bp_status_string(int status);
+const char *bp_layer_last_error(const bp_layer_t *layer);
+
+/* ---- construction: LayerBuilder (src/layer.rs:619-696) ------------------------------------ */
+/* LayerBuilder::new().with_min_depth(min_depth).with_index_capacity(index_capacity)
+ *   .with_collision_capacity(collision_capacity).build::<Index, u32>()
+ * `device` is the HIP device ordinal the layer lives on (-1: the current device).
+ * with_test_capacity (src/layer.rs:665) has no counterpart: the query path is out of scope. */
+int bp_layer_create(bp_layer_t **out, int index_kind, uint32_t min_depth, size_t index_capacity,
+                    size_t collision_capacity, int device);
+int bp_layer_destroy(bp_layer_t *layer);
+/* impl Clone (src/layer.rs:595-616): copies min_depth + tree, drops temporaries */
+int bp_layer_clone(const bp_layer_t *layer, bp_layer_t **out);
+/* impl PartialEq (src/layer.rs:576-586): min_depth, entries in current order, sorted flag */
+int bp_layer_equals(const bp_layer_t *a, const bp_layer_t *b, int *equal);
+
+/* ---- Layer methods on the hot path --------------------------------------------------------- */
+/* Layer::clear (src/layer.rs:84-88) */
+int bp_layer_clear(bp_layer_t *layer);
+
+/* Layer::extend (src/layer.rs:94-121).  system bounds: sys_min[dim], sys_max[dim].
+ * bounds: n rows of 2*dim f32 (min[dim] then max[dim], inclusive); ids: n u32.
+ * Objects not contained in the system bounds are skipped silently, like the reference.
+ * _host takes host pointers (copied H2D on the layer's stream); _device takes pointers that
+ * are already resident on the layer's device (no copy); bp_layer_extend detects which. */
+int bp_layer_extend(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *bounds,
+                    const uint32_t *ids, size_t n);
+int bp_layer_extend_host(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *bounds,
+                         const uint32_t *ids, size_t n);
+int bp_layer_extend_device(bp_layer_t *layer, const float *sys_min, const float *sys_max,
+                           const float *d_bounds, const uint32_t *d_ids, size_t n);
+
+/* Layer::merge (src/layer.rs:127-138); `other` must live on the same device */
+int bp_layer_merge(bp_layer_t *layer, const bp_layer_t *other);
+
+/* Layer::sort / Layer::par_sort (src/layer.rs:146-165): one implementation, two names */
+int bp_layer_sort(bp_layer_t *layer);
+int bp_layer_par_sort(bp_layer_t *layer);
+
+/* Layer::scan / par_scan (src/layer.rs:449-453, 482-488): sorted, duplicate-free list of
+ * (id, id_) pairs as interleaved u32.  *pairs is host-visible (pinned) memory. */
+int bp_layer_scan(bp_layer_t *layer, const uint32_t **pairs, size_t *n_pairs);
+int bp_layer_par_scan(bp_layer_t *layer, const uint32_t **pairs, size_t *n_pairs);
+/* same result left in HBM: *d_pairs is a device pointer (no D2H copy) */
+int bp_layer_scan_device(bp_layer_t *layer, const uint32_t **d_pairs, size_t *n_pairs);
+
+/* Layer::scan_filtered / par_scan_filtered (src/layer.rs:460-477, 493-520).  The filter sees
+ * every raw pair before duplicate removal, in scan_impl's emission order (src/layer.rs:566-570):
+ * the raw pair stream is produced on the device in exactly that order and filtered on the host. */
+int bp_layer_scan_filtered(bp_layer_t *layer, bp_filter_fn filter, void *user, const uint32_t **pairs,
+                           size_t *n_pairs);
+int bp_layer_par_scan_filtered(bp_layer_t *layer, bp_filter_fn filter, void *user, const uint32_t **pairs,
+                               size_t *n_pairs);
+
+/* Raw output of scan_impl (src/layer.rs:550-573) before sort+dedup, in emission order; used by
+ * parity tests and by scan_filtered.  Host-visible, interleaved (id, id_). */
+int bp_layer_scan_raw(bp_layer_t *layer, const uint32_t **pairs, size_t *n_raw);
+
+/* Layer::iter (src/layer.rs:79-81) / serde view of the persistent state (src/layer.rs:49-50):
+ * entries in current order as SoA: keys[m] (u64, Index value zero-extended), ids[m]. */
+int bp_layer_tree(bp_layer_t *layer, const uint64_t **keys, const uint32_t **ids, size_t *m, int *sorted);
+int bp_layer_tree_device(bp_layer_t *layer, const uint64_t **d_keys, const uint32_t **d_ids, size_t *m,
+                         int *sorted);
+/* Deserialize counterpart: replace the persistent state (host or device pointers, detected). */
+int bp_layer_set_tree(bp_layer_t *layer, uint32_t min_depth, const uint64_t *keys, const uint32_t *ids,
+                      size_t m, int sorted);
+/* Append raw entries (what merge does with another layer's tree); used by the multi-GPU exchange. */
+int bp_layer_append_entries(bp_layer_t *layer, const uint64_t *keys, const uint32_t *ids, size_t m);
+
+int bp_layer_len(const bp_layer_t *layer, size_t *m);
+int bp_layer_is_sorted(const bp_layer_t *layer, int *sorted);
+int bp_layer_min_depth(const bp_layer_t *layer, uint32_t *min_depth);
+int bp_layer_index_kind(const bp_layer_t *layer, int *index_kind);
+int bp_layer_device(const bp_layer_t *layer, int *device);
+
+/* ---- multi-GPU support (one process per GPU; the exchange itself is RCCL via the host side) --- */
+/* Scan variant for a Morton-range shard: entries whose depth is < coarse_depth are replicated on
+ * every rank; pairs whose deeper entry is such a coarse entry are emitted only when emit_coarse
+ * is non-zero (exactly one rank sets it), so the union over ranks is the single-GPU raw set. */
+int bp_layer_scan_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
+                               const uint32_t **d_pairs, size_t *n_pairs);
+/* Sort + dedup an arbitrary device-resident list of n (id, id_) pairs (interleaved u32) in place
+ * semantics of collisions.sort_unstable(); collisions.dedup() (src/layer.rs:473-474, 516-517). */
+int bp_layer_sort_unique_pairs_device(bp_layer_t *layer, const uint32_t *d_pairs_in, size_t n,
+                                      const uint32_t **d_pairs, size_t *n_pairs);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+typedef struct bp_stats {
+    uint64_t objects_valid;   /* objects appended by extend since the last clear       */
+    uint64_t objects_invalid; /* objects skipped (outside system bounds)                */
+    uint64_t entries;         /* M: index entries in the tree                           */
+    uint64_t raw_pairs;       /* P_raw of the last scan                                 */
+    uint64_t pairs;           /* P of the last scan                                     */
+    uint32_t tree_sort_passes;
+    uint32_t pair_sort_passes;
+    uint32_t depth_mask;      /* bit d set <=> some entry has depth d                   */
+    uint32_t flags;           /* bit0: key-only stable sort valid, bit1: ids distinct   */
+} bp_stats;
+int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
+
+/* Kernel classes timed with HIP events on the layer's own stream when profiling is enabled */
+typedef enum bp_kernel_class {
+    BP_K_ENCODE = 0,      /* encode_count + encode_emit                   */
+    BP_K_TREE_HIST = 1,   /* digit histograms of the tree sort            */
+    BP_K_TREE_SORT = 2,   /* onesweep radix passes over (key, id) entries */
+    BP_K_SCAN_COUNT = 3,  /* overlap scan, counting pass                  */
+    BP_K_SCAN_EMIT = 4,   /* overlap scan, emitting pass                  */
+    BP_K_PAIR_HIST = 5,   /* digit histograms of the pair sort            */
+    BP_K_PAIR_SORT = 6,   /* onesweep radix passes over packed pairs      */
+    BP_K_DEDUP = 7,       /* adjacent-unique flag/compact                 */
+    BP_K_MISC = 8,        /* block-sum scans, memsets, small reductions   */
+    BP_K_COUNT = 9
+} bp_kernel_class;
+int bp_layer_profile_enable(bp_layer_t *layer, int on);
+int bp_layer_profile_reset(bp_layer_t *layer);
+/* total device milliseconds and number of launches accumulated for one class */
+int bp_layer_profile_get(bp_layer_t *layer, int kernel_class, double *total_ms, uint64_t *launches);
+
+/* library version string, e.g. "broadphase_amd 0.1 gfx950" */
+const char *bp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP_LAYER_H */

@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact: index entries in append order, sorted tree, raw pair stream in scan_impl's
+emission order, and the final sorted duplicate-free pair list.  Mirrors the structure of the
+reference's tests/test_layer.rs (extend / sort / par_sort / scan / par_scan against goldens)."""
+import numpy as np
+import pytest
+
+import oracle
+import broadphase_rs_amd as bp
+from broadphase_rs_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {0: bp.Index32_2D, 1: bp.Index64_2D, 2: bp.Index64_3D}
+
+
+def make_scene(kind, n, seed):
+    if kind == 2:
+        return scenes.gen_boxes(n, seed=seed)
+    return scenes.gen_circles_2d(n, seed=seed)
+
+
+def both(kind, min_depth=0):
+    return bp.Layer(KINDS[kind], min_depth), oracle.OracleLayer(kind, min_depth)
+
+
+def assert_tree_equal(gpu, ref, what):
+    k, i = gpu.tree()
+    rk, ri = ref.keys, ref.ids
+    assert len(k) == len(rk), "%s: %d entries, oracle has %d" % (what, len(k), len(rk))
+    if not np.array_equal(k, rk):
+        bad = int(np.flatnonzero(k != rk)[0])
+        raise AssertionError("%s: key[%d] = %#x, oracle %#x" % (what, bad, int(k[bad]), int(rk[bad])))
+    if not np.array_equal(i, ri):
+        bad = int(np.flatnonzero(i != ri)[0])
+        raise AssertionError("%s: id[%d] = %d, oracle %d" % (what, bad, int(i[bad]), int(ri[bad])))
+    assert gpu.sorted == ref.sorted, what
+
+
+def assert_pairs_equal(got, exp, what):
+    got = np.asarray(got)
+    assert got.shape == exp.shape, "%s: %s pairs, oracle %s" % (what, got.shape, exp.shape)
+    if not np.array_equal(got, exp):
+        bad = int(np.flatnonzero((got != exp).any(axis=1))[0])
+        raise AssertionError("%s: pair[%d] = %s, oracle %s" % (what, bad, got[bad], exp[bad]))
+
+
+@pytest.mark.parametrize("kind,n,min_depth", [
+    (2, 1, 0), (2, 7, 0), (2, 255, 0), (2, 256, 0), (2, 257, 0), (2, 1000, 0), (2, 10000, 0), (2, 100000, 0),
+    (2, 3000, 3), (2, 3000, 7), (2, 2000, 19),
+    (0, 10000, 4), (0, 5000, 0), (0, 3000, 14), (1, 10000, 0), (1, 5000, 6),
+])
+def test_extend_sort_scan_match_oracle(kind, n, min_depth):
+    sysb, bounds, ids = make_scene(kind, n, seed=n + kind)
+    gpu, ref = both(kind, min_depth)
+    gpu.extend(sysb, bounds, ids)
+    ref.extend(sysb, bounds, ids)
+    assert_tree_equal(gpu, ref, "extend")                 # tests/test_layer.rs:25-40
+    gpu.par_sort(); ref.sort()
+    assert_tree_equal(gpu, ref, "par_sort")               # tests/test_layer.rs:74-90
+    raw_ref, _ = ref.scan_raw()
+    assert_pairs_equal(gpu.scan_raw(), raw_ref, "scan_raw")
+    exp = ref.scan()
+    assert_pairs_equal(gpu.par_scan(), exp, "par_scan")   # tests/test_layer.rs:109-124
+    assert_pairs_equal(gpu.scan(), exp, "scan")
+    st = gpu.stats()
+    assert st["raw_pairs"] == len(raw_ref) and st["pairs"] == len(exp)
+
+
+def test_empty_layer_and_all_invalid():
+    gpu, ref = both(2)
+    assert len(gpu) == 0 and gpu.sorted
+    assert len(gpu.scan()) == 0
+    sysb = ([0.0] * 3, [10.0] * 3)
+    bounds = np.array([[20, 20, 20, 21, 21, 21], [-1, 0, 0, 1, 1, 1]], dtype=np.float32)
+    gpu.extend(sysb, bounds, [1, 2]); ref.extend(sysb, bounds, [1, 2])
+    assert len(gpu) == 0 and gpu.sorted                   # nothing valid appended: sorted flag untouched
+    assert_tree_equal(gpu, ref, "all invalid")
+    assert gpu.stats()["objects_invalid"] == 2
+    assert len(gpu.par_scan()) == 0
+    gpu.extend(sysb, np.zeros((0, 6), np.float32), np.zeros(0, np.uint32))
+    assert len(gpu) == 0
+
+
+def test_edge_boxes_nan_zero_size_whole_system():
+    sysb = ([0.0] * 3, [64.0] * 3)
+    bounds = np.array([[0, 0, 0, 64, 64, 64],               # whole system -> depth 0, key 0
+                       [1, 1, 1, 2, 2, 2],
+                       [5, 5, 5, 5, 5, 5],                   # zero size -> depth clamp 19
+                       [float("nan"), 1, 1, 2, 2, 2],        # NaN passes contains(), quantises to 0
+                       [63.5, 63.5, 63.5, 64, 64, 64],
+                       [70, 1, 1, 71, 2, 2],                 # outside
+                       [3, 3, 3, 2, 2, 2]],                  # inverted box (min > max), wrapping sizei
+                      dtype=np.float32)
+    ids = np.arange(len(bounds), dtype=np.uint32) * 3 + 1
+    for min_depth in (0, 2, 5):
+        gpu, ref = both(2, min_depth)
+        gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+        assert_tree_equal(gpu, ref, "edge extend md=%d" % min_depth)
+        assert_pairs_equal(gpu.scan_raw(), ref.scan_raw()[0], "edge raw")
+        assert_pairs_equal(gpu.scan(), ref.scan(), "edge scan")
+
+
+def test_duplicate_ids_take_the_skip_rule_path():
+    # several boxes per id (static-geometry usage, src/layer.rs:92-93): nested same-id cells are skipped
+    rng = np.random.default_rng(5)
+    sysb, bounds, _ = scenes.gen_boxes_powerlaw(4000, seed=9, alpha=1.5)
+    ids = rng.integers(0, 300, size=len(bounds)).astype(np.uint32)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    assert_tree_equal(gpu, ref, "dup extend")
+    gpu.sort(); ref.sort()
+    assert_tree_equal(gpu, ref, "dup sort (ids not monotone -> id digits sorted too)")
+    assert gpu.stats()["flags"] & 2 == 0
+    raw_ref, _ = ref.scan_raw()
+    assert len(raw_ref) > 1000
+    assert_pairs_equal(gpu.scan_raw(), raw_ref, "dup raw")
+    assert_pairs_equal(gpu.scan(), ref.scan(), "dup scan")
+
+
+def test_unordered_ids_and_multiple_extends():
+    sysb, bounds, ids = scenes.gen_boxes(30000, seed=4)
+    perm = np.random.default_rng(1).permutation(len(ids)).astype(np.uint32)
+    gpu, ref = both(2)
+    for lo, hi in ((0, 10000), (10000, 10001), (10001, 30000)):
+        gpu.extend(sysb, bounds[lo:hi], perm[lo:hi]); ref.extend(sysb, bounds[lo:hi], perm[lo:hi])
+    assert_tree_equal(gpu, ref, "multi extend")
+    gpu.par_sort(); ref.sort()
+    assert_tree_equal(gpu, ref, "sort with permuted ids")
+    assert_pairs_equal(gpu.par_scan(), ref.scan(), "scan with permuted ids")
+    # extend after sort keeps working (sorted prefix + appended tail)
+    sysb2, b2, _ = scenes.gen_boxes(30000, seed=8)
+    ids2 = np.arange(40000, 40000 + 500, dtype=np.uint32)
+    gpu.extend(sysb, b2[:500] * np.float32(0.5), ids2); ref.extend(sysb, b2[:500] * np.float32(0.5), ids2)
+    assert not gpu.sorted
+    assert_tree_equal(gpu, ref, "extend after sort")
+    assert_pairs_equal(gpu.par_scan(), ref.scan(), "scan after second extend")
+
+
+def test_monotone_batches_use_key_only_sort_and_match():
+    sysb, bounds, ids = scenes.gen_boxes(50000, seed=12)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds[:20000], ids[:20000]); ref.extend(sysb, bounds[:20000], ids[:20000])
+    gpu.sort(); ref.sort()
+    gpu.extend(sysb, bounds[20000:], ids[20000:]); ref.extend(sysb, bounds[20000:], ids[20000:])
+    assert gpu.stats()["flags"] == 3                       # stable key-only sort valid, ids distinct
+    gpu.sort(); ref.sort()
+    assert_tree_equal(gpu, ref, "resort of sorted prefix + monotone tail")
+    assert_pairs_equal(gpu.scan(), ref.scan(), "scan")
+
+
+def test_merge_clone_eq_and_clear():
+    sysb, bounds, ids = scenes.gen_boxes(20000, seed=21)
+    static_g, static_r = both(2, 0)
+    dyn_g, dyn_r = both(2, 3)
+    static_g.extend(sysb, bounds[:12000], ids[:12000]); static_r.extend(sysb, bounds[:12000], ids[:12000])
+    static_g.sort(); static_r.sort()
+    dyn_g.extend(sysb, bounds[12000:], ids[12000:]); dyn_r.extend(sysb, bounds[12000:], ids[12000:])
+    snapshot = dyn_g.clone()
+    assert snapshot == dyn_g
+    dyn_g.merge(static_g); dyn_r.merge(static_r)            # src/layer.rs:127-138
+    assert dyn_g.min_depth == 0 and dyn_r.min_depth == 0 and not dyn_g.sorted
+    assert snapshot != dyn_g
+    assert_tree_equal(dyn_g, dyn_r, "merge")
+    assert_pairs_equal(dyn_g.par_scan(), dyn_r.scan(), "scan after merge")
+    # merging a sorted layer into an empty sorted layer still clears the sorted flag (layer.rs:137)
+    e_g, e_r = both(2, 0)
+    e_g.merge(static_g); e_r.merge(static_r)
+    assert not e_g.sorted and not e_r.sorted
+    assert_pairs_equal(e_g.scan(), e_r.scan(), "scan of merged-into-empty")
+    dyn_g.clear(); dyn_r.clear()
+    assert len(dyn_g) == 0 and dyn_g.sorted
+    dyn_g.extend(sysb, bounds[:100], ids[:100]); dyn_r.extend(sysb, bounds[:100], ids[:100])
+    assert_tree_equal(dyn_g, dyn_r, "extend after clear")
+
+
+def test_scan_filtered_sees_raw_stream_in_reference_order():
+    sysb, bounds, ids = scenes.gen_boxes(5000, seed=33)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    seen_g, seen_r = [], []
+
+    def fg(a, b):
+        seen_g.append((a, b)); return (a ^ b) & 1 == 0
+
+    def fr(a, b):
+        seen_r.append((a, b)); return (a ^ b) & 1 == 0
+
+    got = np.array(gpu.scan_filtered(fg))
+    exp = ref.scan_filtered(fr)
+    assert seen_g == seen_r and len(seen_g) > 1000          # same calls, same order, before dedup
+    assert_pairs_equal(got, exp, "scan_filtered")
+    assert_pairs_equal(np.array(gpu.par_scan_filtered(lambda a, b: a > 2 * b)), ref.scan_filtered(lambda a, b: a > 2 * b),
+                       "par_scan_filtered")
+    assert len(gpu.scan_filtered(lambda a, b: False)) == 0
+
+
+def test_set_tree_round_trip_and_device_views():
+    sysb, bounds, ids = scenes.gen_boxes(8000, seed=2)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    k, i = gpu.tree()
+    other = bp.Layer(bp.Index64_3D, 0)
+    other.set_tree(0, k, i, False)                          # Deserialize counterpart
+    assert other == gpu
+    assert_pairs_equal(other.scan(), ref.scan(), "scan of deserialized layer")
+    dk, di = gpu.tree_device()
+    assert dk.shape == (len(k),) and di.shape == (len(k),) and dk.ptr and di.ptr
+
+
+def test_device_resident_inputs_and_outputs_with_torch():
+    import torch
+    sysb, bounds, ids = scenes.gen_boxes(60000, seed=77)
+    gpu, ref = both(2)
+    tb = torch.from_numpy(bounds).cuda()
+    ti = torch.from_numpy(ids.astype(np.int32)).cuda()
+    torch.cuda.synchronize()
+    gpu.extend(sysb, tb, ti)
+    ref.extend(sysb, bounds, ids)
+    assert_tree_equal(gpu, ref, "extend from device tensors")
+    d = gpu.scan_device()
+    exp = ref.scan()
+    assert_pairs_equal(d.to_numpy(), exp, "scan_device")
+    t = d.as_torch()
+    assert t.is_cuda and tuple(t.shape) == exp.shape
+    assert_pairs_equal(t.cpu().numpy().view(np.uint32).reshape(-1, 2), exp, "scan_device via torch view")
+
+
+def test_powerlaw_deep_stack():
+    sysb, bounds, ids = scenes.gen_boxes_powerlaw(30000, seed=3, alpha=1.5)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    raw_ref, max_stack = ref.scan_raw()
+    assert max_stack > 40
+    assert_pairs_equal(gpu.scan_raw(), raw_ref, "powerlaw raw")
+    assert_pairs_equal(gpu.par_scan(), ref.par_scan(), "powerlaw scan")
+
+
+def test_one_million_boxes_full_compare():
+    sysb, bounds, ids = scenes.gen_boxes(1_000_000, seed=0)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    assert_tree_equal(gpu, ref, "1M extend")
+    gpu.par_sort(); ref.par_sort()
+    assert_tree_equal(gpu, ref, "1M sort")
+    assert_pairs_equal(gpu.par_scan(), ref.par_scan(), "1M scan")
+
+
+def test_ten_million_boxes_properties():
+    """BASELINE.json full size: size-independent properties + counts against the oracle."""
+    sysb, bounds, ids = scenes.gen_boxes(10_000_000, seed=0)
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    gpu.extend(sysb, bounds, ids)
+    gpu.par_sort()
+    k, i = gpu.tree()
+    order = (k[1:] > k[:-1]) | ((k[1:] == k[:-1]) & (i[1:] >= i[:-1]))
+    assert bool(order.all())                               # tests/test_layer.rs:42-54 is_sorted
+    pairs = np.array(gpu.par_scan())
+    packed = (pairs[:, 0].astype(np.uint64) << np.uint64(32)) | pairs[:, 1].astype(np.uint64)
+    assert bool((packed[1:] > packed[:-1]).all())          # strictly increasing: sorted + unique
+    assert bool((pairs[:, 0] != pairs[:, 1]).all())
+    # idempotence: scanning again gives the identical list
+    again = np.array(gpu.par_scan())
+    assert np.array_equal(again, pairs)
+    ref = oracle.OracleLayer(2, 0)
+    ref.extend(sysb, bounds, ids)
+    assert len(ref) == len(k)
+    exp = ref.par_scan()
+    assert_pairs_equal(pairs, exp, "10M scan")
