@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Layer extend -> sort -> scan path on MI355X.
+
+Metric (BASELINE.json): candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak.
+A "step" is one pass of the hot path over one batch of synthetic AABBs that are already resident
+in HBM: clear + extend + par_sort + par_scan, result (sorted, duplicate-free pair list) left in HBM.
+value = unique pairs produced by all ranks / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--objects M]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`
+(one rank per GPU, RCCL); scaling is weak: every rank contributes `--objects` objects of one
+global scene, entries and pairs are exchanged by Morton / id range (broadphase_rs_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--objects", type=int, default=10_000_000, help="objects per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-objects", type=int, default=1_000_000, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def usable_cpus(hw):
+    """threads this process may really use: affinity mask and cgroup quota, not the host's core count"""
+    n = hw
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(n_objects, seed):
+    """The oracle (C restatement of the reference's algorithm and structure) timed on this host.
+    kind = "port": the Rust crate itself cannot be built here (no rustc/cargo).  Bounded sample:
+    the same gen_boxes recipe and density at n_objects objects, full extend+par_sort+par_scan."""
+    import oracle  # checker only: never on the measured GPU path
+    from broadphase_rs_amd import scenes
+    sysb, bounds, ids = scenes.gen_boxes(n_objects, seed=seed)
+    threads = usable_cpus(oracle.lib().orc_hw_threads())
+    rows = {}
+    # "tuned": min_depth = smallest natural depth of the scene, so indices/results are unchanged
+    # but par_scan_impl can actually split (src/layer.rs:533-546); "default": min_depth = 0, where
+    # level_mask(0) == 0 makes the reference's scan one serial sweep (only the sorts are parallel).
+    probe = oracle.OracleLayer(oracle.INDEX64_3D, 0)
+    probe.extend(sysb, bounds[:20000], ids[:20000])
+    natural = int((probe.keys & 31).min())
+    for name, md in (("default_min_depth_0", 0), ("tuned_min_depth_%d" % natural, natural)):
+        lay = oracle.OracleLayer(oracle.INDEX64_3D, md)
+        t0 = time.perf_counter()
+        lay.clear()
+        lay.extend(sysb, bounds, ids)
+        lay.par_sort(threads)
+        pairs = lay.par_scan(threads)
+        dt = time.perf_counter() - t0
+        rows[name] = {"pairs": int(len(pairs)), "seconds": dt, "pairs_per_s": len(pairs) / dt}
+        del lay, pairs
+    best = max(rows.values(), key=lambda r: r["pairs_per_s"])
+    return {"value": best["pairs_per_s"] / 1e6, "unit": "Mpairs/s", "cores": threads, "kind": "port",
+            "sample": "gen_boxes(%d objects, density 0.001, seed %d): clear+extend+par_sort+par_scan, OpenMP "
+                      "C restatement with the reference's structure; rows: %s" % (
+                          n_objects, seed, json.dumps({k: round(v["pairs_per_s"] / 1e6, 3) for k, v in rows.items()})),
+            "rows": rows}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch  # plumbing: device memory for the inputs, torch.distributed (RCCL) for N > 1
+    import broadphase_rs_amd as bp
+    from broadphase_rs_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.objects
+    n_global = n * world
+    # one global scene, sharded by object index: rank r owns ids [r*n, (r+1)*n); same density as
+    # the reference's recipe, so the global side is cbrt(n_global / 0.001) + 5.5
+    sysb, bounds, ids = scenes.gen_boxes_shard(n_global, rank, world, seed=args.seed) if world > 1 else \
+        scenes.gen_boxes(n, seed=args.seed)
+    d_bounds = torch.from_numpy(bounds).to(dev)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+
+    if world == 1:
+        layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
+
+        def step():
+            layer.clear()
+            layer.extend(sysb, d_bounds, d_ids)
+            layer.par_sort()
+            return layer.scan_device()
+        engine = layer
+    else:
+        from broadphase_rs_amd import dist as bpd
+        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global)
+
+        def step():
+            sharded.clear()
+            sharded.extend(sysb, d_bounds, d_ids)
+            return sharded.par_scan_device()
+        engine = sharded.shard_layer
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    engine.profile_reset()
+    engine.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    engine.profile_enable(False)
+    n_pairs_local = len(out)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([n_pairs_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_pairs = int(c.item())
+    else:
+        n_pairs = n_pairs_local
+
+    if rank == 0:
+        st = engine.stats()
+        prof = engine.profile()
+        ms_per_step = dt / args.steps * 1e3
+        value = n_pairs / (dt / args.steps)
+        M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
+        # dominant kernel: one radix pass over the packed raw pairs.  ALGORITHMIC bytes per launch:
+        # 16 B per raw pair (8 B read + 8 B written), SURVEY.md 8(d) B_pairsort = (8 + 16 p_p) P_raw.
+        sort_ms, sort_launches = prof["pair_sort"]
+        per_launch_ms = sort_ms / max(sort_launches, 1)
+        bytes_per_launch = 16.0 * P_raw
+        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        # model bytes of one whole step, with the passes actually run
+        pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
+        b_total = (28.0 * n + 12.0 * M) + (8 + 24 * pk) * M + (12.0 * M + 8.0 * P_raw) + (8 + 16 * pp) * P_raw + \
+            (8.0 * P_raw + 8.0 * P)
+        line = {
+            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dM Index64_3D uniform-random AABBs per GPU (gen_boxes recipe, density 0.001, "
+                                   "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
+                                   % (n // 1_000_000) if n % 1_000_000 == 0 else "%d Index64_3D AABBs per GPU" % n,
+                       "objects_per_gpu": n, "objects_total": n_global, "entries": M, "raw_pairs": P_raw,
+                       "pairs_rank0": P, "pairs_total": n_pairs, "tree_sort_passes": pk, "pair_sort_passes": pp,
+                       "parallelism": "1 GPU" if world == 1 else "morton-range shards x%d, RCCL all-to-all" % world},
+            "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel<u64,NoVal> (pair sort pass)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": per_launch_ms,
+                         "launches": sort_launches},
+            "step_model": {"bytes": b_total, "GBps": b_total / (ms_per_step * 1e-3) / 1e9,
+                           "frac_of_peak": b_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_objects, args.seed)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

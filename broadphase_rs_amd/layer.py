@@ -82,11 +82,37 @@ def build_library(force=False):
     return _LIB
 
 
+def _preload_hip_runtime():
+    """A process can host only ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (SONAME libamdhip64.so.7, the same as /opt/rocm's), so if torch is installed and
+    no HIP runtime is mapped yet, map torch's copy first: the library's DT_NEEDED then resolves
+    to it by SONAME and a later `import torch` in this process shares the same runtime.  Without
+    torch the library's RPATH (/opt/rocm/lib) is used.  BP_HIP_RUNTIME=system skips this."""
+    if os.environ.get("BP_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+    except OSError:
+        pass
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """dlopen the in-tree HIP library.  Fails loudly: there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     if not os.path.exists(_LIB):
         raise BroadphaseError("BP_ERR_NO_LIBRARY", "HIP library %s is missing -- run "
                               "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)" % _LIB)
@@ -175,7 +201,7 @@ class DeviceArray:
             pass
         v = _View()
         signed = {4: "<i4", 8: "<i8"}[self.dtype.itemsize]
-        v.__cuda_array_interface__ = {"shape": self.shape, "typestr": signed, "data": (self.ptr or 0, True), "version": 2}
+        v.__cuda_array_interface__ = {"shape": self.shape, "typestr": signed, "data": (self.ptr or 0, False), "version": 2}
         if int(np.prod(self.shape)) == 0:
             return torch.empty(self.shape, dtype={4: torch.int32, 8: torch.int64}[self.dtype.itemsize], device="cuda")
         return torch.as_tensor(v, device="cuda")
