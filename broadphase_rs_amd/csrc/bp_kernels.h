@@ -75,12 +75,8 @@ hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* id
                               hipStream_t stream);
 
 // ---- radix sort (K4, K7): stands in for par_sort_unstable, src/layer.rs:149,516 ---------------
-constexpr int RS_THREADS = 512;
-constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 8192 keys per workgroup
 constexpr int RS_BINS = 256;
 constexpr int RS_MAX_PASSES = 12;
-inline size_t rs_tiles(size_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
 struct RadixPlan {
     int n_passes;

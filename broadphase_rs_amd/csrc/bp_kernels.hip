@@ -9,6 +9,8 @@
 #include "bp_kernels.h"
 #include "bp_device.h"
 
+#include <cstdlib>
+
 namespace bp {
 namespace {
 
@@ -321,7 +323,6 @@ __global__ __launch_bounds__(256) void tree_reduce_kernel(const u64* __restrict_
 // =================================================================================================
 // radix sort: one-sweep LSD with decoupled look-back
 // =================================================================================================
-constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr u64 ST_FLAG_AGG = 1ull << 62;   // tile-local digit count published
 constexpr u64 ST_FLAG_PRE = 2ull << 62;   // inclusive prefix over tiles 0..t published
 constexpr u64 ST_VALUE = (1ull << 62) - 1ull;
@@ -378,11 +379,21 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 
 // One radix pass over n records.  K: type carrying the digit (u64 index value / packed pair, or
 // u32 id); V: payload type (u32 id, u64 index value) or NoVal.  Stable.
-template <typename K, typename V>
-__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
+//
+// Phase order inside a tile (chosen so that no tile ever sits idle waiting for its predecessors):
+//   1 ticket + load keys
+//   4 rank (per-wave digit counters, lane-mask match in LDS)
+//   2/3 tile digit counts -> publish AGGREGATE at once
+//   5 tile-local scatter of the keys into LDS (needs no global information)
+//   6 look-back for the global digit bases (predecessors have had phase 5 to publish), PREFIX publish
+//   7 coalesced global stores (+ payload round trip through LDS)
+template <typename K, typename V, int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, int shift, const u64* __restrict__ bin_base,
-                                                                    u64* status, u32* tile_counter, DevScalars* sc) {
+                                                                    u64* status, u32* tile_counter, DevScalars* sc, int dbg) {
+    constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
+    static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
     constexpr size_t STAGE = RS_TILE * (sizeof(K) > StageBytes<V>::value ? sizeof(K) : StageBytes<V>::value);
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE];
@@ -392,94 +403,80 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const K* __r
     __shared__ u32 s_tile;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);  // ticket: tile t only ever waits on tiles < t
+    if (tid == 0) s_tile = (dbg & 2) ? blockIdx.x : atomicAdd(tile_counter, 1u);  // ticket: tile t only ever waits on tiles < t
 #pragma unroll
-    for (int j = tid; j < RS_WAVES * RS_BINS; j += RS_THREADS) (&s_cnt[0][0])[j] = 0;
+    for (int j = tid; j < RS_WAVES * RS_BINS; j += RS_THREADS) {
+        (&s_cnt[0][0])[j] = 0;
+        reinterpret_cast<u64*>(s_stage)[j] = 0ull;  // per-(wave, digit) lane masks of the ranking phase
+    }
     __syncthreads();
     const u32 tile = s_tile;
     const size_t base = (size_t)tile * RS_TILE;
     const u32 tile_n = (u32)((n - base) < (size_t)RS_TILE ? (n - base) : (size_t)RS_TILE);
 
-    // ---- load: wave w owns RS_ITEMS * 64 consecutive records, 64 per round (coalesced) ---------
+    // ---- 1. load: wave w owns RS_ITEMS * 64 consecutive records, 64 per round (coalesced) -------
     K key[RS_ITEMS];
-    u32 packed[RS_ITEMS];  // digit | rank-in-(wave,digit) << 8
+    u32 packed[RS_ITEMS];  // digit | rank-in-(wave,digit) << 8, later the tile-local destination
     const u32 wbase = (u32)w * (64 * RS_ITEMS) + (u32)lane;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 li = wbase + (u32)r * 64u;
         key[r] = li < tile_n ? keys_in[base + li] : (K)0;
     }
-    // ---- rank: wave64 ballot match on the 8 digit bits; per-wave digit counters in LDS ----------
+    u64* my_status = status + (size_t)tile * RS_BINS + tid;
+
+    // ---- 4. rank: peers of a key = lanes of this wave holding the same digit in this round.  Each
+    // lane ORs its lane bit into an LDS mask word per (wave, digit) -- OR is order-independent, so
+    // the result is deterministic -- then reads the word back: one ds_or_b64 + one ds_read_b64
+    // replace an 8-ballot match.  The masks alias the (not yet used) staging buffer.
+    u64* s_mask = reinterpret_cast<u64*>(s_stage) + (size_t)w * RS_BINS;
+    const u64 lanebit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 li = wbase + (u32)r * 64u;
         const bool valid = li < tile_n;
         const u32 dg = (u32)(key[r] >> shift) & 0xFFu;
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(peers >> 32), __builtin_amdgcn_mbcnt_lo((u32)peers, 0u));
-        const u32 npeers = (u32)__popcll(peers);
-        u32 old = 0;
-        if (valid) old = s_cnt[w][dg];
+        if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) s_cnt[w][dg] = old + npeers;
+        u64 peers = 0;
+        u32 old = 0;
+        if (valid) {
+            peers = s_mask[dg];
+            old = s_cnt[w][dg];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(peers >> 32), __builtin_amdgcn_mbcnt_lo((u32)peers, 0u));
+        if (valid && below == 0) {  // lowest peer lane: bump the (wave, digit) counter, clear the mask
+            s_cnt[w][dg] = old + (u32)__popcll(peers);
+            s_mask[dg] = 0ull;
+        }
         __builtin_amdgcn_wave_barrier();
         packed[r] = dg | ((old + below) << 8);
     }
     __syncthreads();
 
-    // ---- per digit: exclusive prefix over the waves, tile offset, look-back for the global base -
+    // ---- 2./3. per digit: count over the waves = this tile's AGGREGATE, published at once; then the
+    // exclusive prefix over the digits (tile-local offsets) and over the waves
     u32 total = 0;
     if (tid < RS_BINS) {
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) {
-            const u32 c = s_cnt[ww][tid];
-            s_cnt[ww][tid] = total;
-            total += c;
-        }
+        for (int ww = 0; ww < RS_WAVES; ++ww) total += s_cnt[ww][tid];
+        if (tile != 0 && !(dbg & 1)) st_store(my_status, ST_FLAG_AGG | (u64)total);
     }
     u32 tile_total;
     const u32 tile_off = block_excl_scan_u32<RS_THREADS>(total, s_ws, tile_total);
     if (tid < RS_BINS) {
-        u64* my = status + (size_t)tile * RS_BINS + tid;
-        u64 excl = 0;
-        if (tile == 0) {
-            st_store(my, ST_FLAG_PRE | (u64)total);
-        } else {
-            st_store(my, ST_FLAG_AGG | (u64)total);
-            size_t p = tile;
-            u32 spins = 0;
-            while (p > 0) {
-                const u64 s = st_load(status + (p - 1) * RS_BINS + tid);
-                const u64 f = s >> 62;
-                if (f == 2) {
-                    excl += s & ST_VALUE;
-                    break;
-                } else if (f == 1) {
-                    excl += s & ST_VALUE;
-                    --p;
-                } else {
-                    if (++spins > LOOKBACK_SPIN_LIMIT) {  // never expected; keeps every wave finite
-                        atomicOr(&sc->err, KERR_LOOKBACK_TIMEOUT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            st_store(my, ST_FLAG_PRE | (excl + (u64)total));
-        }
-        s_glob[tid] = bin_base[tid] + excl - (u64)tile_off;
+        u32 run = tile_off;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) s_cnt[ww][tid] += tile_off;
+        for (int ww = 0; ww < RS_WAVES; ++ww) {
+            const u32 c = s_cnt[ww][tid];
+            s_cnt[ww][tid] = run;
+            run += c;
+        }
     }
     __syncthreads();
 
-    // ---- keys: scatter into tile-sorted order in LDS, then stream out coalesced ------------------
+    // ---- 5. keys: scatter into tile-sorted order in LDS -----------------------------------------
     K* stage_k = reinterpret_cast<K*>(s_stage);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -491,7 +488,53 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const K* __r
             stage_k[pos] = key[r];
         }
     }
+
+    // ---- 6. look-back: global base of every digit = bin_base + sum of the predecessors' counts ---
+    if (tid < RS_BINS) {
+        u64 excl = 0;
+        if (tile == 0 || (dbg & 1)) {
+            st_store(my_status, ST_FLAG_PRE | (u64)total);
+        } else {
+            // LB_BATCH independent status loads per step (one fabric round trip per step instead of
+            // per predecessor).  Tile 0 always holds a prefix, so the walk ends there at the latest.
+            constexpr int LB_BATCH = 8;
+            size_t p = tile;  // tiles [p, tile) are already summed into excl
+            u32 spins = 0;
+            bool done = false;
+            while (!done) {
+                u64 sv[LB_BATCH];
+#pragma unroll
+                for (int k = 0; k < LB_BATCH; ++k) {
+                    const size_t q = p > (size_t)k ? p - 1 - (size_t)k : 0;
+                    sv[k] = st_load(status + q * RS_BINS + tid);
+                }
+                size_t consumed = 0;
+#pragma unroll
+                for (int k = 0; k < LB_BATCH; ++k) {
+                    if (!done && consumed == (size_t)k) {
+                        const u64 f = sv[k] >> 62;
+                        if (f == 2) { excl += sv[k] & ST_VALUE; done = true; }
+                        else if (f == 1) { excl += sv[k] & ST_VALUE; consumed = (size_t)k + 1; }
+                    }
+                }
+                if (!done) {
+                    p -= consumed;
+                    if (consumed == 0) {
+                        if (++spins > LOOKBACK_SPIN_LIMIT) {  // never expected; keeps every wave finite
+                            atomicOr(&sc->err, KERR_LOOKBACK_TIMEOUT);
+                            done = true;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            st_store(my_status, ST_FLAG_PRE | (excl + (u64)total));
+        }
+        s_glob[tid] = bin_base[tid] + excl - (u64)tile_off;
+    }
     __syncthreads();
+
+    // ---- 7. stream the tile out: consecutive threads write consecutive records of a digit run ----
     u32 out_dg[RS_ITEMS];
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
@@ -775,14 +818,47 @@ RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned 
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// tile geometry, selectable at run time for A/B measurements (BP_RS_CONFIG=0..3)
+struct RsConfig { int threads, items; };
+static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 8}, {256, 8}, {1024, 16}};
+static int rs_config_id() {
+    static int id = -1;
+    if (id < 0) {
+        const char* e = getenv("BP_RS_CONFIG");
+        id = e ? atoi(e) : 0;
+        if (id < 0 || id >= (int)(sizeof(RS_CONFIGS) / sizeof(RS_CONFIGS[0]))) id = 0;
+    }
+    return id;
+}
+static size_t rs_tile_size() { return (size_t)RS_CONFIGS[rs_config_id()].threads * RS_CONFIGS[rs_config_id()].items; }
+static size_t rs_num_tiles(size_t n) { return (n + rs_tile_size() - 1) / rs_tile_size(); }
+
 size_t radix_workspace_bytes(size_t n, int n_passes) {
     const size_t np = (size_t)(n_passes > 0 ? n_passes : 1);
     size_t b = 0;
     b += np * RS_BINS * sizeof(u64);                      // hist
     b += np * RS_BINS * sizeof(u64);                      // bin_base
     b += align_up(np * sizeof(u32), 256);                 // tile counters
-    b += np * rs_tiles(n) * RS_BINS * sizeof(u64);        // status
+    b += np * rs_num_tiles(n) * RS_BINS * sizeof(u64);    // status
     return align_up(b, 256);
+}
+
+template <typename K, typename V>
+static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, int shift, const u64* bb, u64* st,
+                                  u32* tc, DevScalars* sc, hipStream_t stream) {
+    const unsigned tiles = (unsigned)rs_num_tiles(n);
+    static int dbg_env = -1;
+    if (dbg_env < 0) { const char* e = getenv("BP_RS_DEBUG"); dbg_env = e ? atoi(e) : 0; }
+    const int dbg = StageBytes<V>::value == 0 ? dbg_env : 0;  // timing experiments: keys-only passes only
+    switch (rs_config_id()) {
+        case 1: radix_onesweep_kernel<K, V, 256, 16><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        case 2: radix_onesweep_kernel<K, V, 1024, 8><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        case 3: radix_onesweep_kernel<K, V, 512, 8><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        case 4: radix_onesweep_kernel<K, V, 256, 8><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        case 5: radix_onesweep_kernel<K, V, 1024, 16><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        default: radix_onesweep_kernel<K, V, 512, 16><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
@@ -792,13 +868,14 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
+    if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (radix_workspace_bytes(n, np) > workspace_bytes) return hipErrorInvalidValue;
     unsigned char* ws = (unsigned char*)workspace;
     u64* hist = (u64*)ws;
     u64* bin_base = hist + (size_t)np * RS_BINS;
     u32* counters = (u32*)(bin_base + (size_t)np * RS_BINS);
     u64* status = (u64*)((unsigned char*)counters + align_up((size_t)np * sizeof(u32), 256));
-    const size_t tiles = rs_tiles(n);
+    const size_t tiles = rs_num_tiles(n);
     hipError_t e;
 
     if (mark) mark(mark_ctx, class_hist);
@@ -820,16 +897,13 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         u64* st = status + (size_t)p * tiles * RS_BINS;
         u32* tc = counters + p;
         if (!vals0) {
-            radix_onesweep_kernel<u64, NoVal><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
-                kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, plan.shift[p], bb, st, tc, sc);
+            e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, plan.shift[p], bb, st, tc, sc, stream);
         } else if (plan.from_val[p]) {
-            radix_onesweep_kernel<u32, u64><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
-                vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc);
+            e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc, stream);
         } else {
-            radix_onesweep_kernel<u64, u32><<<(unsigned)tiles, RS_THREADS, 0, stream>>>(
-                kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc);
+            e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc, stream);
         }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (e != hipSuccess) return e;
         if (mark) mark(mark_ctx, -1);
         cur ^= 1;
     }
