@@ -97,6 +97,20 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort);
 
+// ---- multi-GPU bucketing: one stable one-sweep pass with a custom digit (<= 256 buckets) --------
+// entries -> owner rank by Morton cell at split_depth (lut on the device), coarse entries
+// (depth < split_depth) -> bucket `coarse_bucket`; *d_hist (device, 256 u64) = bucket sizes
+hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
+                             const unsigned char* d_lut, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
+                             uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
+                             const unsigned long long** d_hist, hipStream_t stream);
+// packed pairs -> owner rank of the first id; bounds[i] = first id owned by rank i+1
+hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
+                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream);
+// entries per cell at split_depth; slot n_cells counts the coarse entries
+hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
+                            uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream);
+
 // ---- overlap scan (K5, K6): reference src/layer.rs:550-573 --------------------------------------
 constexpr int SCAN_THREADS = 256;
 inline size_t scan_blocks(size_t m) { return (m + SCAN_THREADS - 1) / SCAN_THREADS; }

@@ -360,6 +360,40 @@ __global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __r
     }
 }
 
+// one digit histogram with an arbitrary digit functor (partition passes)
+template <typename DigitFn>
+__global__ __launch_bounds__(HIST_THREADS) void digit_hist_kernel(const u64* __restrict__ keys, size_t n, DigitFn digit,
+                                                                  u64* __restrict__ hist) {
+    __shared__ u32 h[RS_BINS];
+    for (int j = threadIdx.x; j < RS_BINS; j += HIST_THREADS) h[j] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS)
+        atomicAdd(&h[digit(keys[i])], 1u);
+    __syncthreads();
+    for (int j = threadIdx.x; j < RS_BINS; j += HIST_THREADS) {
+        const u32 c = h[j];
+        if (c) atomicAdd(&hist[j], (u64)c);
+    }
+}
+
+// multi-GPU splitter selection: entries per cell at split_depth (+ one slot for coarse entries)
+__global__ __launch_bounds__(256) void cell_hist_kernel(const u64* __restrict__ keys, size_t m, int cell_shift, u32 depth_mask,
+                                                        u32 split_depth, u32 n_cells, u64* __restrict__ hist) {
+    extern __shared__ u32 h_dyn[];
+    for (u32 j = threadIdx.x; j <= n_cells; j += 256) h_dyn[j] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
+        const u64 k = keys[i];
+        const u32 slot = ((u32)k & depth_mask) < split_depth ? n_cells : (u32)(k >> cell_shift);
+        atomicAdd(&h_dyn[slot], 1u);
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j <= n_cells; j += 256) {
+        const u32 c = h_dyn[j];
+        if (c) atomicAdd(&hist[j], (u64)c);
+    }
+}
+
 // per pass: exclusive scan of the 256 global digit counts -> bin_base
 __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __restrict__ hist, u64* __restrict__ bin_base) {
     __shared__ u64 s_wave[RS_BINS / 64];
@@ -372,6 +406,30 @@ __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __res
     for (int k = 0; k < w; ++k) base += s_wave[k];
     bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
 }
+
+// digit functors: what a one-sweep pass buckets by
+struct ShiftDigit {  // LSD radix digit
+    int shift;
+    template <typename K> __device__ __forceinline__ u32 operator()(K k) const { return (u32)(k >> shift) & 0xFFu; }
+};
+struct EntryDestDigit {  // multi-GPU: owner rank of an index entry (Morton range), coarse entries -> extra bucket
+    const unsigned char* lut;  // [cells at split_depth] -> owner
+    int cell_shift;
+    u32 depth_mask, split_depth, coarse_bucket;
+    __device__ __forceinline__ u32 operator()(u64 k) const {
+        return ((u32)k & depth_mask) < split_depth ? coarse_bucket : (u32)lut[(size_t)(k >> cell_shift)];
+    }
+};
+struct PairOwnerDigit {  // multi-GPU: owner rank of a packed pair = range of its first id
+    u32 bounds[15];  // first id owned by rank 1, 2, ...
+    int n;
+    __device__ __forceinline__ u32 operator()(u64 k) const {
+        const u32 id = (u32)(k >> 32);
+        u32 d = 0;
+        for (int i = 0; i < n; ++i) d += id >= bounds[i] ? 1u : 0u;
+        return d;
+    }
+};
 
 template <typename T> struct StageBytes { static constexpr size_t value = sizeof(T); };
 struct NoVal {};
@@ -387,10 +445,10 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 //   5 tile-local scatter of the keys into LDS (needs no global information)
 //   6 look-back for the global digit bases (predecessors have had phase 5 to publish), PREFIX publish
 //   7 coalesced global stores (+ payload round trip through LDS)
-template <typename K, typename V, int THREADS, int ITEMS>
+template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
 __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
-                                                                    size_t n, int shift, const u64* __restrict__ bin_base,
+                                                                    size_t n, DigitFn digit, const u64* __restrict__ bin_base,
                                                                     u64* status, u32* tile_counter, DevScalars* sc, int dbg) {
     constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
     static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
@@ -435,7 +493,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 li = wbase + (u32)r * 64u;
         const bool valid = li < tile_n;
-        const u32 dg = (u32)(key[r] >> shift) & 0xFFu;
+        const u32 dg = digit(key[r]);
         if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
         u64 peers = 0;
@@ -542,7 +600,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
         out_dg[k] = 0;
         if (li < tile_n) {
             const K kk = stage_k[li];
-            const u32 dg = (u32)(kk >> shift) & 0xFFu;
+            const u32 dg = digit(kk);
             out_dg[k] = dg;
             size_t g = (size_t)(s_glob[dg] + (u64)li);
             if (g < n) keys_out[g] = kk;  // g < n always holds unless a look-back timed out
@@ -820,7 +878,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // tile geometry, selectable at run time for A/B measurements (BP_RS_CONFIG=0..3)
 struct RsConfig { int threads, items; };
-static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 8}, {256, 8}, {1024, 16}};
+static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {512, 16}, {1024, 16}};
 static int rs_config_id() {
     static int id = -1;
     if (id < 0) {
@@ -843,20 +901,18 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
     return align_up(b, 256);
 }
 
-template <typename K, typename V>
-static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, int shift, const u64* bb, u64* st,
+template <typename K, typename V, typename DigitFn>
+static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream) {
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     static int dbg_env = -1;
     if (dbg_env < 0) { const char* e = getenv("BP_RS_DEBUG"); dbg_env = e ? atoi(e) : 0; }
     const int dbg = StageBytes<V>::value == 0 ? dbg_env : 0;  // timing experiments: keys-only passes only
     switch (rs_config_id()) {
-        case 1: radix_onesweep_kernel<K, V, 256, 16><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
-        case 2: radix_onesweep_kernel<K, V, 1024, 8><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
-        case 3: radix_onesweep_kernel<K, V, 512, 8><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
-        case 4: radix_onesweep_kernel<K, V, 256, 8><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
-        case 5: radix_onesweep_kernel<K, V, 1024, 16><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
-        default: radix_onesweep_kernel<K, V, 512, 16><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, shift, bb, st, tc, sc, dbg); break;
+        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
+        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
+        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
+        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
     }
     return hipGetLastError();
 }
@@ -897,11 +953,11 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         u64* st = status + (size_t)p * tiles * RS_BINS;
         u32* tc = counters + p;
         if (!vals0) {
-            e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, plan.shift[p], bb, st, tc, sc, stream);
+            e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else if (plan.from_val[p]) {
-            e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc, stream);
+            e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else {
-            e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, plan.shift[p], bb, st, tc, sc, stream);
+            e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         }
         if (e != hipSuccess) return e;
         if (mark) mark(mark_ctx, -1);
@@ -909,6 +965,55 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     }
     *result_buf = cur;
     return hipSuccess;
+}
+
+// one stable bucketing pass (<= 256 buckets) with an arbitrary digit functor; hist[256] (device,
+// inside the workspace) holds the bucket sizes afterwards
+template <typename V, typename DigitFn>
+static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, size_t n, DigitFn fn, void* workspace,
+                                 size_t workspace_bytes, DevScalars* sc, const u64** d_hist, hipStream_t stream) {
+    if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (radix_workspace_bytes(n, 1) > workspace_bytes) return hipErrorInvalidValue;
+    unsigned char* ws = (unsigned char*)workspace;
+    u64* hist = (u64*)ws;
+    u64* bin_base = hist + RS_BINS;
+    u32* counters = (u32*)(bin_base + RS_BINS);
+    u64* status = (u64*)((unsigned char*)counters + align_up(sizeof(u32), 256));
+    hipError_t e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(n, 1), stream);
+    if (e != hipSuccess) return e;
+    *d_hist = hist;
+    if (n == 0) return hipSuccess;
+    digit_hist_kernel<DigitFn><<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(ki, n, fn, hist);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    radix_binbase_kernel<<<1, RS_BINS, 0, stream>>>(hist, bin_base);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream);
+}
+
+hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
+                             const unsigned char* d_lut, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
+                             uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
+                             const unsigned long long** d_hist, hipStream_t stream) {
+    EntryDestDigit fn{d_lut, cell_shift, depth_mask, split_depth, coarse_bucket};
+    return partition_pass<u32, EntryDestDigit>((const u64*)keys_in, (u64*)keys_out, ids_in, ids_out, m, fn, workspace,
+                                               workspace_bytes, sc, (const u64**)d_hist, stream);
+}
+
+hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
+                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream) {
+    PairOwnerDigit fn;
+    fn.n = n_bounds;
+    for (int i = 0; i < 15; ++i) fn.bounds[i] = i < n_bounds ? bounds[i] : 0xFFFFFFFFu;
+    return partition_pass<NoVal, PairOwnerDigit>((const u64*)in, (u64*)out, (const NoVal*)nullptr, (NoVal*)nullptr, n, fn, workspace,
+                                                 workspace_bytes, sc, (const u64**)d_hist, stream);
+}
+
+hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
+                            uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    cell_hist_kernel<<<grid_for(m, 256 * 8, 512), 256, (n_cells + 1) * sizeof(u32), stream>>>((const u64*)keys, m, cell_shift, depth_mask,
+                                                                                              split_depth, n_cells, (u64*)d_hist);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream) {

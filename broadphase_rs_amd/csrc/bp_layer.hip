@@ -411,27 +411,28 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
     return BP_OK;
 }
 
-// sort + dedup of n packed pairs sitting in L->pairs[0] -> L->out_pairs (interleaved), L->n_pairs
-int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying) {
+// sort + dedup of n packed pairs sitting in buf0 (scratch partner: L->pairs[1]) -> L->out_pairs
+// (interleaved), L->n_pairs
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying) {
     L->n_pairs = 0;
     L->stats.pairs = 0;
     if (n == 0) return BP_OK;
-    const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
     const RadixPlan plan = make_radix_plan(varying, 0, 0);
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
+    uint64_t* bufs[2] = {buf0, nullptr};
     if (plan.n_passes > 0 && n > 1) {
         BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+        bufs[1] = (uint64_t*)L->pairs[1].p;
         const size_t wsb = radix_workspace_bytes(n, plan.n_passes);
         BP_TRY(ensure_dev(L, L->radix_ws, wsb));
         BP_TRY(sc_reset(L));
-        HIP_TRY(L, radix_sort((uint64_t*)L->pairs[0].p, (uint64_t*)L->pairs[1].p, nullptr, nullptr, n, plan, L->radix_ws.p,
-                              L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST,
-                              BP_K_PAIR_SORT));
+        HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
+                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT));
     } else {
         BP_TRY(sc_reset(L));
     }
-    const uint64_t* sorted = (const uint64_t*)L->pairs[res].p;
+    const uint64_t* sorted = bufs[res];
     const size_t nb = uq_blocks(n);
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
     {
@@ -454,6 +455,10 @@ int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying) {
     L->n_pairs = np;
     L->stats.pairs = np;
     return BP_OK;
+}
+
+int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying) {
+    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, ((unsigned long long)id_varying << 32) | id_varying);
 }
 
 int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
@@ -748,6 +753,124 @@ int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in,
     }
     L->n_raw = n;
     BP_TRY(sort_unique_pairs(L, n, 0xFFFFFFFFu));  // nothing is known about foreign ids: all 64 bits vary
+    if (n == 0) BP_TRY(sync_stream(L));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_append_entries_assume(bp_layer_t* L, const uint64_t* keys, const uint32_t* ids, size_t m, uint32_t facts) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    const bool was_empty = L->m == 0;
+    const bool order_before = L->order_ok, distinct_before = L->ids_distinct;
+    BP_TRY(bp_layer_append_entries(L, keys, ids, m));
+    if (m) {  // append_entries dropped both facts; restore what the caller vouches for
+        L->order_ok = (was_empty || order_before) && (facts & BP_FACT_ORDER_OK);
+        L->ids_distinct = (was_empty || distinct_before) && (facts & BP_FACT_IDS_DISTINCT);
+    }
+    return BP_OK;
+}
+
+int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist, size_t n_cells) {
+    if (!L || !hist) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_cell_histogram: null argument");
+    const KindInfo ki = kind_info(L->kind);
+    if (split_depth == 0 || split_depth > ki.axis_bits || n_cells != ((size_t)1 << (ki.dim * split_depth)) || n_cells > 4096)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_cell_histogram: n_cells must be 2^(dim*split_depth) <= 4096");
+    DeviceGuard g(L->device);
+    const size_t bytes = (n_cells + 1) * sizeof(unsigned long long);
+    BP_TRY(ensure_dev(L, L->block_sums, bytes));
+    BP_TRY(ensure_host(L, L->h_raw, bytes));
+    HIP_TRY(L, hipMemsetAsync(L->block_sums.p, 0, bytes, L->stream));
+    const int cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * split_depth);
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_cell_hist(cur_keys(L), L->m, cell_shift, (1u << ki.depth_bits) - 1u, split_depth, (uint32_t)n_cells,
+                                    (unsigned long long*)L->block_sums.p, L->stream));
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, L->block_sums.p, bytes, hipMemcpyDeviceToHost, L->stream));
+    BP_TRY(sync_stream(L));
+    std::memcpy(hist, L->h_raw.p, bytes);
+    return BP_OK;
+}
+
+int bp_layer_partition_entries_device(bp_layer_t* L, uint32_t split_depth, const uint8_t* lut, size_t n_cells, uint32_t n_dest,
+                                      uint64_t* counts, const uint64_t** d_keys, const uint32_t** d_ids) {
+    if (!L || !lut || !counts || !d_keys || !d_ids) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: null argument");
+    const KindInfo ki = kind_info(L->kind);
+    if (split_depth == 0 || split_depth > ki.axis_bits || n_cells != ((size_t)1 << (ki.dim * split_depth)) || n_cells > 4096 ||
+        n_dest == 0 || n_dest > 255)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: bad split_depth / n_cells / n_dest");
+    DeviceGuard g(L->device);
+    const int other = L->cur ^ 1;
+    for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = 0;
+    BP_TRY(ensure_dev(L, L->keys[other], std::max<size_t>(L->m, 1) * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->ids[other], std::max<size_t>(L->m, 1) * sizeof(uint32_t)));
+    *d_keys = (const uint64_t*)L->keys[other].p;
+    *d_ids = (const uint32_t*)L->ids[other].p;
+    if (L->m == 0) return BP_OK;
+    BP_TRY(ensure_dev(L, L->skip, n_cells));  // device copy of the lut
+    HIP_TRY(L, hipMemcpyAsync(L->skip.p, lut, n_cells, hipMemcpyHostToDevice, L->stream));
+    BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, 1)));
+    BP_TRY(ensure_host(L, L->h_raw, 256 * sizeof(unsigned long long)));
+    BP_TRY(sc_reset(L));
+    const int cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * split_depth);
+    const unsigned long long* d_hist = nullptr;
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, partition_entries(cur_keys(L), (uint64_t*)L->keys[other].p, cur_ids(L), (uint32_t*)L->ids[other].p, L->m,
+                                     (const unsigned char*)L->skip.p, cell_shift, (1u << ki.depth_bits) - 1u, split_depth, n_dest,
+                                     L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream));
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = ((const unsigned long long*)L->h_raw.p)[i];
+    return BP_OK;
+}
+
+int bp_layer_scan_raw_shard_device(bp_layer_t* L, uint32_t coarse_depth, int emit_coarse, const uint64_t** d_packed, size_t* n_raw) {
+    if (!L || !d_packed || !n_raw) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_raw_shard: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
+    BP_TRY(sync_stream(L));
+    *d_packed = (const uint64_t*)L->pairs[0].p;
+    *n_raw = L->n_raw;
+    return BP_OK;
+}
+
+int bp_layer_partition_pairs_device(bp_layer_t* L, const uint64_t* d_packed, size_t n, const uint32_t* bounds, uint32_t n_bounds,
+                                    uint64_t* counts, const uint64_t** d_out) {
+    if (!L || !counts || !d_out || (n && !d_packed) || (n_bounds && !bounds) || n_bounds > 15)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_pairs: bad argument");
+    DeviceGuard g(L->device);
+    for (uint32_t i = 0; i <= n_bounds; ++i) counts[i] = 0;
+    // write into whichever pair buffer is not the input
+    DevBuf& dst = (d_packed == (const uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];
+    BP_TRY(ensure_dev(L, dst, std::max<size_t>(n, 1) * sizeof(uint64_t)));
+    *d_out = (const uint64_t*)dst.p;
+    if (n == 0) return BP_OK;
+    BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(n, 1)));
+    BP_TRY(ensure_host(L, L->h_raw, 256 * sizeof(unsigned long long)));
+    BP_TRY(sc_reset(L));
+    const unsigned long long* d_hist = nullptr;
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, partition_pairs(d_packed, (uint64_t*)dst.p, n, bounds, (int)n_bounds, L->radix_ws.p, L->radix_ws.cap,
+                                   (DevScalars*)L->d_sc.p, &d_hist, L->stream));
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    for (uint32_t i = 0; i <= n_bounds; ++i) counts[i] = ((const unsigned long long*)L->h_raw.p)[i];
+    return BP_OK;
+}
+
+int bp_layer_sort_unique_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask,
+                                       const uint32_t** d_pairs, size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs || (n && !d_packed)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_unique_packed: null argument");
+    DeviceGuard g(L->device);
+    L->n_raw = n;
+    BP_TRY(sort_unique_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull));
     if (n == 0) BP_TRY(sync_stream(L));
     *d_pairs = (const uint32_t*)L->out_pairs.p;
     *n_pairs = L->n_pairs;

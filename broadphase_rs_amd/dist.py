@@ -1,0 +1,244 @@
+"""Multi-GPU `Layer`: objects shard across the GPUs of one node, index entries and raw pairs are
+exchanged by range over RCCL (torch.distributed, one process per GPU).
+
+The reference is single-process; its only partitioning idea is the `min_depth` split of the sorted
+array at cell boundaries (src/layer.rs:533-546), which works because an entry only ever interacts
+with the entries whose cell contains its own.  The same property shards the path across GPUs:
+
+  1. every rank encodes its own objects (extend)                                  [local, HIP]
+  2. entries per Morton cell at `split_depth` are counted and all-reduced; contiguous cell ranges
+     are assigned to ranks so that entry counts balance                           [allreduce, tiny]
+  3. entries move to the owner of their cell (all-to-all); the few entries coarser than
+     `split_depth` ("boundary keys": cells that span several ranges) are all-gathered so that
+     every rank holds every possible ancestor of its own entries                  [all-to-all + allgather]
+  4. every rank sorts and scans its shard; pairs whose deeper entry is a coarse (replicated)
+     entry are emitted by rank 0 only                                             [local, HIP]
+  5. raw pairs move to the owner of their first id (all-to-all); a pair can be produced on two
+     ranks when an object's cells fall into different ranges, so duplicate removal has to happen
+     after this exchange; each rank sorts + dedups its id range                   [all-to-all; local, HIP]
+
+The concatenation of the per-rank results in rank order is exactly the single-GPU pair list.
+All device work goes through the C ABI (`Layer`); torch supplies tensors and collectives only.
+A backend object isolates the compute so that the exchange logic can be exercised with gloo on
+CPU in tests (tests/test_dist_cpu.py provides an oracle-backed backend; the product has none).
+"""
+import numpy as np
+
+from .layer import Index64_3D, Layer
+
+
+def choose_owner_lut(hist_fine, n_ranks):
+    """Contiguous, balanced assignment of Morton cells to ranks: cell c -> owner.  Deterministic in
+    its inputs, so every rank computes the same table from the all-reduced histogram."""
+    hist = np.asarray(hist_fine, dtype=np.float64)
+    total = float(hist.sum())
+    lut = np.zeros(len(hist), dtype=np.uint8)
+    if total <= 0:
+        return lut
+    cum = np.cumsum(hist)
+    # cell c goes to rank floor(G * (entries before the middle of c) / total)
+    mid = cum - hist * 0.5
+    owner = np.minimum((mid * n_ranks / total).astype(np.int64), n_ranks - 1)
+    owner = np.maximum.accumulate(owner)  # contiguous ranges
+    return owner.astype(np.uint8)
+
+
+def id_range_bounds(max_id, n_ranks):
+    """first id owned by rank 1..G-1 when [0, max_id] is cut into G equal ranges"""
+    span = (int(max_id) + n_ranks) // n_ranks
+    return np.array([min(span * (r + 1), 0xFFFFFFFF) for r in range(n_ranks - 1)], dtype=np.uint32)
+
+
+def _varying_bits(lo, hi):
+    """mask of the bits that can differ among integers in [lo, hi]"""
+    if hi <= lo:
+        return 0
+    x = int(lo) ^ int(hi)
+    return (1 << x.bit_length()) - 1
+
+
+class HipBackend:
+    """Device compute of one rank through the C ABI: a `local` layer (encode target) and a `shard`
+    layer (sort/scan target)."""
+
+    def __init__(self, index, min_depth, device):
+        import torch
+        self.torch = torch
+        self.index = index
+        self.device = torch.device("cuda", device)
+        self.local = Layer(index, min_depth, device=device)
+        self.shard = Layer(index, min_depth, device=device)
+
+    # -- encode -------------------------------------------------------------------------------------
+    def local_clear(self):
+        self.local.clear()
+
+    def local_extend(self, system_bounds, bounds, ids):
+        self.local.extend(system_bounds, bounds, ids)
+
+    def local_cell_histogram(self, split_depth):
+        return self.local.cell_histogram(split_depth)
+
+    def local_partition_entries(self, split_depth, lut, n_ranks):
+        counts, keys, ids = self.local.partition_entries_device(split_depth, lut, n_ranks)
+        return counts, keys.as_torch(), ids.as_torch()
+
+    # -- shard ----------------------------------------------------------------------------------------
+    def shard_set_entries(self, chunks):
+        """chunks: [(keys int64 tensor, ids int32 tensor)] in an order for which equal index values
+        carry non-decreasing ids; ids are distinct across objects."""
+        self.shard.clear()
+        for keys, ids in chunks:
+            if keys.numel():
+                self.shard.append_entries_assume(keys.data_ptr(), ids.data_ptr(), int(keys.numel()), True, True)
+
+    def shard_scan_raw(self, coarse_depth, emit_coarse):
+        return self.shard.scan_raw_shard_device(coarse_depth, emit_coarse).as_torch()
+
+    def partition_pairs(self, packed, bounds):
+        counts, out = self.shard.partition_pairs_device(packed.data_ptr(), int(packed.numel()), bounds)
+        return counts, out.as_torch()
+
+    def sort_unique_packed(self, packed, varying_mask):
+        return self.shard.sort_unique_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
+
+    def empty(self, n, dtype):
+        return self.torch.empty(n, dtype=dtype, device=self.device)
+
+    def sync(self):
+        """collectives run on torch's streams, the layers on their own: fence between the two"""
+        self.torch.cuda.synchronize(self.device)
+
+
+class TorchComm:
+    """collectives of one rank over a torch.distributed process group (nccl = RCCL on ROCm, gloo on CPU)"""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce_sum(self, arr, backend):
+        t = self.torch.from_numpy(np.asarray(arr).astype(np.int64)).to(backend.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def all_reduce_max(self, value, backend):
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=backend.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def all_to_all_v(self, send, send_counts, dtype, backend):
+        """variable-size all-to-all of a tensor that is already grouped by destination"""
+        torch, dist = self.torch, self.dist
+        sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=send.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(c) for c in rc.cpu().tolist()]
+        recv = backend.empty(sum(recv_counts), dtype)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
+                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        backend.sync()
+        return recv
+
+    def all_gather_v(self, t, dtype, backend):
+        """all-gather of per-rank tensors of different lengths, concatenated in rank order"""
+        torch, dist = self.torch, self.dist
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+        sizes = [torch.empty_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes)
+        if mx == 0:
+            return backend.empty(0, dtype)
+        pad = backend.empty(mx, dtype)
+        pad[: t.numel()] = t
+        if t.numel() < mx:
+            pad[t.numel():] = 0
+        parts = [backend.empty(mx, dtype) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        out = torch.cat([p[:s] for p, s in zip(parts, sizes)])
+        backend.sync()
+        return out
+
+
+class ShardedLayer:
+    """`Layer` across the ranks of a torch.distributed process group (weak scaling: every rank
+    extends its own objects).  Method names follow the reference; `par_scan_device` returns this
+    rank's slice (a contiguous first-id range) of the global sorted, duplicate-free pair list."""
+
+    def __init__(self, index=Index64_3D, min_depth=0, device=0, n_global=None, split_depth=None, group=None,
+                 backend=None, comm=None):
+        import torch
+        self.torch = torch
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.rank, self.world = self.comm.rank, self.comm.world
+        self.index = index
+        self.backend = backend if backend is not None else HipBackend(index, min_depth, device)
+        # cells at split_depth are the unit of ownership: 8^3 = 512 (3-D) / 4^4 = 256 (2-D) cells
+        self.split_depth = split_depth if split_depth is not None else (3 if index.dim == 3 else 4)
+        self.n_global = n_global
+        self.max_id_local = -1
+        self.last = {}
+
+    @property
+    def shard_layer(self):
+        return self.backend.shard
+
+    def clear(self):
+        self.backend.local_clear()
+        self.max_id_local = -1
+
+    def extend(self, system_bounds, bounds, ids):
+        self.backend.local_extend(system_bounds, bounds, ids)
+        if self.n_global is None and len(ids):
+            if hasattr(ids, "max") and hasattr(ids, "is_cuda"):
+                self.max_id_local = max(self.max_id_local, int(ids.to(self.torch.int64).max().item()) & 0xFFFFFFFF)
+            else:
+                self.max_id_local = max(self.max_id_local, int(np.asarray(ids).max()))
+
+    # ---- the pipeline --------------------------------------------------------------------------------------
+    def par_scan_device(self):
+        torch, G, be, comm = self.torch, self.world, self.backend, self.comm
+        d_s = self.split_depth
+        # 2. balanced contiguous Morton ranges from the all-reduced cell histogram
+        hist_all = comm.all_reduce_sum(be.local_cell_histogram(d_s), be)
+        lut = choose_owner_lut(hist_all[:-1], G)
+        # 3. entries -> owners (fine), boundary keys -> everyone (coarse)
+        counts, keys, ids = be.local_partition_entries(d_s, lut, G)
+        n_fine = int(counts[:G].sum())
+        rk = comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be)
+        ri = comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be)
+        ck = comm.all_gather_v(keys[n_fine:n_fine + int(counts[G])], torch.int64, be)
+        ci = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be)
+        # received chunks arrive in rank order and every rank's entries are in id order, so equal index
+        # values carry non-decreasing ids (fine and coarse entries never share an index value)
+        be.shard_set_entries([(rk, ri), (ck, ci)])
+        # 4. local sort + scan; coarse-coarse pairs only once
+        raw = be.shard_scan_raw(d_s, self.rank == 0)
+        # 5. raw pairs -> owner of the first id, then sort + dedup per id range
+        if self.n_global is not None:
+            max_id = int(self.n_global) - 1
+        else:
+            max_id = max(comm.all_reduce_max(self.max_id_local, be), 0)
+        bounds = id_range_bounds(max_id, G)
+        pcounts, grouped = be.partition_pairs(raw, bounds)
+        rp = comm.all_to_all_v(grouped, pcounts, torch.int64, be)
+        lo = 0 if self.rank == 0 else int(bounds[self.rank - 1])
+        hi = max_id if self.rank == G - 1 else int(bounds[self.rank]) - 1
+        varying = (_varying_bits(lo, max(hi, lo)) << 32) | _varying_bits(0, max_id)
+        out = be.sort_unique_packed(rp, varying)
+        self.last = {"entries_local": int(counts.sum()), "entries_shard": int(rk.numel() + ck.numel()),
+                     "coarse": int(ck.numel()), "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
+                     "pairs": len(out), "id_range": (lo, hi)}
+        return out
+
+    # reference names
+    def par_scan(self):
+        out = self.par_scan_device()
+        return out.to_numpy() if hasattr(out, "to_numpy") else out
+
+    def scan(self):
+        return self.par_scan()

@@ -24,6 +24,23 @@ def gen_boxes(count, seed=0, density=0.001, size_range=(1.0, 10.0)):
     return sysb, bounds, np.arange(count, dtype=np.uint32)
 
 
+def gen_boxes_shard(count_global, rank, world, seed=0, density=0.001, size_range=(1.0, 10.0)):
+    """Rank `rank`'s share of one global gen_boxes scene of count_global objects: the same system
+    bounds on every rank (side from the GLOBAL count), objects drawn independently per rank, ids
+    [rank * n, (rank + 1) * n).  Statistically the global scene sharded by object index."""
+    n = count_global // world
+    rng = np.random.Generator(np.random.PCG64([seed, rank, world]))
+    lo, hi = np.float32(size_range[0]), np.float32(size_range[1])
+    avg = (lo + hi) / np.float32(2)
+    linear = np.float32(np.cbrt(np.float32(count_global) / np.float32(density))) + avg
+    size = lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)
+    mn = (linear - size) * rng.random((n, 3), dtype=np.float32)
+    mx = mn + size
+    bounds = np.concatenate([mn, mx], axis=1).astype(np.float32)
+    sysb = np.array([[0, 0, 0], [linear, linear, linear]], dtype=np.float32)
+    return sysb, bounds, (np.arange(n, dtype=np.uint32) + np.uint32(rank * n))
+
+
 def gen_boxes_powerlaw(count, seed=0, density=0.001, alpha=2.5, cap_frac=0.25):
     """Mixed-scale scene (BASELINE.json configs[4]): same placement as gen_boxes, isotropic size
     ~ Pareto(x_m=1, alpha) capped at cap_frac * L (deep-stack stress)."""

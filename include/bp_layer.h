@@ -135,6 +135,35 @@ int bp_layer_scan_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emi
 int bp_layer_sort_unique_pairs_device(bp_layer_t *layer, const uint32_t *d_pairs_in, size_t n,
                                       const uint32_t **d_pairs, size_t *n_pairs);
 
+/* Building blocks of the Morton-range sharded pipeline (host side: broadphase_rs_amd/dist.py).
+ * All results are borrowed device pointers, valid until the next mutating call on the handle. */
+enum { BP_FACT_ORDER_OK = 1u, BP_FACT_IDS_DISTINCT = 2u };
+/* append raw entries and assert facts the caller can prove about them (they only select faster
+ * kernels): ORDER_OK = among equal index values the ids are non-decreasing in the resulting
+ * array order; IDS_DISTINCT = no id occurs on two objects.  Facts are AND-ed with the layer's. */
+int bp_layer_append_entries_assume(bp_layer_t *layer, const uint64_t *keys, const uint32_t *ids, size_t m,
+                                   uint32_t facts);
+/* entries per Morton cell at split_depth: hist[n_cells + 1] (host), last slot = coarse entries
+ * (depth < split_depth).  n_cells must be 2^(dim * split_depth) and <= 4096. */
+int bp_layer_cell_histogram(bp_layer_t *layer, uint32_t split_depth, uint64_t *hist, size_t n_cells);
+/* stable bucketing of the layer's entries by owner: lut[n_cells] (host) maps a cell to its owner
+ * 0..n_dest-1, coarse entries form bucket n_dest.  counts[n_dest + 1] (host).  The layer itself
+ * is not modified. */
+int bp_layer_partition_entries_device(bp_layer_t *layer, uint32_t split_depth, const uint8_t *lut, size_t n_cells,
+                                      uint32_t n_dest, uint64_t *counts, const uint64_t **d_keys,
+                                      const uint32_t **d_ids);
+/* raw pair stream of the shard scan as packed u64 (id << 32 | id_), left in HBM */
+int bp_layer_scan_raw_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
+                                   const uint64_t **d_packed, size_t *n_raw);
+/* stable bucketing of n packed pairs by the owner of the first id: bounds[i] = first id owned by
+ * rank i + 1 (n_bounds <= 15); counts[n_bounds + 1] (host) */
+int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed, size_t n, const uint32_t *bounds,
+                                    uint32_t n_bounds, uint64_t *counts, const uint64_t **d_out);
+/* sort + dedup n packed pairs in device memory (d_packed is used as scratch and clobbered);
+ * varying_mask: bits that may differ between the pairs (0 = all 64) */
+int bp_layer_sort_unique_packed_device(bp_layer_t *layer, uint64_t *d_packed, size_t n, uint64_t varying_mask,
+                                       const uint32_t **d_pairs, size_t *n_pairs);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 typedef struct bp_stats {
     uint64_t objects_valid;   /* objects appended by extend since the last clear       */

@@ -86,6 +86,8 @@ def lib():
     L.orc_layer_extend.argtypes = [C.c_void_p, f32p, f32p, f32p, u32p, sz]
     L.orc_layer_merge.restype = C.c_int
     L.orc_layer_merge.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_layer_append_entries.restype = C.c_int
+    L.orc_layer_append_entries.argtypes = [C.c_void_p, u64p, u32p, sz]
     L.orc_layer_sort.restype = None
     L.orc_layer_sort.argtypes = [C.c_void_p]
     L.orc_layer_par_sort.restype = None
@@ -205,6 +207,12 @@ class OracleLayer:
     def merge(self, other):
         if self._L.orc_layer_merge(self._h, other._h):
             raise MemoryError("orc_layer_merge failed")
+
+    def append_entries(self, keys, ids):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        if self._L.orc_layer_append_entries(self._h, _ptr(keys, C.c_uint64), _ptr(ids, C.c_uint32), len(keys)):
+            raise MemoryError("orc_layer_append_entries failed")
 
     def sort(self):
         self._L.orc_layer_sort(self._h)

@@ -471,6 +471,16 @@ int orc_layer_merge(orc_layer_t *l, const orc_layer_t *other) {
     return 0;
 }
 
+int orc_layer_append_entries(orc_layer_t *l, const uint64_t *keys, const uint32_t *ids, size_t m) {
+    if (recvec_reserve(&l->tree, l->tree.n + m)) return -1;
+    for (size_t i = 0; i < m; ++i) {
+        rec_t r = {keys[i], ids[i], 0};
+        l->tree.p[l->tree.n++] = r;
+    }
+    l->sorted = 0;
+    return 0;
+}
+
 /* layer.rs:159-165 */
 void orc_layer_sort(orc_layer_t *l) {
     if (!l->sorted) { sort_rec(l->tree.p, l->tree.n, 1); l->sorted = 1; }

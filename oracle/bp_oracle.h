@@ -74,6 +74,8 @@ void         orc_layer_clear(orc_layer_t *);                          /* layer.r
 int          orc_layer_extend(orc_layer_t *, const float *sys_min, const float *sys_max,
                               const float *bounds, const uint32_t *ids, size_t n);
 int          orc_layer_merge(orc_layer_t *, const orc_layer_t *other); /* layer.rs:127-138 */
+/* merge() with the other layer's tree given as raw arrays (test helper for the sharded pipeline) */
+int          orc_layer_append_entries(orc_layer_t *, const uint64_t *keys, const uint32_t *ids, size_t m);
 void         orc_layer_sort(orc_layer_t *);                           /* layer.rs:159-165 */
 void         orc_layer_par_sort(orc_layer_t *, int threads);          /* layer.rs:146-152 */
 /* scan family: layer.rs:449-573.  Returned pointer is owned by the layer (interleaved id,id_). */

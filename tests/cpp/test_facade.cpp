@@ -1,0 +1,72 @@
+// C++ facade test (GPU): mirrors the reference's usage snippet (src/lib.rs:24-47) and the
+// assertions of tests/test_layer.rs on the SURVEY.md 8(c) worked example.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "broadphase/layer.hpp"
+
+using namespace broadphase;
+
+#define CHECK(cond)                                                         \
+    do {                                                                    \
+        if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #cond, __LINE__); return 1; } \
+    } while (0)
+
+int main() {
+    using B3 = Bounds<3>;
+    const B3 system_bounds{{0, 0, 0}, {16, 16, 16}};
+    std::vector<std::pair<B3, uint32_t>> objects = {
+        {B3{{1, 1, 1}, {2, 2, 2}}, 0},      {B3{{1.5f, 1.5f, 1.5f}, {3, 3, 3}}, 1}, {B3{{0, 0, 0}, {16, 16, 16}}, 2},
+        {B3{{7, 7, 7}, {9, 9, 9}}, 3},      {B3{{20, 0, 0}, {21, 1, 1}}, 4},  // outside: skipped silently
+    };
+    auto layer = LayerBuilder::create().with_min_depth(0).with_index_capacity(64).build<Index64_3D, uint32_t>();
+    layer.clear();
+    layer.extend(system_bounds, objects);
+    CHECK(layer.len() == 25 && !layer.sorted());
+    auto tree = layer.iter();
+    CHECK(tree[0].first == 0x4ull && tree[0].second == 0);          // id 0, depth 4, first cell
+    CHECK(tree[16].first == 0x0ull && tree[16].second == 2);        // whole-system box: Index::default()
+    CHECK(tree[24].first == 0x3800000000000003ull && tree[24].second == 3);
+
+    auto snapshot = layer;  // Clone
+    CHECK(snapshot == layer);
+    layer.par_sort();
+    CHECK(layer.sorted() && snapshot != layer);
+    tree = layer.iter();
+    for (size_t i = 1; i < tree.size(); ++i) CHECK(tree[i - 1] <= tree[i]);  // tests/test_layer.rs:42-54
+
+    const uint32_t expect[4][2] = {{0, 1}, {0, 2}, {1, 2}, {3, 2}};
+    auto pairs = layer.par_scan();
+    CHECK(pairs.size() == 4);
+    for (size_t i = 0; i < 4; ++i) CHECK(pairs[i].first == expect[i][0] && pairs[i].second == expect[i][1]);
+    auto serial = layer.scan();
+    CHECK(serial.size() == 4);
+
+    size_t calls = 0;
+    auto filtered = layer.scan_filtered([&](uint32_t a, uint32_t b) { ++calls; return b == 2 && a != 3; });
+    CHECK(calls == 32);  // the filter sees every raw pair before dedup (layer.rs:455-459)
+    CHECK(filtered.size() == 2 && filtered[0].first == 0 && filtered[1].first == 1);
+
+    // merge: static layer into a dynamic one (layer.rs:123-138)
+    auto dynamic = LayerBuilder::create().with_min_depth(2).build<Index64_3D>();
+    dynamic.extend(system_bounds, {{B3{{2.5f, 2.5f, 2.5f}, {2.75f, 2.75f, 2.75f}}, 9}});
+    dynamic.merge(layer);
+    CHECK(dynamic.min_depth() == 0 && !dynamic.sorted() && dynamic.len() > 25 && dynamic.iter().size() == dynamic.len());
+    auto merged = dynamic.par_scan();
+    bool has_9_1 = false, has_9_2 = false;
+    for (size_t i = 0; i < merged.size(); ++i) {
+        has_9_1 |= merged[i].first == 9 && merged[i].second == 1;
+        has_9_2 |= merged[i].first == 9 && merged[i].second == 2;
+    }
+    CHECK(has_9_1 && has_9_2);
+
+    // 2-D index type through the same facade
+    auto flat = LayerBuilder::create().with_min_depth(4).build<Index32_2D>();
+    flat.extend(Bounds<2>{{-1, -1}, {1280, 1280}}, {{Bounds<2>{{10, 10}, {20, 20}}, 1}, {Bounds<2>{{15, 15}, {30, 30}}, 2}, {Bounds<2>{{600, 600}, {610, 610}}, 3}});
+    auto p2 = flat.par_scan();
+    CHECK(p2.size() == 1 && ((p2[0].first == 2 && p2[0].second == 1) || (p2[0].first == 1 && p2[0].second == 2)));
+
+    std::printf("facade ok: %zu pairs, %zu merged pairs\n", pairs.size(), merged.size());
+    return 0;
+}

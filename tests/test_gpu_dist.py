@@ -1,0 +1,132 @@
+"""GPU tests of the sharded pipeline's HIP building blocks.  The pool gives one GPU per box, so
+(a) a 1-rank NCCL group runs the production path (TorchComm + HipBackend) end to end, and
+(b) N rank-threads in one process run the real kernels of N HipBackends on the same GPU with an
+    in-memory stand-in for the collectives -- the multi-rank data flow on device buffers."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import broadphase_rs_amd as bp
+from broadphase_rs_amd import scenes
+from broadphase_rs_amd.dist import HipBackend, ShardedLayer
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadComm:
+    """collectives among rank-threads of one process (test stand-in for RCCL)"""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, value):
+        self.sh.slots[self.rank] = value
+        self.sh.barrier.wait()
+        vals = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return vals
+
+    def all_reduce_sum(self, arr, backend):
+        return np.sum(self._exchange(np.asarray(arr).astype(np.int64)), axis=0)
+
+    def all_reduce_max(self, value, backend):
+        return max(self._exchange(int(value)))
+
+    def all_to_all_v(self, send, send_counts, dtype, backend):
+        import torch
+        offs = np.concatenate([[0], np.cumsum([int(c) for c in send_counts])])
+        vals = self._exchange([send[int(offs[d]):int(offs[d + 1])].clone() for d in range(self.world)])
+        parts = [vals[src][self.rank] for src in range(self.world)]
+        out = torch.cat(parts) if sum(p.numel() for p in parts) else backend.empty(0, dtype)
+        backend.sync()
+        self.sh.barrier.wait()
+        return out
+
+    def all_gather_v(self, t, dtype, backend):
+        import torch
+        vals = self._exchange(t.clone())
+        out = torch.cat(vals) if sum(v.numel() for v in vals) else backend.empty(0, dtype)
+        backend.sync()
+        self.sh.barrier.wait()
+        return out
+
+
+def _giants(parts, world):
+    for r, (sysb, b, _ids) in enumerate(parts):
+        L = float(sysb[1][0])
+        b[0] = [0, 0, 0, L, L, L]
+        b[1] = [0.1 * L * (r + 1) / world, 0, 0, 0.1 * L * (r + 1) / world + 0.4 * L, 0.5 * L, 0.45 * L]
+        b[2] = [0.3 * L, 0.3 * L, 0.3 * L, 0.62 * L, 0.62 * L, 0.62 * L]
+
+
+@pytest.mark.parametrize("world,n_per_rank,giants", [(2, 40000, True), (4, 25000, True), (3, 30000, False)])
+def test_rank_threads_on_one_gpu_match_the_oracle(world, n_per_rank, giants):
+    import torch
+    torch.cuda.init()
+    parts = [scenes.gen_boxes_shard(world * n_per_rank, r, world, seed=3) for r in range(world)]
+    if giants:
+        _giants(parts, world)
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lay = ShardedLayer(bp.Index64_3D, 0, device=0, backend=HipBackend(bp.Index64_3D, 0, 0), comm=ThreadComm(shared, rank))
+            sysb, bounds, ids = parts[rank]
+            for _frame in range(2):
+                lay.clear()
+                lay.extend(sysb, torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda())
+                out = lay.par_scan()
+            results[rank] = (out, lay.last, lay.shard_layer.stats())
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    ref = oracle.OracleLayer(2, 0)
+    for sysb, b, ids in parts:
+        ref.extend(sysb, b, ids)
+    expect = ref.scan()
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    for r in range(world):
+        assert results[r][2]["flags"] == 3          # shard layers ran the fast (key-only sort, distinct-id) kernels
+        if giants:
+            assert results[r][1]["coarse"] >= 3 * world
+    loads = [results[r][1]["entries_shard"] for r in range(world)]
+    assert max(loads) < 1.5 * (sum(loads) / world) + 1000
+
+
+def test_single_rank_nccl_group_runs_the_production_path():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sysb, bounds, ids = scenes.gen_boxes(120000, seed=9)
+        lay = ShardedLayer(bp.Index64_3D, 0, device=0, n_global=len(ids))
+        lay.clear()
+        lay.extend(sysb, torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda())
+        got = lay.par_scan()
+        ref = oracle.OracleLayer(2, 0)
+        ref.extend(sysb, bounds, ids)
+        expect = ref.scan()
+        assert got.shape == expect.shape and np.array_equal(got, expect)
+    finally:
+        dist.destroy_process_group()

@@ -278,3 +278,14 @@ def test_ten_million_boxes_properties():
     assert len(ref) == len(k)
     exp = ref.par_scan()
     assert_pairs_equal(pairs, exp, "10M scan")
+
+
+def test_cpp_facade_binary():
+    """include/broadphase/layer.hpp (the C++ mirror of Layer/LayerBuilder) over the C ABI"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(bp.library_path()), "test_facade.bin")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "facade ok" in out.stdout
