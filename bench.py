@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-objects", type=int, default=1_000_000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
     return ap.parse_args()
 
 
@@ -108,9 +109,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded_path = world > 1 or args.sharded
+    if sharded_path:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n = args.objects
     n_global = n * world
@@ -122,7 +129,7 @@ def main():
     d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
     torch.cuda.synchronize()
 
-    if world == 1:
+    if not sharded_path:
         layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
 
         def step():
@@ -205,6 +212,8 @@ def main():
                            "frac_of_peak": b_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
+        if sharded_path:
+            line["sharded"] = sharded.last
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_objects, args.seed)
         else:
