@@ -33,6 +33,27 @@ template <> __device__ __forceinline__ uint64_t spread_bits<3>(uint64_t x) {
     return x;
 }
 
+// inverse of spread_bits: bit DIM*k -> bit k
+template <int DIM> __device__ __forceinline__ uint32_t compact_bits(uint64_t x);
+template <> __device__ __forceinline__ uint32_t compact_bits<2>(uint64_t x) {
+    x &= 0x5555555555555555ull;
+    x = (x ^ (x >> 1)) & 0x3333333333333333ull;
+    x = (x ^ (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x ^ (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x ^ (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x ^ (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+template <> __device__ __forceinline__ uint32_t compact_bits<3>(uint64_t x) {
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10C30C30C30C30C3ull;
+    x = (x ^ (x >> 4)) & 0x100F00F00F00F00Full;
+    x = (x ^ (x >> 8)) & 0x001F0000FF0000FFull;
+    x = (x ^ (x >> 16)) & 0x001F00000000FFFFull;
+    x = (x ^ (x >> 32)) & 0x00000000001FFFFFull;
+    return (uint32_t)x;
+}
+
 // level_mask (src/index.rs:82-86)
 template <int KIND> __device__ __forceinline__ uint64_t level_mask(uint32_t depth) {
     constexpr uint32_t DIM = KT<KIND>::DIM, TOP = KT<KIND>::DIM * KT<KIND>::AB + KT<KIND>::DB;

