@@ -1162,7 +1162,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
 // inside the workspace) holds the bucket sizes afterwards
 template <typename V, typename DigitFn>
 static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, size_t n, DigitFn fn, void* workspace,
-                                 size_t workspace_bytes, DevScalars* sc, const u64** d_hist, hipStream_t stream) {
+                                 size_t workspace_bytes, DevScalars* sc, const u64** d_hist, hipStream_t stream,
+                                 const uint8_t* box_in = nullptr) {
     if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (radix_workspace_bytes(n, 1) > workspace_bytes) return hipErrorInvalidValue;
     unsigned char* ws = (unsigned char*)workspace;
@@ -1178,16 +1179,29 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<1, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream);
+    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr);
 }
 
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
                              const unsigned char* d_lut, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                              uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
-                             const unsigned long long** d_hist, hipStream_t stream) {
+                             const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in) {
     EntryDestDigit fn{d_lut, cell_shift, depth_mask, split_depth, coarse_bucket};
     return partition_pass<u32, EntryDestDigit>((const u64*)keys_in, (u64*)keys_out, ids_in, ids_out, m, fn, workspace,
-                                               workspace_bytes, sc, (const u64**)d_hist, stream);
+                                               workspace_bytes, sc, (const u64**)d_hist, stream, box_in);
+}
+
+__global__ __launch_bounds__(256) void split_box_kernel(u32* __restrict__ ids, uint8_t* __restrict__ box, size_t m) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
+        const u32 v = ids[i];
+        box[i] = (uint8_t)(v >> BOX_ID_BITS);
+        ids[i] = v & BOX_ID_MASK;
+    }
+}
+hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    split_box_kernel<<<grid_for(m, 256, 4096), 256, 0, stream>>>(ids, box, m);
+    return hipGetLastError();
 }
 
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,

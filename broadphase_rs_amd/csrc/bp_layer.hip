@@ -851,12 +851,29 @@ int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in,
 int bp_layer_append_entries_assume(bp_layer_t* L, const uint64_t* keys, const uint32_t* ids, size_t m, uint32_t facts) {
     if (!L) return BP_ERR_INVALID_ARG;
     const bool was_empty = L->m == 0;
-    const bool order_before = L->order_ok, distinct_before = L->ids_distinct;
+    const bool order_before = L->order_ok, distinct_before = L->ids_distinct, known_before = L->box_all_known;
+    const size_t at = L->m;
     BP_TRY(bp_layer_append_entries(L, keys, ids, m));
-    if (m) {  // append_entries dropped both facts; restore what the caller vouches for
+    if (m) {  // append_entries dropped the facts; restore what the caller vouches for
         L->order_ok = (was_empty || order_before) && (facts & BP_FACT_ORDER_OK);
         L->ids_distinct = (was_empty || distinct_before) && (facts & BP_FACT_IDS_DISTINCT);
+        if (facts & BP_FACT_IDS_CARRY_BOX) {
+            DeviceGuard g(L->device);
+            HIP_TRY(L, launch_split_box(cur_ids(L) + at, (uint8_t*)L->box[L->cur].p + at, m, L->stream));
+            BP_TRY(sync_stream(L));
+            // the id OR/AND were reduced over the packed values: the code bits are not id bits
+            L->id_or &= BOX_ID_MASK;
+            L->id_and &= BOX_ID_MASK;
+            L->box_all_known = known_before;  // codes may still be BOX_UNKNOWN: the sender says so via facts
+            if (!(facts & BP_FACT_BOX_ALL_KNOWN)) L->box_all_known = false;
+        }
     }
+    return BP_OK;
+}
+
+int bp_layer_can_pack_box(const bp_layer_t* L, int* can) {
+    if (!L || !can) return BP_ERR_INVALID_ARG;
+    *can = (box_can_ride(L) ? 1 : 0) | (L->box_all_known ? 2 : 0);
     return BP_OK;
 }
 
@@ -884,11 +901,17 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
 
 int bp_layer_partition_entries_device(bp_layer_t* L, uint32_t split_depth, const uint8_t* lut, size_t n_cells, uint32_t n_dest,
                                       uint64_t* counts, const uint64_t** d_keys, const uint32_t** d_ids) {
+    return bp_layer_partition_entries_packed_device(L, split_depth, lut, n_cells, n_dest, 0, counts, d_keys, d_ids);
+}
+
+int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth, const uint8_t* lut, size_t n_cells, uint32_t n_dest,
+                                             int pack_box, uint64_t* counts, const uint64_t** d_keys, const uint32_t** d_ids) {
     if (!L || !lut || !counts || !d_keys || !d_ids) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: null argument");
     const KindInfo ki = kind_info(L->kind);
     if (split_depth == 0 || split_depth > ki.axis_bits || n_cells != ((size_t)1 << (ki.dim * split_depth)) || n_cells > 4096 ||
         n_dest == 0 || n_dest > 255)
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: bad split_depth / n_cells / n_dest");
+    if (pack_box && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
     DeviceGuard g(L->device);
     const int other = L->cur ^ 1;
     for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = 0;
@@ -908,7 +931,8 @@ int bp_layer_partition_entries_device(bp_layer_t* L, uint32_t split_depth, const
         ProfScope ps(L, BP_K_MISC);
         HIP_TRY(L, partition_entries(cur_keys(L), (uint64_t*)L->keys[other].p, cur_ids(L), (uint32_t*)L->ids[other].p, L->m,
                                      (const unsigned char*)L->skip.p, cell_shift, (1u << ki.depth_bits) - 1u, split_depth, n_dest,
-                                     L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream));
+                                     L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream,
+                                     pack_box ? (const uint8_t*)L->box[L->cur].p : nullptr));
     }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
@@ -924,6 +948,35 @@ int bp_layer_scan_raw_shard_device(bp_layer_t* L, uint32_t coarse_depth, int emi
     BP_TRY(sync_stream(L));
     *d_packed = (const uint64_t*)L->pairs[0].p;
     *n_raw = L->n_raw;
+    return BP_OK;
+}
+
+int bp_layer_scan_shard_pairs_device(bp_layer_t* L, uint32_t coarse_depth, int emit_coarse, const uint64_t** d_packed, size_t* n_raw,
+                                     int* unique) {
+    if (!L || !d_packed || !n_raw || !unique) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_shard_pairs: null argument");
+    DeviceGuard g(L->device);
+    if (L->ids_distinct) {
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, true));
+    } else {
+        BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
+        BP_TRY(sync_stream(L));
+        L->raw_is_unique = false;
+    }
+    *d_packed = (const uint64_t*)L->pairs[0].p;
+    *n_raw = L->n_raw;
+    *unique = L->raw_is_unique ? 1 : 0;
+    return BP_OK;
+}
+
+int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask, const uint32_t** d_pairs,
+                                size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs || (n && !d_packed)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_packed: null argument");
+    DeviceGuard g(L->device);
+    L->n_raw = n;
+    BP_TRY(sort_unique_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull, true));
+    if (n == 0) BP_TRY(sync_stream(L));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
     return BP_OK;
 }
 

@@ -79,27 +79,35 @@ class HipBackend:
     def local_cell_histogram(self, split_depth):
         return self.local.cell_histogram(split_depth)
 
-    def local_partition_entries(self, split_depth, lut, n_ranks):
-        counts, keys, ids = self.local.partition_entries_device(split_depth, lut, n_ranks)
+    def local_can_pack_box(self):
+        return self.local.can_pack_box()
+
+    def local_partition_entries(self, split_depth, lut, n_ranks, pack_box=False):
+        counts, keys, ids = self.local.partition_entries_device(split_depth, lut, n_ranks, pack_box)
         return counts, keys.as_torch(), ids.as_torch()
 
     # -- shard ----------------------------------------------------------------------------------------
-    def shard_set_entries(self, chunks):
+    def shard_set_entries(self, chunks, ids_carry_box=False, box_all_known=False):
         """chunks: [(keys int64 tensor, ids int32 tensor)] in an order for which equal index values
         carry non-decreasing ids; ids are distinct across objects."""
         self.shard.clear()
         for keys, ids in chunks:
             if keys.numel():
-                self.shard.append_entries_assume(keys.data_ptr(), ids.data_ptr(), int(keys.numel()), True, True)
+                self.shard.append_entries_assume(keys.data_ptr(), ids.data_ptr(), int(keys.numel()), True, True,
+                                                 ids_carry_box, box_all_known)
 
-    def shard_scan_raw(self, coarse_depth, emit_coarse):
-        return self.shard.scan_raw_shard_device(coarse_depth, emit_coarse).as_torch()
+    def shard_scan_pairs(self, coarse_depth, emit_coarse):
+        """(packed raw pairs, arbitrary order; True if this rank suppressed every duplicate at the source)"""
+        raw, unique = self.shard.scan_shard_pairs_device(coarse_depth, emit_coarse)
+        return raw.as_torch(), unique
 
     def partition_pairs(self, packed, bounds):
         counts, out = self.shard.partition_pairs_device(packed.data_ptr(), int(packed.numel()), bounds)
         return counts, out.as_torch()
 
-    def sort_unique_packed(self, packed, varying_mask):
+    def sort_unique_packed(self, packed, varying_mask, already_unique=False):
+        if already_unique:
+            return self.shard.sort_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
         return self.shard.sort_unique_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
 
     def empty(self, n, dtype):
@@ -119,6 +127,9 @@ class TorchComm:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        import os
+        if os.environ.get("BP_DIST_CHUNK_BYTES"):
+            self.CHUNK_BYTES = max(8, int(os.environ["BP_DIST_CHUNK_BYTES"]))
 
     def all_reduce_sum(self, arr, backend):
         t = self.torch.from_numpy(np.asarray(arr).astype(np.int64)).to(backend.device)
@@ -130,16 +141,40 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
+    # The RCCL build bundled with PyTorch-ROCm 2.10 silently moves only HALF of any single
+    # send/recv larger than 1 GiB (measured on MI355X: tools/dbg_a2a.py), so every exchange is cut
+    # into per-peer pieces of at most CHUNK_BYTES.
+    CHUNK_BYTES = 256 << 20
+
     def all_to_all_v(self, send, send_counts, dtype, backend):
         """variable-size all-to-all of a tensor that is already grouped by destination"""
         torch, dist = self.torch, self.dist
-        sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=send.device)
+        send_counts = [int(c) for c in send_counts]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
         recv_counts = [int(c) for c in rc.cpu().tolist()]
         recv = backend.empty(sum(recv_counts), dtype)
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
-                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        ch = max(1, self.CHUNK_BYTES // send.element_size())
+        rounds = self.all_reduce_max((max(send_counts + recv_counts) + ch - 1) // ch, backend)
+        soff = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        roff = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        if rounds <= 1:
+            dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                   group=self.group)
+        else:
+            for r in range(rounds):  # all_to_all_single works on every backend (gloo has no list all_to_all)
+                isz = [min(c, (r + 1) * ch) - min(c, r * ch) for c in send_counts]
+                osz = [min(c, (r + 1) * ch) - min(c, r * ch) for c in recv_counts]
+                stage_in = torch.cat([send[int(soff[d]) + min(send_counts[d], r * ch):int(soff[d]) + min(send_counts[d], (r + 1) * ch)]
+                                      for d in range(self.world)])
+                stage_out = backend.empty(sum(osz), dtype)
+                dist.all_to_all_single(stage_out, stage_in, output_split_sizes=osz, input_split_sizes=isz, group=self.group)
+                o = 0
+                for d in range(self.world):
+                    a = int(roff[d]) + min(recv_counts[d], r * ch)
+                    recv[a:a + osz[d]] = stage_out[o:o + osz[d]]
+                    o += osz[d]
         backend.sync()
         return recv
 
@@ -203,11 +238,17 @@ class ShardedLayer:
     def par_scan_device(self):
         torch, G, be, comm = self.torch, self.world, self.backend, self.comm
         d_s = self.split_depth
-        # 2. balanced contiguous Morton ranges from the all-reduced cell histogram
-        hist_all = comm.all_reduce_sum(be.local_cell_histogram(d_s), be)
+        # 2. balanced contiguous Morton ranges from the all-reduced cell histogram; the same reduction
+        #    tells whether EVERY rank's ids can carry their box codes and knows all of them
+        can_pack, all_known = be.local_can_pack_box()
+        hist = np.concatenate([be.local_cell_histogram(d_s).astype(np.int64), [1 if can_pack else 0, 1 if all_known else 0]])
+        hist_all = comm.all_reduce_sum(hist, be)
+        pack = int(hist_all[-2]) == G
+        all_known = pack and int(hist_all[-1]) == G
+        hist_all = hist_all[:-2]
         lut = choose_owner_lut(hist_all[:-1], G)
         # 3. entries -> owners (fine), boundary keys -> everyone (coarse)
-        counts, keys, ids = be.local_partition_entries(d_s, lut, G)
+        counts, keys, ids = be.local_partition_entries(d_s, lut, G, pack)
         n_fine = int(counts[:G].sum())
         rk = comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be)
         ri = comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be)
@@ -215,9 +256,11 @@ class ShardedLayer:
         ci = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be)
         # received chunks arrive in rank order and every rank's entries are in id order, so equal index
         # values carry non-decreasing ids (fine and coarse entries never share an index value)
-        be.shard_set_entries([(rk, ri), (ck, ci)])
-        # 4. local sort + scan; coarse-coarse pairs only once
-        raw = be.shard_scan_raw(d_s, self.rank == 0)
+        be.shard_set_entries([(rk, ri), (ck, ci)], pack, all_known)
+        # 4. local sort + scan (single pass); coarse-coarse pairs only once.  With box codes every pair
+        #    is emitted by exactly one entry on exactly one rank, so no duplicate ever crosses the wire.
+        raw, unique = be.shard_scan_pairs(d_s, self.rank == 0)
+        unique = comm.all_reduce_max(0 if unique else 1, be) == 0
         # 5. raw pairs -> owner of the first id, then sort + dedup per id range
         if self.n_global is not None:
             max_id = int(self.n_global) - 1
@@ -229,10 +272,10 @@ class ShardedLayer:
         lo = 0 if self.rank == 0 else int(bounds[self.rank - 1])
         hi = max_id if self.rank == G - 1 else int(bounds[self.rank]) - 1
         varying = (_varying_bits(lo, max(hi, lo)) << 32) | _varying_bits(0, max_id)
-        out = be.sort_unique_packed(rp, varying)
+        out = be.sort_unique_packed(rp, varying, unique)
         self.last = {"entries_local": int(counts.sum()), "entries_shard": int(rk.numel() + ck.numel()),
                      "coarse": int(ck.numel()), "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
-                     "pairs": len(out), "id_range": (lo, hi)}
+                     "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique)}
         return out
 
     # reference names

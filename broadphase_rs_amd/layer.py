@@ -66,6 +66,8 @@ EXPORTS = [
     "bp_layer_profile_enable", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_sort_unique_packed_device",
+    "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
+    "bp_layer_sort_packed_device",
 ]
 
 
@@ -157,6 +159,11 @@ def load_library():
     L.bp_layer_partition_entries_device.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, u64p,
                                                     C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_scan_raw_shard_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp]
+    L.bp_layer_can_pack_box.argtypes = [vp, ip]
+    L.bp_layer_partition_entries_packed_device.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32,
+                                                           C.c_int, u64p, C.POINTER(vp), C.POINTER(vp)]
+    L.bp_layer_scan_shard_pairs_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
+    L.bp_layer_sort_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
     L.bp_layer_partition_pairs_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_uint32, u64p, C.POINTER(vp)]
     L.bp_layer_sort_unique_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
@@ -406,8 +413,8 @@ class Layer:
         self._check(self._L.bp_layer_append_entries(self._h, C.c_void_p(kp), C.c_void_p(ip), m))
 
     # ---- building blocks of the Morton-range sharded pipeline (dist.py) -------------------------------
-    def append_entries_assume(self, keys_ptr, ids_ptr, m, order_ok, ids_distinct):
-        facts = (1 if order_ok else 0) | (2 if ids_distinct else 0)
+    def append_entries_assume(self, keys_ptr, ids_ptr, m, order_ok, ids_distinct, ids_carry_box=False, box_all_known=False):
+        facts = (1 if order_ok else 0) | (2 if ids_distinct else 0) | (4 if ids_carry_box else 0) | (8 if box_all_known else 0)
         self._check(self._L.bp_layer_append_entries_assume(self._h, C.c_void_p(keys_ptr), C.c_void_p(ids_ptr), m, facts))
 
     def cell_histogram(self, split_depth):
@@ -416,12 +423,18 @@ class Layer:
         self._check(self._L.bp_layer_cell_histogram(self._h, split_depth, hist.ctypes.data_as(C.POINTER(C.c_uint64)), n_cells))
         return hist
 
-    def partition_entries_device(self, split_depth, lut, n_dest):
+    def can_pack_box(self):
+        """(ids can carry box codes, all box codes known)"""
+        c = C.c_int()
+        self._check(self._L.bp_layer_can_pack_box(self._h, C.byref(c)))
+        return bool(c.value & 1), bool(c.value & 2)
+
+    def partition_entries_device(self, split_depth, lut, n_dest, pack_box=False):
         lut = np.ascontiguousarray(lut, dtype=np.uint8)
         counts = np.zeros(n_dest + 1, dtype=np.uint64)
         k, i = C.c_void_p(), C.c_void_p()
-        self._check(self._L.bp_layer_partition_entries_device(
-            self._h, split_depth, lut.ctypes.data_as(C.POINTER(C.c_uint8)), len(lut), n_dest,
+        self._check(self._L.bp_layer_partition_entries_packed_device(
+            self._h, split_depth, lut.ctypes.data_as(C.POINTER(C.c_uint8)), len(lut), n_dest, 1 if pack_box else 0,
             counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(k), C.byref(i)))
         m = len(self)
         return counts, DeviceArray(k.value, (m,), np.uint64, self), DeviceArray(i.value, (m,), np.uint32, self)
@@ -430,6 +443,18 @@ class Layer:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._L.bp_layer_scan_raw_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value,), np.uint64, self)
+
+    def scan_shard_pairs_device(self, coarse_depth, emit_coarse):
+        """(packed raw pairs in arbitrary order, duplicates-already-suppressed flag)"""
+        p, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._check(self._L.bp_layer_scan_shard_pairs_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+                                                             C.byref(n), C.byref(u)))
+        return DeviceArray(p.value, (n.value,), np.uint64, self), bool(u.value)
+
+    def sort_packed_device(self, packed_ptr, n, varying_mask=0):
+        p, m = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_sort_packed_device(self._h, C.c_void_p(packed_ptr), n, varying_mask, C.byref(p), C.byref(m)))
+        return DeviceArray(p.value, (m.value, 2), np.uint32, self)
 
     def partition_pairs_device(self, packed_ptr, n, bounds):
         bounds = np.ascontiguousarray(bounds, dtype=np.uint32)

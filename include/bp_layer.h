@@ -137,10 +137,13 @@ int bp_layer_sort_unique_pairs_device(bp_layer_t *layer, const uint32_t *d_pairs
 
 /* Building blocks of the Morton-range sharded pipeline (host side: broadphase_rs_amd/dist.py).
  * All results are borrowed device pointers, valid until the next mutating call on the handle. */
-enum { BP_FACT_ORDER_OK = 1u, BP_FACT_IDS_DISTINCT = 2u };
+enum { BP_FACT_ORDER_OK = 1u, BP_FACT_IDS_DISTINCT = 2u, BP_FACT_IDS_CARRY_BOX = 4u, BP_FACT_BOX_ALL_KNOWN = 8u };
 /* append raw entries and assert facts the caller can prove about them (they only select faster
  * kernels): ORDER_OK = among equal index values the ids are non-decreasing in the resulting
- * array order; IDS_DISTINCT = no id occurs on two objects.  Facts are AND-ed with the layer's. */
+ * array order; IDS_DISTINCT = no id occurs on two objects; IDS_CARRY_BOX = bits 27..31 of every id
+ * hold the entry's cell-box code as packed by bp_layer_partition_entries_device (they are split
+ * off again here); BOX_ALL_KNOWN = none of those codes is "unknown".  Facts are AND-ed with the
+ * layer's. */
 int bp_layer_append_entries_assume(bp_layer_t *layer, const uint64_t *keys, const uint32_t *ids, size_t m,
                                    uint32_t facts);
 /* entries per Morton cell at split_depth: hist[n_cells + 1] (host), last slot = coarse entries
@@ -152,9 +155,20 @@ int bp_layer_cell_histogram(bp_layer_t *layer, uint32_t split_depth, uint64_t *h
 int bp_layer_partition_entries_device(bp_layer_t *layer, uint32_t split_depth, const uint8_t *lut, size_t n_cells,
                                       uint32_t n_dest, uint64_t *counts, const uint64_t **d_keys,
                                       const uint32_t **d_ids);
+/* *can: bit 0 = this layer's ids can carry their box codes (ids < 2^27, distinct, id-ordered),
+ * bit 1 = every box code of the layer is known */
+int bp_layer_can_pack_box(const bp_layer_t *layer, int *can);
+/* as above, with the box code of every entry packed into bits 27..31 of its id (pack_box != 0) */
+int bp_layer_partition_entries_packed_device(bp_layer_t *layer, uint32_t split_depth, const uint8_t *lut,
+                                             size_t n_cells, uint32_t n_dest, int pack_box, uint64_t *counts,
+                                             const uint64_t **d_keys, const uint32_t **d_ids);
 /* raw pair stream of the shard scan as packed u64 (id << 32 | id_), left in HBM */
 int bp_layer_scan_raw_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
                                    const uint64_t **d_packed, size_t *n_raw);
+/* same stream in arbitrary order (single-pass scan); *unique = 1 if duplicates were suppressed at
+ * the source for every entry of this layer (all box codes known) */
+int bp_layer_scan_shard_pairs_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
+                                     const uint64_t **d_packed, size_t *n_raw, int *unique);
 /* stable bucketing of n packed pairs by the owner of the first id: bounds[i] = first id owned by
  * rank i + 1 (n_bounds <= 15); counts[n_bounds + 1] (host) */
 int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed, size_t n, const uint32_t *bounds,
@@ -163,6 +177,9 @@ int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed,
  * varying_mask: bits that may differ between the pairs (0 = all 64) */
 int bp_layer_sort_unique_packed_device(bp_layer_t *layer, uint64_t *d_packed, size_t n, uint64_t varying_mask,
                                        const uint32_t **d_pairs, size_t *n_pairs);
+/* sort only (the caller knows the n pairs are already distinct) */
+int bp_layer_sort_packed_device(bp_layer_t *layer, uint64_t *d_packed, size_t n, uint64_t varying_mask,
+                                const uint32_t **d_pairs, size_t *n_pairs);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 typedef struct bp_stats {

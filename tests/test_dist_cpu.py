@@ -58,7 +58,11 @@ class OracleBackend:
         hist[n_cells] = coarse.sum()
         return hist
 
-    def local_partition_entries(self, split_depth, lut, n_ranks):
+    def local_can_pack_box(self):
+        return False, False
+
+    def local_partition_entries(self, split_depth, lut, n_ranks, pack_box=False):
+        assert not pack_box
         keys, ids = self.local.keys, self.local.ids
         coarse, cell = self._cells(keys, split_depth)
         dest = np.where(coarse, n_ranks, np.asarray(lut)[np.minimum(cell, len(lut) - 1)]).astype(np.int64)
@@ -66,11 +70,15 @@ class OracleBackend:
         counts = np.bincount(dest, minlength=n_ranks + 1).astype(np.uint64)
         return (counts, torch.from_numpy(keys[order].view(np.int64).copy()), torch.from_numpy(ids[order].view(np.int32).copy()))
 
-    def shard_set_entries(self, chunks):
+    def shard_set_entries(self, chunks, ids_carry_box=False, box_all_known=False):
+        assert not ids_carry_box
         self.shard.clear()
         for k, i in chunks:
             if k.numel():
                 self.shard.append_entries(k.numpy().view(np.uint64), i.numpy().view(np.uint32))
+
+    def shard_scan_pairs(self, coarse_depth, emit_coarse):
+        return self.shard_scan_raw(coarse_depth, emit_coarse), False
 
     def shard_scan_raw(self, coarse_depth, emit_coarse):
         raw, _ = self.shard.scan_raw()
@@ -89,7 +97,8 @@ class OracleBackend:
         counts = np.bincount(owner, minlength=len(bounds) + 1).astype(np.uint64)
         return counts, torch.from_numpy(p[order].view(np.int64).copy())
 
-    def sort_unique_packed(self, packed, varying_mask):
+    def sort_unique_packed(self, packed, varying_mask, already_unique=False):
+        assert not already_unique
         p = np.unique(packed.numpy().view(np.uint64))
         if varying_mask:  # the mask must cover every bit that differs between the pairs
             assert len(p) == 0 or int(np.bitwise_or.reduce(p ^ p[0])) & ~int(varying_mask) == 0
@@ -114,6 +123,8 @@ def _scene(world, n_per_rank, seed, with_giants):
 
 
 def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q):
+    if split_depth == 2:
+        os.environ["BP_DIST_CHUNK_BYTES"] = "4096"   # force the multi-round (chunked) exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -114,11 +114,25 @@ def test_rank_threads_on_one_gpu_match_the_oracle(world, n_per_rank, giants):
 def test_single_rank_nccl_group_runs_the_production_path():
     import torch
     import torch.distributed as dist
+    from broadphase_rs_amd.dist import TorchComm
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        # regression: exchanges above 1 GiB must arrive complete (this RCCL halves single messages > 1 GiB)
+        class _Be:
+            device = torch.device("cuda", 0)
+
+            def empty(self, n, dtype):
+                return torch.empty(n, dtype=dtype, device=self.device)
+
+            def sync(self):
+                torch.cuda.synchronize()
+        big = torch.arange(150_000_000, dtype=torch.int64, device="cuda") * 7 + 3       # 1.2 GB
+        got_big = TorchComm().all_to_all_v(big, [big.numel()], torch.int64, _Be())
+        assert torch.equal(got_big, big)
+        del big, got_big
         sysb, bounds, ids = scenes.gen_boxes(120000, seed=9)
         lay = ShardedLayer(bp.Index64_3D, 0, device=0, n_global=len(ids))
         lay.clear()
