@@ -42,6 +42,7 @@ enum : unsigned {
 enum : unsigned {
     KERR_LOOKBACK_TIMEOUT = 1u,  // a decoupled look-back spin hit its bound
     KERR_COUNT_OVERFLOW = 2u,    // an object expands to more cells than a launch can index
+    KERR_SEGMENT_TOO_LONG = 4u,  // segment_finish: one first id owns more pairs than its window holds
 };
 
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
@@ -159,6 +160,15 @@ hipError_t launch_unique_count(const uint64_t* sorted, size_t n, unsigned long l
 // writes each surviving packed pair (id << 32 | id_) as interleaved u32 (id, id_)
 hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned long long* block_offs,
                               uint32_t* pairs_out, hipStream_t stream);
+
+// Finishing step after a radix sort on the FIRST id only: `in` holds n DISTINCT packed pairs grouped
+// by first id (segments in arbitrary internal order); every segment is rank-sorted by second id
+// inside an LDS window and written in the ABI layout.  Sets KERR_SEGMENT_TOO_LONG in sc->err when a
+// segment does not fit the window (the caller then falls back to the full-width sort).
+constexpr int SEG_THREADS = 256;
+constexpr int SEG_CHUNK = 2048;
+constexpr int SEG_HALO = 512;
+hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
 
 // interleaved (id, id_) u32 pairs <-> packed u64 (id << 32 | id_)
 hipError_t launch_pack_pairs(const uint32_t* pairs, size_t n, uint64_t* packed, hipStream_t stream);

@@ -453,7 +453,7 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 //   5 tile-local scatter of the keys into LDS (needs no global information)
 //   6 look-back for the global digit bases (predecessors have had phase 5 to publish), PREFIX publish
 //   7 coalesced global stores (+ payload round trip through LDS)
-template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
+template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool BALLOT_MATCH = false>
 __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
@@ -503,19 +503,33 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
         const u32 li = wbase + (u32)r * 64u;
         const bool valid = li < tile_n;
         const u32 dg = digit(key[r]);
-        if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_wave_barrier();
         u64 peers = 0;
         u32 old = 0;
-        if (valid) {
-            peers = s_mask[dg];
-            old = s_cnt[w][dg];
+        if constexpr (BALLOT_MATCH) {
+            // match on the 8 digit bits with wave64 ballots: no LDS traffic, ~50 VALU per round
+            peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (dg >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            if (valid) old = s_cnt[w][dg];
+            else peers = 0;
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                peers = s_mask[dg];
+                old = s_cnt[w][dg];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(peers >> 32), __builtin_amdgcn_mbcnt_lo((u32)peers, 0u));
         if (valid && below == 0) {  // lowest peer lane: bump the (wave, digit) counter, clear the mask
             s_cnt[w][dg] = old + (u32)__popcll(peers);
-            s_mask[dg] = 0ull;
+            if constexpr (!BALLOT_MATCH) s_mask[dg] = 0ull;
         }
         __builtin_amdgcn_wave_barrier();
         packed[r] = dg | ((old + below) << 8);
@@ -974,6 +988,65 @@ __global__ __launch_bounds__(UQ_THREADS) void unique_emit_kernel(const u64* __re
     }
 }
 
+__global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* __restrict__ in, size_t n,
+                                                                      uint2* __restrict__ out, DevScalars* sc) {
+    constexpr int WIN = SEG_HALO + SEG_CHUNK + SEG_HALO;
+    constexpr int GROUPS = WIN / 64;
+    __shared__ u64 s_win[WIN];
+    __shared__ u64 s_heads[GROUPS];  // per 64 window elements: bit l set <=> element starts a segment
+    const size_t base = (size_t)blockIdx.x * SEG_CHUNK;
+    const size_t win_lo = base > (size_t)SEG_HALO ? base - SEG_HALO : 0;
+    const size_t hi_want = base + SEG_CHUNK + SEG_HALO;
+    const size_t win_hi = hi_want < n ? hi_want : n;
+    const u32 wlen = (u32)(win_hi - win_lo);
+    for (u32 k = threadIdx.x; k < (u32)WIN; k += SEG_THREADS) s_win[k] = k < wlen ? in[win_lo + k] : ~0ull;
+    __syncthreads();
+    // head flags by ballot: wave w covers groups w, w + 4, ...
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    for (int g = w; g < GROUPS; g += SEG_THREADS / 64) {
+        const u32 x = (u32)g * 64u + (u32)lane;
+        const bool head = x < wlen && (x == 0 || (u32)(s_win[x] >> 32) != (u32)(s_win[x - 1] >> 32));
+        const u64 m = __ballot(head);
+        if (lane == 0) s_heads[g] = m;
+    }
+    __syncthreads();
+    const u32 off = (u32)(base - win_lo);
+    const u32 cend = (u32)(((base + SEG_CHUNK) < n ? (base + SEG_CHUNK) : n) - win_lo);
+    const u32 ngroups = (wlen + 63u) / 64u;
+    bool too_long = false;
+    for (u32 x = off + threadIdx.x; x < cend; x += SEG_THREADS) {
+        const u64 v = s_win[x];
+        const u32 g = x >> 6, l = x & 63u;
+        const u64 m = s_heads[g];
+        const u64 le = l == 63u ? ~0ull : ((2ull << l) - 1ull);
+        // segment start: nearest head at or before x
+        u32 start;
+        const u64 below = m & le;
+        if (below) {
+            start = g * 64u + 63u - (u32)__clzll((long long)below);
+        } else {
+            int gg = (int)g - 1;
+            while (gg >= 0 && s_heads[gg] == 0) --gg;
+            start = gg < 0 ? 0u : (u32)gg * 64u + 63u - (u32)__clzll((long long)s_heads[gg]);
+        }
+        // segment end: nearest head after x
+        u32 end;
+        const u64 above = m & ~le;
+        if (above) {
+            end = g * 64u + (u32)__builtin_ctzll(above);
+        } else {
+            u32 gg = g + 1;
+            while (gg < ngroups && s_heads[gg] == 0) ++gg;
+            end = gg < ngroups ? gg * 64u + (u32)__builtin_ctzll(s_heads[gg]) : wlen;
+        }
+        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) too_long = true;  // may leave the window
+        u32 rank = 0;
+        for (u32 y = start; y < end; ++y) rank += s_win[y] < v ? 1u : 0u;  // independent LDS reads
+        out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
+    }
+    if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
+}
+
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2* __restrict__ in, size_t n, u64* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint2 v = in[i];
@@ -1068,7 +1141,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // tile geometry, selectable at run time for A/B measurements (BP_RS_CONFIG=0..3)
 struct RsConfig { int threads, items; };
-static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {512, 16}, {1024, 16}};
+static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {1024, 16}, {1024, 16}};
 static int rs_config_id() {
     static int id = -1;
     if (id < 0) {
@@ -1100,6 +1173,8 @@ static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t
     const int dbg = StageBytes<V>::value == 0 ? dbg_env : 0;  // timing experiments: keys-only passes only
     switch (rs_config_id()) {
         case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 3: radix_onesweep_kernel<K, V, 512, 16, DigitFn, true><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 4: radix_onesweep_kernel<K, V, 1024, 16, DigitFn, true><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
@@ -1269,6 +1344,13 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
                               uint32_t* pairs_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     unique_emit_kernel<<<(unsigned)uq_blocks(n), UQ_THREADS, 0, stream>>>((const u64*)sorted, n, block_offs, (uint2*)pairs_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)((n + SEG_CHUNK - 1) / SEG_CHUNK);
+    segment_finish_kernel<<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
     return hipGetLastError();
 }
 

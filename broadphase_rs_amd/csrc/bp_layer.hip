@@ -434,7 +434,44 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
 
 // sort + dedup of n packed pairs sitting in buf0 (scratch partner: L->pairs[1]) -> L->out_pairs
 // (interleaved), L->n_pairs
-int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false) {
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false);
+
+// n DISTINCT packed pairs in buf0: radix sort on the first id only, then rank-sort the small
+// equal-first-id segments in LDS while writing the ABI layout (3 passes + 1 kernel instead of
+// 6 passes + 1 kernel).  Falls back to the full-width sort when a segment is too long.
+int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying) {
+    static const bool disabled = getenv("BP_NO_SEGMENT_FINISH") != nullptr;  // A/B switch
+    const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
+    if (disabled || n < 2) return sort_unique_pairs_in(L, buf0, n, varying, true);
+    const RadixPlan plan = make_radix_plan(hi_var, 0, 0);
+    L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
+    int res = 0;
+    uint64_t* bufs[2] = {buf0, nullptr};
+    BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+    bufs[1] = (uint64_t*)L->pairs[1].p;
+    BP_TRY(sc_reset(L));
+    if (plan.n_passes > 0) {
+        BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(n, plan.n_passes)));
+        HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
+                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT));
+    }
+    BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_segment_finish(bufs[res], n, (uint32_t*)L->out_pairs.p, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+    BP_TRY(sync_stream(L));
+    const DevScalars sc = *(DevScalars*)L->h_sc.p;
+    if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+    if (sc.err & KERR_SEGMENT_TOO_LONG)  // some id owns > SEG_HALO pairs: sort all 64 bits instead
+        return sort_unique_pairs_in(L, bufs[res], n, varying, true);
+    L->n_pairs = n;
+    L->stats.pairs = n;
+    return BP_OK;
+}
+
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique) {
     L->n_pairs = 0;
     L->stats.pairs = 0;
     if (n == 0) return BP_OK;
@@ -443,8 +480,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
     int res = 0;
     uint64_t* bufs[2] = {buf0, nullptr};
     if (plan.n_passes > 0 && n > 1) {
-        BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
-        bufs[1] = (uint64_t*)L->pairs[1].p;
+        DevBuf& partner = (buf0 == (uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];  // never buf0 itself
+        BP_TRY(ensure_dev(L, partner, n * sizeof(uint64_t)));
+        bufs[1] = (uint64_t*)partner.p;
         const size_t wsb = radix_workspace_bytes(n, plan.n_passes);
         BP_TRY(ensure_dev(L, L->radix_ws, wsb));
         BP_TRY(sc_reset(L));
@@ -491,7 +529,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 }
 
 int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false) {
-    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, ((unsigned long long)id_varying << 32) | id_varying, assume_unique);
+    const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
+    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying);
+    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, false);
 }
 
 // raw pairs in ARBITRARY order (they are sorted afterwards): one walk per entry, workgroup-staged
@@ -973,7 +1013,7 @@ int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uin
     if (!L || !d_pairs || !n_pairs || (n && !d_packed)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_packed: null argument");
     DeviceGuard g(L->device);
     L->n_raw = n;
-    BP_TRY(sort_unique_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull, true));
+    BP_TRY(sort_distinct_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull));
     if (n == 0) BP_TRY(sync_stream(L));
     *d_pairs = (const uint32_t*)L->out_pairs.p;
     *n_pairs = L->n_pairs;

@@ -290,3 +290,23 @@ def test_cpp_facade_binary():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "facade ok" in out.stdout
+
+
+def test_segment_finish_falls_back_when_one_id_owns_many_pairs():
+    # one small box inside > 1024 large ones: its id owns more pairs than the LDS window of the
+    # first-id-only sort holds -> the full-width sort must take over, result unchanged
+    rng = np.random.default_rng(2)
+    n_big = 1500
+    sysb = ([0.0] * 3, [1000.0] * 3)
+    lo = rng.uniform(0, 300, size=(n_big, 3)).astype(np.float32)
+    hi = (lo + rng.uniform(400, 650, size=(n_big, 3))).astype(np.float32)
+    small = np.array([[350, 350, 350, 351, 351, 351]], dtype=np.float32)
+    more = scenes.gen_boxes(20000, seed=5)[1] * np.float32(1000.0 / 280.0)
+    bounds = np.concatenate([np.concatenate([lo, hi], axis=1), more[:5000], small]).astype(np.float32)
+    ids = np.arange(len(bounds), dtype=np.uint32)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    exp = ref.scan()
+    assert (exp[:, 0] == ids[-1]).sum() > 1024                # longer than any LDS window halo
+    assert_pairs_equal(gpu.par_scan(), exp, "scan with a >1024-pair segment")
+    assert gpu.stats()["flags"] == 3
