@@ -679,9 +679,12 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
 // that lies before i; runs are visited deepest first, so each search range ends where the
 // previous one began.  Emission order inside an entry (stack bottom -> top) is ascending j.
 // =================================================================================================
-// Ancestor runs of entry i, deepest level first; runs are found by galloping back from the end of
-// the remaining range and bisecting, so each search ends where the previous one began.
-// visit(j, dd) is called for every ancestor index j (descending) with the depth dd of its run.
+// Ancestor runs of entry i, deepest level first.  The kernels built on this are bound by the number
+// of DEPENDENT load round trips a wave makes (lanes diverge, so every lane's chain is serialised), so
+// the search is written to issue independent loads together: all gallop probes of a level at once
+// (distances 1, 3, 7, 15, 31, 63 back from the end of the remaining range), a small bracket loaded
+// whole instead of bisected, and the run of equal keys read four entries per step.
+// visit(lo, hi, dd) receives each non-empty run [lo, hi) of keys equal to the level's target.
 template <int KIND, class Visit>
 __device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, u32 i, u64 key, u32 present, Visit&& visit) {
     const u32 d = key_depth<KIND>(key);
@@ -693,25 +696,61 @@ __device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, u32
         const u64 target = (key & level_mask<KIND>(dd)) | (u64)dd;
         u32 hi = end;  // first index in [0, end) whose key is > target
         if (dd != d) {
-            u32 hb = end, lb = 0, step = 1;
-            for (;;) {
-                if (step > hb) { lb = 0; break; }
-                const u32 p = hb - step;
-                if (keys[p] > target) { hb = p; step <<= 1; }
-                else { lb = p + 1; break; }
+            constexpr int G = 6;
+            u32 pp[G];
+            u64 pv[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const u32 dist = (2u << k) - 1u;
+                pp[k] = end >= dist ? end - dist : 0u;
+                pv[k] = keys[pp[k]];
             }
-            while (lb < hb) {
+            u32 lb = 0, hb = pp[G - 1];
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (!found && pv[k] <= target) {
+                    found = true;
+                    lb = pp[k] + 1;
+                    hb = k == 0 ? end : pp[k - 1];
+                }
+            }
+            if (!found) {  // farther than 63 entries back: classic gallop from there
+                u32 step = 64;
+                for (;;) {
+                    if (step > hb) { lb = 0; break; }
+                    const u32 p = hb - step;
+                    if (keys[p] > target) { hb = p; step <<= 1; }
+                    else { lb = p + 1; break; }
+                }
+            }
+            while (hb - lb > 8) {
                 const u32 mid = lb + ((hb - lb) >> 1);
                 if (keys[mid] > target) hb = mid;
                 else lb = mid + 1;
             }
-            hi = lb;
+            u32 le = 0;  // sorted: the keys <= target form a prefix of the bracket
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) {
+                const u64 kq = (lb + q) < hb ? keys[lb + q] : ~0ull;
+                le += kq <= target ? 1u : 0u;
+            }
+            hi = lb + le;
         }
         u32 j = hi;
-        while (j > 0 && keys[j - 1] == target) {
-            --j;
-            visit(j, dd);
+        for (;;) {
+            u32 eq = 0;
+            bool run = true;
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) {
+                const u64 kq = j > q ? keys[j - 1 - q] : ~target;
+                run = run && kq == target;
+                eq += run ? 1u : 0u;
+            }
+            j -= eq;
+            if (eq < 4) break;
         }
+        if (j < hi) visit(j, hi, dd);
         end = j;
     }
 }
@@ -725,84 +764,111 @@ __device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, u32
 // entry (c of a) keeps ancestor (C of b) iff no cell c' of a with key(c') < key(c) lies in b's
 // box.  Unknown boxes (BOX_UNKNOWN) never suppress on their side, which can only leave extra
 // duplicates for the (then mandatory) final dedup pass -- never lose a pair.
+//
+// Everything the rule needs can be read off the low bits of the cell coordinates: a neighbour cell
+// c +/- 1 falls into a different depth-(d - sh) cell iff the low sh bits of c are all ones / all
+// zeros, and the most significant bit in which c +/- 1 differs from c is the position of c's lowest
+// zero / lowest one.  So per axis only the counts of trailing zeros and trailing ones of the
+// coordinate are kept, taken straight from the Morton code (no decode).
 template <int KIND> struct BoxCtx {
     u32 depth;
-    u32 c[3];        // this entry's cell coordinates at its depth
-    u32 lo[3];       // the object's box: first cell per axis
-    u32 n[3];        // cells per axis (1 or 2)
-    u32 earlier;     // bit (kx + 2 ky + 4 kz): that cell of the box exists and sorts before this one
+    u32 tz[3], to[3];  // trailing zeros / trailing ones of this cell's coordinate, per axis (<= depth)
+    u32 t[3];          // own box code per axis: 0 single, 1 lower of two, 2 upper of two
+    u32 earlier;       // bit (kx + 2 ky + 4 kz): that cell of the box exists and sorts before this one
 
-    __device__ __forceinline__ static void decode_box(u32 code, u32 t[3]) {
-        const u32 tz = (code * 57u) >> 9;           // code / 9 for code < 32
-        const u32 r = code - 9u * tz;
+    __device__ __forceinline__ static void decode_box(u32 code, u32 tt[3]) {
+        const u32 tz_ = (code * 57u) >> 9;          // code / 9 for code < 32
+        const u32 r = code - 9u * tz_;
         const u32 ty = (r * 11u) >> 5;              // r / 3 for r < 9
-        t[0] = r - 3u * ty; t[1] = ty; t[2] = tz;
-    }
-    // Morton order of two cells of one depth: the axis holding the most significant differing bit
-    // decides; on a tie the higher axis wins (z over y over x: src/index.rs:21-23)
-    __device__ __forceinline__ static bool morton_less(const u32 p[3], const u32 q[3]) {
-        constexpr int DIM = (int)KT<KIND>::DIM;
-        int best = 0;
-        u32 bx = p[0] ^ q[0];
-#pragma unroll
-        for (int ax = 1; ax < DIM; ++ax) {
-            const u32 x = p[ax] ^ q[ax];
-            const bool x_lower = x < bx && x < (x ^ bx);  // msb(x) < msb(bx)
-            if (!x_lower) { best = ax; bx = x; }
-        }
-        return p[best] < q[best];
+        tt[0] = r - 3u * ty; tt[1] = ty; tt[2] = tz_;
     }
     __device__ __forceinline__ void init(u64 key, u32 code) {
         constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+        constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
         depth = key_depth<KIND>(key);
-        const u64 morton = key >> DB;
-        const u32 down = AB - depth;
+        const u64 md = depth == 0 ? 0ull : ((key >> DB) >> (DIM * (AB - depth)));  // DIM * depth Morton bits
+        const u64 valid = depth == 0 ? 0ull : ((1ull << (DIM * depth)) - 1ull);
 #pragma unroll
-        for (u32 ax = 0; ax < 3; ++ax) { c[ax] = 0; lo[ax] = 0; n[ax] = 1; }
+        for (u32 ax = 0; ax < 3; ++ax) { tz[ax] = depth; to[ax] = depth; t[ax] = 0; }
 #pragma unroll
-        for (u32 ax = 0; ax < DIM; ++ax) c[ax] = depth == 0 ? 0u : (compact_bits<(int)DIM>(morton >> ax) >> down);
+        for (u32 ax = 0; ax < DIM; ++ax) {
+            const u64 ones = (md >> ax) & LANE;
+            const u64 zeros = (~(md >> ax)) & LANE & (valid >> ax);
+            const u32 z = ones ? (u32)__builtin_ctzll(ones) : DIM * depth;
+            const u32 o = zeros ? (u32)__builtin_ctzll(zeros) : DIM * depth;
+            tz[ax] = DIM == 3 ? (z * 171u) >> 9 : z >> 1;   // / DIM
+            to[ax] = DIM == 3 ? (o * 171u) >> 9 : o >> 1;
+        }
         earlier = 0;
-        if (code >= 27u) {  // unknown box: behave as a single-cell object (never suppressed)
-#pragma unroll
-            for (u32 ax = 0; ax < 3; ++ax) lo[ax] = c[ax];
-            return;
-        }
-        u32 t[3];
+        if (code >= 27u) return;  // unknown box: behave as a single-cell object (never suppressed)
         decode_box(code, t);
+        // cell k of the box = this cell + delta, delta_ax = k_ax - (t_ax == 2).  It differs from this
+        // cell most significantly at bit (to or tz) of the axis that moved up or down; the axis with
+        // the largest interleaved bit position decides the Morton order.
 #pragma unroll
-        for (u32 ax = 0; ax < 3; ++ax) {
-            n[ax] = t[ax] ? 2u : 1u;
-            lo[ax] = c[ax] - (t[ax] == 2u ? 1u : 0u);
-        }
+        for (u32 k = 1; k < 8; ++k) {
+            int best = -1;
+            bool less = false;
+            bool exists = true;
 #pragma unroll
-        for (u32 k = 0; k < 8; ++k) {
-            const u32 kx = k & 1u, ky = (k >> 1) & 1u, kz = k >> 2;
-            if (kx < n[0] && ky < n[1] && kz < n[2]) {
-                const u32 q[3] = {lo[0] + kx, lo[1] + ky, lo[2] + kz};
-                if (morton_less(q, c)) earlier |= 1u << k;
+            for (u32 ax = 0; ax < 3; ++ax) {
+                const u32 kk = (k >> ax) & 1u;
+                const u32 self = t[ax] == 2u ? 1u : 0u;
+                if (kk >= (t[ax] ? 2u : 1u)) exists = false;
+                if (kk != self) {
+                    const bool up = kk > self;
+                    const int pos = (int)((up ? to[ax] : tz[ax]) * DIM + ax);
+                    if (pos > best) { best = pos; less = !up; }
+                }
             }
+            if (exists && best >= 0 && less) earlier |= 1u << k;
+        }
+        // bit 0 is cell (0,0,0) of the box: handled by the loop only for k >= 1
+        {
+            int best = -1;
+            bool less = false;
+#pragma unroll
+            for (u32 ax = 0; ax < 3; ++ax) {
+                if (t[ax] == 2u) {  // this cell is the upper one: cell 0 is one step down on this axis
+                    const int pos = (int)(tz[ax] * DIM + ax);
+                    if (pos > best) { best = pos; less = true; }
+                }
+            }
+            if (best >= 0 && less) earlier |= 1u;
         }
     }
     // ancestor entry at depth dd <= depth with box code `code`: is the pair emitted elsewhere?
     __device__ __forceinline__ bool suppressed(u32 dd, u32 code) const {
-        if (earlier == 0) return false;
         const u32 sh = depth - dd;
-        u32 t[3] = {0, 0, 0};
-        if (code < 27u) decode_box(code, t);
+        u32 tb[3] = {0, 0, 0};
+        if (code < 27u) decode_box(code, tb);
         u32 inside = 0xFFu;
         const u32 pat0[3] = {0x55u, 0x33u, 0x0Fu}, pat1[3] = {0xAAu, 0xCCu, 0xF0u};
 #pragma unroll
         for (u32 ax = 0; ax < 3; ++ax) {
-            const u32 C = c[ax] >> sh;                         // the ancestor's cell on this axis
-            const u32 blo = C - (t[ax] == 2u ? 1u : 0u), bn = t[ax] ? 2u : 1u;
-            u32 m = 0;
-            if (((lo[ax] >> sh) - blo) < bn) m |= pat0[ax];
-            if (n[ax] == 2u && (((lo[ax] + 1u) >> sh) - blo) < bn) m |= pat1[ax];
+            const u32 self_pat = t[ax] == 2u ? pat1[ax] : pat0[ax];
+            u32 m = self_pat;  // this cell lies in the ancestor's cell by construction
+            if (t[ax] != 0u) {
+                const bool up = t[ax] == 1u;  // the other cell of the box is one step up / down
+                const bool crosses = (up ? to[ax] : tz[ax]) >= sh;
+                const bool other_inside = !crosses || tb[ax] == (up ? 1u : 2u);
+                if (other_inside) m |= (pat0[ax] | pat1[ax]) & ~self_pat;
+            }
             inside &= m;
         }
         return (inside & earlier) != 0;
     }
 };
+
+// candidates of one run, highest index first, FOUR per step so their id / box loads are independent
+template <class F> __device__ __forceinline__ void for_run_desc(u32 lo, u32 hi, F&& f) {
+    u32 j = hi;
+    while (j >= lo + 4) {
+        j -= 4;
+        f(j + 3); f(j + 2); f(j + 1); f(j);
+    }
+    while (j > lo) { --j; f(j); }
+}
 
 // general mode only: skipped(i) <=> some ancestor carries the same id (src/layer.rs:563-565)
 template <int KIND>
@@ -813,7 +879,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_skipflags_kernel(ScanParams
     const u64 key = p.keys[i];
     const u32 id = p.ids[i];
     bool sk = false;
-    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) { sk = sk || (p.ids[j] == id); });
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32) {
+        for_run_desc(lo, hi, [&](u32 j) { sk = sk || (p.ids[j] == id); });
+    });
     p.skip[i] = sk ? 1 : 0;
 }
 
@@ -830,13 +898,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_count_kernel(ScanParams p, 
         if (GENERAL) active = active && !p.skip[i];
         if (active) {
             if (GENERAL) {
-                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) { cnt += p.skip[j] ? 0u : 1u; });
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32) {
+                    for_run_desc(lo, hi, [&](u32 j) { cnt += p.skip[j] ? 0u : 1u; });
+                });
             } else if (p.box) {
                 BoxCtx<KIND> bx;
                 bx.init(key, p.box[i]);
-                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) { cnt += bx.suppressed(dd, p.box[j]) ? 0u : 1u; });
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+                    if (bx.earlier == 0) { cnt += hi - lo; return; }
+                    for_run_desc(lo, hi, [&](u32 j) { cnt += bx.suppressed(dd, p.box[j]) ? 0u : 1u; });
+                });
             } else {
-                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32, u32) { ++cnt; });
+                walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32) { cnt += hi - lo; });
             }
         }
         counts[i] = cnt;
@@ -870,17 +943,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, c
     if (!GENERAL && p.box) {
         BoxCtx<KIND> bx;
         bx.init(key, p.box[i]);
-        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
-            if (bx.suppressed(dd, p.box[j])) return;
-            --pos;
-            out[pos] = hi_id | (u64)p.ids[j];
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            for_run_desc(lo, hi, [&](u32 j) {
+                const u32 idj = p.ids[j];
+                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                --pos;
+                out[pos] = hi_id | (u64)idj;
+            });
         });
         return;
     }
-    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32) {
-        if (GENERAL && p.skip[j]) return;
-        --pos;
-        out[pos] = hi_id | (u64)p.ids[j];
+    walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32) {
+        for_run_desc(lo, hi, [&](u32 j) {
+            const u32 idj = p.ids[j];
+            if (GENERAL && p.skip[j]) return;
+            --pos;
+            out[pos] = hi_id | (u64)idj;
+        });
     });
 }
 
@@ -913,12 +992,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
         }
     }
     u32 mine = 0;
-    if (active) {
-        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
-            if (p.box && bx.suppressed(dd, p.box[j])) return;
-            const u32 slot = atomicAdd(&s_cursor, 1u);
-            if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)p.ids[j];
-            ++mine;
+    const int dbg = p.general;  // timing experiments only (general is always 0 on this path)
+    if (active && (dbg & 3)) {
+        u32 acc = 0;
+        walk_ancestors<KIND>(p.keys, i, key, (dbg & 2) ? (p.depth_mask & (1u << key_depth<KIND>(key))) : p.depth_mask,
+                             [&](u32 lo, u32 hi, u32) { acc += hi - lo; });
+        if (acc == 0xFFFFFFFFu) s_pairs[0] = acc;
+    } else if (active && (dbg & 4)) {
+        u32 acc = 0;
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            for_run_desc(lo, hi, [&](u32 j) {
+                const u32 idj = p.ids[j];
+                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                acc += idj;
+            });
+        });
+        if (acc == 0xFFFFFFFFu) s_pairs[0] = acc;
+    } else if (active) {
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            for_run_desc(lo, hi, [&](u32 j) {
+                const u32 idj = p.ids[j];
+                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                const u32 slot = atomicAdd(&s_cursor, 1u);
+                if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)idj;
+                ++mine;
+            });
         });
     }
     __syncthreads();
@@ -935,10 +1033,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
     if (active && mine) {
-        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 j, u32 dd) {
-            if (p.box && bx.suppressed(dd, p.box[j])) return;
-            const u32 slot = atomicAdd(&s_cursor, 1u);
-            out[base + slot] = hi_id | (u64)p.ids[j];
+        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            for_run_desc(lo, hi, [&](u32 j) {
+                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                const u32 slot = atomicAdd(&s_cursor, 1u);
+                out[base + slot] = hi_id | (u64)p.ids[j];
+            });
         });
     }
 }

@@ -549,6 +549,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.coarse_depth = coarse_depth;
     p.emit_coarse = emit_coarse;
     p.general = 0;
+    { const char* e = getenv("BP_SCAN_DEBUG"); if (e) p.general = atoi(e); }  // timing experiments only
     p.skip = nullptr;
     p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
