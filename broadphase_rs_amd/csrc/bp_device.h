@@ -64,6 +64,18 @@ template <int KIND> __device__ __forceinline__ uint32_t key_depth(uint64_t key) 
     return (uint32_t)key & ((1u << KT<KIND>::DB) - 1u);
 }
 
+// box code: memory byte (2 bits per axis) <-> 5-bit ternary field of the packed sort payload
+__device__ __forceinline__ uint32_t box_to_packed(uint32_t b) {
+    return b == 0xFFu ? 31u : (b & 3u) + 3u * ((b >> 2) & 3u) + 9u * ((b >> 4) & 3u);
+}
+__device__ __forceinline__ uint32_t box_from_packed(uint32_t c) {
+    if (c >= 27u) return 0xFFu;
+    const uint32_t tz = (c * 57u) >> 9;  // c / 9
+    const uint32_t r = c - 9u * tz;
+    const uint32_t ty = (r * 11u) >> 5;  // r / 3
+    return (r - 3u * ty) | (ty << 2) | (tz << 4);
+}
+
 // Rust `f32 as u32`: saturating, NaN -> 0
 __device__ __forceinline__ uint32_t f32_to_u32_sat(float f) {
     if (!(f > 0.0f)) return 0u;

@@ -53,9 +53,10 @@ struct BlockAux {
 
 // Per-entry description of its object's cell set, when that set is a box of at most 2 cells per
 // axis (always, unless min_depth forces more): per axis t = 0 (one cell), 1 (two cells, this is the
-// lower), 2 (two cells, this is the upper); code = t_x + 3 t_y + 9 t_z  (0..26).  It rides in the
-// 5 spare high bits of the id payload through the tree sort (ids < 2^27).
-enum : unsigned { BOX_UNKNOWN = 31u, BOX_ID_BITS = 27u, BOX_ID_MASK = (1u << 27) - 1u };
+// lower), 2 (two cells, this is the upper).  In memory: one byte, 2 bits per axis (t_x | t_y << 2 |
+// t_z << 4), BOX_UNKNOWN otherwise.  Through the tree sort it rides in the 5 spare high bits of
+// the id payload (ids < 2^27) as the ternary number t_x + 3 t_y + 9 t_z (31 = unknown).
+enum : unsigned { BOX_UNKNOWN = 0xFFu, BOX_PACKED_UNKNOWN = 31u, BOX_ID_BITS = 27u, BOX_ID_MASK = (1u << 27) - 1u };
 
 struct SysBounds {
     float mn[3];
@@ -169,6 +170,14 @@ constexpr int SEG_THREADS = 256;
 constexpr int SEG_CHUNK = 2048;
 constexpr int SEG_HALO = 512;
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
+
+// Finishing step of the tree sort after radix passes on the high key bits only: entries are grouped
+// by (key >> seg_shift); every group is rank-sorted by (key, id, input position) in an LDS window and
+// written out.  payload_packed: the u32 payload carries the box code in bits 27..31 (it is split into
+// ids_out / box_out here).  Sets KERR_SEGMENT_TOO_LONG when a group does not fit the window.
+hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* ids_in, size_t m, int seg_shift,
+                                      int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out,
+                                      DevScalars* sc, hipStream_t stream);
 
 // interleaved (id, id_) u32 pairs <-> packed u64 (id << 32 | id_)
 hipError_t launch_pack_pairs(const uint32_t* pairs, size_t n, uint64_t* packed, hipStream_t stream);

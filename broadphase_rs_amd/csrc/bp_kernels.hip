@@ -222,7 +222,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 ids_out[pos] = id;
                 if (box_out) {
                     const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
-                    box_out[pos] = boxy ? (uint8_t)(tx + 3u * ty + 9u * tz) : (uint8_t)BOX_UNKNOWN;
+                    box_out[pos] = boxy ? (uint8_t)(tx | (ty << 2) | (tz << 4)) : (uint8_t)BOX_UNKNOWN;
                 }
                 ++pos;
             }
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
             if (li < tile_n) {
                 val[r] = vals_in[base + li];
                 if constexpr (sizeof(V) == 4) {
-                    if (box_in) val[r] |= (V)box_in[base + li] << BOX_ID_BITS;  // first pass: pack
+                    if (box_in) val[r] |= (V)box_to_packed(box_in[base + li]) << BOX_ID_BITS;  // first pass: pack
                 }
             }
         }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
                     V v = stage_v[li];
                     if constexpr (sizeof(V) == 4) {
                         if (box_out) {  // last pass: unpack
-                            box_out[g] = (uint8_t)(v >> BOX_ID_BITS);
+                            box_out[g] = (uint8_t)box_from_packed((u32)v >> BOX_ID_BITS);
                             v &= (V)BOX_ID_MASK;
                         }
                     }
@@ -776,12 +776,6 @@ template <int KIND> struct BoxCtx {
     u32 t[3];          // own box code per axis: 0 single, 1 lower of two, 2 upper of two
     u32 earlier;       // bit (kx + 2 ky + 4 kz): that cell of the box exists and sorts before this one
 
-    __device__ __forceinline__ static void decode_box(u32 code, u32 tt[3]) {
-        const u32 tz_ = (code * 57u) >> 9;          // code / 9 for code < 32
-        const u32 r = code - 9u * tz_;
-        const u32 ty = (r * 11u) >> 5;              // r / 3 for r < 9
-        tt[0] = r - 3u * ty; tt[1] = ty; tt[2] = tz_;
-    }
     __device__ __forceinline__ void init(u64 key, u32 code) {
         constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
         constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
@@ -800,8 +794,8 @@ template <int KIND> struct BoxCtx {
             to[ax] = DIM == 3 ? (o * 171u) >> 9 : o >> 1;
         }
         earlier = 0;
-        if (code >= 27u) return;  // unknown box: behave as a single-cell object (never suppressed)
-        decode_box(code, t);
+        if (code == BOX_UNKNOWN) return;  // unknown box: behave as a single-cell object (never suppressed)
+        t[0] = code & 3u; t[1] = (code >> 2) & 3u; t[2] = (code >> 4) & 3u;
         // cell k of the box = this cell + delta, delta_ax = k_ax - (t_ax == 2).  It differs from this
         // cell most significantly at bit (to or tz) of the axis that moved up or down; the axis with
         // the largest interleaved bit position decides the Morton order.
@@ -840,8 +834,8 @@ template <int KIND> struct BoxCtx {
     // ancestor entry at depth dd <= depth with box code `code`: is the pair emitted elsewhere?
     __device__ __forceinline__ bool suppressed(u32 dd, u32 code) const {
         const u32 sh = depth - dd;
-        u32 tb[3] = {0, 0, 0};
-        if (code < 27u) decode_box(code, tb);
+        const u32 cb = code == BOX_UNKNOWN ? 0u : code;  // unknown: the ancestor's own cell only
+        const u32 tb[3] = {cb & 3u, (cb >> 2) & 3u, (cb >> 4) & 3u};
         u32 inside = 0xFFu;
         const u32 pat0[3] = {0x55u, 0x33u, 0x0Fu}, pat1[3] = {0xAAu, 0xCCu, 0xF0u};
 #pragma unroll
@@ -1141,8 +1135,83 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* 
         }
         if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) too_long = true;  // may leave the window
         u32 rank = 0;
-        for (u32 y = start; y < end; ++y) rank += s_win[y] < v ? 1u : 0u;  // independent LDS reads
+        const u32 vb = (u32)v;
+        const u32* s_lo = reinterpret_cast<const u32*>(s_win);  // low dword = second id (first ids are equal)
+        for (u32 y = start; y < end; ++y) rank += s_lo[2 * y] < vb ? 1u : 0u;  // independent LDS reads
         out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
+    }
+    if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const u64* __restrict__ keys_in,
+                                                                           const u32* __restrict__ ids_in, size_t n, int seg_shift,
+                                                                           u64* __restrict__ keys_out, u32* __restrict__ ids_out,
+                                                                           uint8_t* __restrict__ box_out, DevScalars* sc) {
+    constexpr int WIN = SEG_HALO + SEG_CHUNK + SEG_HALO;
+    constexpr int GROUPS = WIN / 64;
+    __shared__ u64 s_key[WIN];
+    __shared__ u32 s_id[WIN];
+    __shared__ u64 s_heads[GROUPS];
+    const size_t base = (size_t)blockIdx.x * SEG_CHUNK;
+    const size_t win_lo = base > (size_t)SEG_HALO ? base - SEG_HALO : 0;
+    const size_t hi_want = base + SEG_CHUNK + SEG_HALO;
+    const size_t win_hi = hi_want < n ? hi_want : n;
+    const u32 wlen = (u32)(win_hi - win_lo);
+    for (u32 k = threadIdx.x; k < (u32)WIN; k += SEG_THREADS) {
+        s_key[k] = k < wlen ? keys_in[win_lo + k] : ~0ull;
+        s_id[k] = k < wlen ? ids_in[win_lo + k] : 0u;
+    }
+    __syncthreads();
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    for (int g = w; g < GROUPS; g += SEG_THREADS / 64) {
+        const u32 x = (u32)g * 64u + (u32)lane;
+        const bool head = x < wlen && (x == 0 || (s_key[x] >> seg_shift) != (s_key[x - 1] >> seg_shift));
+        const u64 m = __ballot(head);
+        if (lane == 0) s_heads[g] = m;
+    }
+    __syncthreads();
+    const u32 off = (u32)(base - win_lo);
+    const u32 cend = (u32)(((base + SEG_CHUNK) < n ? (base + SEG_CHUNK) : n) - win_lo);
+    const u32 ngroups = (wlen + 63u) / 64u;
+    bool too_long = false;
+    for (u32 x = off + threadIdx.x; x < cend; x += SEG_THREADS) {
+        const u64 kx = s_key[x];
+        const u32 px = s_id[x];
+        const u32 ix = PACKED ? (px & BOX_ID_MASK) : px;
+        const u32 g = x >> 6, l = x & 63u;
+        const u64 m = s_heads[g];
+        const u64 le = l == 63u ? ~0ull : ((2ull << l) - 1ull);
+        u32 start;
+        const u64 below = m & le;
+        if (below) {
+            start = g * 64u + 63u - (u32)__clzll((long long)below);
+        } else {
+            int gg = (int)g - 1;
+            while (gg >= 0 && s_heads[gg] == 0) --gg;
+            start = gg < 0 ? 0u : (u32)gg * 64u + 63u - (u32)__clzll((long long)s_heads[gg]);
+        }
+        u32 end;
+        const u64 above = m & ~le;
+        if (above) {
+            end = g * 64u + (u32)__builtin_ctzll(above);
+        } else {
+            u32 gg = g + 1;
+            while (gg < ngroups && s_heads[gg] == 0) ++gg;
+            end = gg < ngroups ? gg * 64u + (u32)__builtin_ctzll(s_heads[gg]) : wlen;
+        }
+        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) too_long = true;
+        u32 rank = 0;
+        for (u32 y = start; y < end; ++y) {  // order: key, then id, then input position (exact duplicates)
+            const u64 ky = s_key[y];
+            const u32 iy = PACKED ? (s_id[y] & BOX_ID_MASK) : s_id[y];
+            const bool less = ky < kx || (ky == kx && (iy < ix || (iy == ix && y < x)));
+            rank += less ? 1u : 0u;
+        }
+        const size_t dst = win_lo + start + rank;
+        keys_out[dst] = kx;
+        ids_out[dst] = ix;
+        if (PACKED) box_out[dst] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
     }
     if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
 }
@@ -1369,7 +1438,7 @@ hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const 
 __global__ __launch_bounds__(256) void split_box_kernel(u32* __restrict__ ids, uint8_t* __restrict__ box, size_t m) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
         const u32 v = ids[i];
-        box[i] = (uint8_t)(v >> BOX_ID_BITS);
+        box[i] = (uint8_t)box_from_packed(v >> BOX_ID_BITS);
         ids[i] = v & BOX_ID_MASK;
     }
 }
@@ -1451,6 +1520,20 @@ hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_o
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)((n + SEG_CHUNK - 1) / SEG_CHUNK);
     segment_finish_kernel<<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
+    return hipGetLastError();
+}
+
+hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* ids_in, size_t m, int seg_shift,
+                                      int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out,
+                                      DevScalars* sc, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    const unsigned g = (unsigned)((m + SEG_CHUNK - 1) / SEG_CHUNK);
+    if (payload_packed)
+        tree_segment_finish_kernel<true><<<g, SEG_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, m, seg_shift, (u64*)keys_out,
+                                                                         ids_out, box_out, sc);
+    else
+        tree_segment_finish_kernel<false><<<g, SEG_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, m, seg_shift, (u64*)keys_out,
+                                                                          ids_out, box_out, sc);
     return hipGetLastError();
 }
 

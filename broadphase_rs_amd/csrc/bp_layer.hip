@@ -350,32 +350,91 @@ bool box_can_ride(const bp_layer* L) {  // the box codes travel in the id payloa
     return L->box_valid && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
 }
 
+// full-width LSD sort (every varying key bit, ids first when the order fact is missing)
+int sort_tree_full(bp_layer* L, bool payload_already_packed) {
+    const RadixPlan plan = make_radix_plan(L->key_or ^ L->key_and, L->order_ok ? 0 : 1, L->id_or ^ L->id_and);
+    L->stats.tree_sort_passes += (uint32_t)plan.n_passes;
+    if (plan.n_passes == 0) return BP_OK;
+    const int other = L->cur ^ 1;
+    BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
+    const bool ride = payload_already_packed || box_can_ride(L);
+    const int dest = (plan.n_passes & 1) ? other : L->cur;
+    if (ride) BP_TRY(ensure_dev(L, L->box[dest], L->m, dest == L->cur ? L->m : 0));
+    BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, plan.n_passes)));
+    BP_TRY(sc_reset(L));
+    int res = 0;
+    uint64_t* k0 = (uint64_t*)L->keys[L->cur].p; uint64_t* k1 = (uint64_t*)L->keys[other].p;
+    uint32_t* v0 = (uint32_t*)L->ids[L->cur].p;  uint32_t* v1 = (uint32_t*)L->ids[other].p;
+    HIP_TRY(L, radix_sort(k0, k1, v0, v1, L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res,
+                          L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
+                          (ride && !payload_already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr,
+                          ride ? (uint8_t*)L->box[dest].p : nullptr));
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    if (res) L->cur = other;
+    L->box_valid = ride;  // otherwise the codes stayed behind in append order
+    return BP_OK;
+}
+
 int sort_tree(bp_layer* L) {
     if (L->sorted) return BP_OK;  // src/layer.rs:148, 161
+    static const bool no_finish = getenv("BP_NO_TREE_FINISH") != nullptr;  // A/B switch for measurements
+    L->stats.tree_sort_passes = 0;
     if (L->m > 1) {
-        const RadixPlan plan = make_radix_plan(L->key_or ^ L->key_and, L->order_ok ? 0 : 1, L->id_or ^ L->id_and);
-        L->stats.tree_sort_passes = (uint32_t)plan.n_passes;
-        if (plan.n_passes > 0) {
+        const unsigned long long varying = L->key_or ^ L->key_and;
+        // Partial sort: radix passes over the top key bits only, enough that the groups of equal
+        // prefix hold ~4 entries on average; the groups are then rank-sorted by (key, id) in LDS.
+        int top = varying ? 64 - __builtin_clzll(varying) : 0;
+        int want_bits = 8;
+        while (want_bits < 56 && ((unsigned long long)L->m >> (want_bits + 2)) != 0) want_bits += 8;
+        const int n_part = want_bits / 8;
+        const int seg_shift = top - 8 * n_part;
+        const bool partial = !no_finish && L->m >= 4096 && seg_shift > 0 && (varying & ((1ull << seg_shift) - 1ull)) != 0;
+        bool done = false;
+        if (partial) {
+            RadixPlan plan;
+            plan.n_passes = n_part;
+            for (int i = 0; i < RS_MAX_PASSES; ++i) { plan.shift[i] = 0; plan.from_val[i] = 0; }
+            for (int i = 0; i < n_part; ++i) plan.shift[i] = seg_shift + 8 * i;
+            L->stats.tree_sort_passes = (uint32_t)n_part;
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
             BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
             const bool ride = box_can_ride(L);
-            const int dest = (plan.n_passes & 1) ? other : L->cur;
-            if (ride) BP_TRY(ensure_dev(L, L->box[dest], L->m, dest == L->cur ? L->m : 0));
-            const size_t wsb = radix_workspace_bytes(L->m, plan.n_passes);
-            BP_TRY(ensure_dev(L, L->radix_ws, wsb));
+            BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, plan.n_passes)));
             BP_TRY(sc_reset(L));
             int res = 0;
-            uint64_t* k0 = (uint64_t*)L->keys[L->cur].p; uint64_t* k1 = (uint64_t*)L->keys[other].p;
-            uint32_t* v0 = (uint32_t*)L->ids[L->cur].p;  uint32_t* v1 = (uint32_t*)L->ids[other].p;
-            HIP_TRY(L, radix_sort(k0, k1, v0, v1, L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &res,
-                                  L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
-                                  ride ? (const uint8_t*)L->box[L->cur].p : nullptr, ride ? (uint8_t*)L->box[dest].p : nullptr));
-            DevScalars sc;
-            BP_TRY(sc_fetch(L, &sc));
-            if (res) L->cur = other;
-            L->box_valid = ride;  // otherwise the codes stayed behind in append order
+            uint64_t* kb[2] = {(uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p};
+            uint32_t* vb[2] = {(uint32_t*)L->ids[L->cur].p, (uint32_t*)L->ids[other].p};
+            // first pass packs the box codes into the payload; the finish kernel splits them off again
+            HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
+                                  &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
+                                  ride ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr));
+            const int src = res ? other : L->cur, dst = src ^ 1;
+            if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
+            {
+                ProfScope ps(L, BP_K_TREE_SORT);
+                HIP_TRY(L, launch_tree_segment_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, L->m, seg_shift,
+                                                      ride ? 1 : 0, (uint64_t*)L->keys[dst].p, (uint32_t*)L->ids[dst].p,
+                                                      ride ? (uint8_t*)L->box[dst].p : nullptr, (DevScalars*)L->d_sc.p, L->stream));
+            }
+            HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+            BP_TRY(sync_stream(L));
+            const DevScalars sc = *(DevScalars*)L->h_sc.p;
+            if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+            if (sc.err & KERR_SEGMENT_TOO_LONG) {
+                // a group of equal key prefix is longer than the LDS window (heavily clustered input):
+                // finish with the full-width sort, starting from the partially sorted (still packed) data
+                L->cur = src;
+                BP_TRY(sort_tree_full(L, ride));
+            } else {
+                L->cur = dst;
+                L->box_valid = ride;
+            }
+            done = true;
         }
+        if (!done) BP_TRY(sort_tree_full(L, false));
     }
     L->sorted = true;
     L->order_ok = true;  // a (key, id)-sorted array satisfies the stable-sort precondition again
