@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--objects", type=int, default=10_000_000, help="objects per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-objects", type=int, default=1_000_000, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-objects", type=int, default=10_000_000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
     return ap.parse_args()
@@ -183,16 +183,40 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n_pairs / (dt / args.steps)
         M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
-        # dominant kernel: one radix pass over the packed raw pairs.  ALGORITHMIC bytes per launch:
-        # 16 B per raw pair (8 B read + 8 B written), SURVEY.md 8(d) B_pairsort = (8 + 16 p_p) P_raw.
-        sort_ms, sort_launches = prof["pair_sort"]
-        per_launch_ms = sort_ms / max(sort_launches, 1)
-        bytes_per_launch = 16.0 * P_raw
-        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        # model bytes of one whole step, with the passes actually run
         pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
-        b_total = (28.0 * n + 12.0 * M) + (8 + 24 * pk) * M + (12.0 * M + 8.0 * P_raw) + (8 + 16 * pp) * P_raw + \
-            (8.0 * P_raw + 8.0 * P)
+        # ALGORITHMIC bytes per step and per kernel class (SURVEY.md 8(d) per-unit figures x measured
+        # N / M / P_raw / P).  P_raw is what the scan actually emitted: with
+        # duplicate suppression at the source it equals P.
+        model = {
+            "encode": 64.0 * n + 13.0 * M,                    # bounds+ids read twice, counts w+r, entries + box written
+            "tree_hist": 8.0 * M,
+            "tree_sort": 24.0 * M * pk + 25.0 * M,            # key+id per pass (r+w) + finish (12 r + 13 w)
+            "scan_count": 12.0 * M,
+            "scan_emit": 13.0 * M + 8.0 * P_raw,              # keys, ids, box read; packed pairs written
+            "pair_hist": 8.0 * P_raw,
+            "pair_sort": 16.0 * P_raw * pp,
+            "dedup": 16.0 * P_raw,                            # finish / unique: pairs read, ABI layout written
+            "misc": 0.0,
+        }
+        launches = {k: v[1] / args.steps for k, v in prof.items()}
+        per_step_ms = {k: v[0] / args.steps for k, v in prof.items()}
+        kernels = {k: {"ms_per_step": per_step_ms[k], "timed_regions_per_step": launches[k], "model_bytes_per_step": model[k],
+                       "GBps": (model[k] / (per_step_ms[k] * 1e-3) / 1e9) if per_step_ms[k] > 0 else 0.0}
+                   for k in prof}
+        # dominant kernel = the kernel (by name) with the largest time per step.  Radix passes are
+        # timed per launch, so a class total is launches x one kernel; the scan is a single launch.
+        cand = {
+            "scan_fused_kernel (overlap scan, single pass)": ("scan_emit", 1.0, model["scan_emit"]),
+            "radix_onesweep_kernel<u64,NoVal> (pair-sort pass)": ("pair_sort", max(launches["pair_sort"], 1.0), 16.0 * P_raw),
+        }
+        dom_name = max(cand, key=lambda k: per_step_ms[cand[k][0]])
+        dom_cls, dom_launches, bytes_per_launch = cand[dom_name]
+        per_launch_ms = per_step_ms[dom_cls] / dom_launches
+        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        # the radix pass is the HBM-bound kernel of the path: always reported as well
+        rp_ms = per_step_ms["pair_sort"] / max(launches["pair_sort"], 1.0)
+        rp_achieved = 16.0 * P_raw / (rp_ms * 1e-3) / 1e9 if rp_ms > 0 else 0.0
+        b_total = sum(model.values())
         line = {
             "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,14 +228,29 @@ def main():
                        "objects_per_gpu": n, "objects_total": n_global, "entries": M, "raw_pairs": P_raw,
                        "pairs_rank0": P, "pairs_total": n_pairs, "tree_sort_passes": pk, "pair_sort_passes": pp,
                        "parallelism": "1 GPU" if world == 1 else "morton-range shards x%d, RCCL all-to-all" % world},
-            "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel<u64,NoVal> (pair sort pass)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": per_launch_ms,
-                         "launches": sort_launches},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": per_launch_ms, "launches_per_step": dom_launches},
+            "roofline_radix_pass": {"bound": "hbm", "kernel": "radix_onesweep_kernel<u64,NoVal> (pair-sort pass)",
+                                    "achieved": rp_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": rp_achieved / HBM_PEAK_GBS, "bytes_per_launch": 16.0 * P_raw, "avg_launch_ms": rp_ms},
             "step_model": {"bytes": b_total, "GBps": b_total / (ms_per_step * 1e-3) / 1e9,
                            "frac_of_peak": b_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernels": kernels,
+            "kernel_ms_per_step": per_step_ms,
         }
+        # HBM traffic per launch of the dominant kernel from the rocprofv3 PMC passes of the same
+        # command (profiles/traffic.json, written by profiles/summarize.py: 2 x FETCH_SIZE + WRITE_SIZE
+        # KiB, the guide's gfx950 correction); null when no such profile has been committed
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            key = "scan_fused_kernel" if dom_cls == "scan_emit" else "radix_onesweep_kernel<u64, NoVal"
+            hit = [v for k, v in tj.get("bytes_per_launch", {}).items() if k.startswith(key)]
+            if hit and tj.get("objects") == n:
+                line["roofline"]["traffic"] = hit[0]
+                line["roofline"]["traffic_source"] = tj.get("source")
+        except (OSError, ValueError):
+            pass
         if sharded_path:
             line["sharded"] = sharded.last
         if not args.no_cpu_baseline and world == 1:
