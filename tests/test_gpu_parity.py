@@ -310,3 +310,22 @@ def test_segment_finish_falls_back_when_one_id_owns_many_pairs():
     assert (exp[:, 0] == ids[-1]).sum() > 1024                # longer than any LDS window halo
     assert_pairs_equal(gpu.par_scan(), exp, "scan with a >1024-pair segment")
     assert gpu.stats()["flags"] == 3
+
+
+def test_powerlaw_200k_overflows_stage_and_segments():
+    """Mixed-scale scene (BASELINE.json configs[4] shape, scaled down): hundreds of raw pairs per
+    object -> workgroups overflow the fused scan's LDS stage (> 3072 pairs per 256 entries), long
+    first-id segments, deep ancestor chains."""
+    sysb, bounds, ids = scenes.gen_boxes_powerlaw(200_000, seed=6, alpha=1.5)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    assert_tree_equal(gpu, ref, "powerlaw extend")
+    gpu.par_sort(); ref.par_sort()
+    assert_tree_equal(gpu, ref, "powerlaw sort")
+    exp = ref.par_scan()
+    assert len(exp) > 20 * len(ids)
+    assert np.bincount(exp[:, 0]).max() > 128               # long first-id segments (the >1024 fallback has its own test)
+    got = np.array(gpu.par_scan())
+    assert_pairs_equal(got, exp, "powerlaw scan")
+    st = gpu.stats()
+    assert st["raw_pairs"] == len(exp)                      # still exactly unique at the source
