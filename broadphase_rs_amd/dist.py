@@ -146,17 +146,32 @@ class TorchComm:
     # into per-peer pieces of at most CHUNK_BYTES.
     CHUNK_BYTES = 256 << 20
 
-    def all_to_all_v(self, send, send_counts, dtype, backend):
+    def all_gather_counts(self, counts, backend):
+        """every rank's count vector -> matrix C[src][k] (one small collective instead of one per exchange)"""
+        torch, dist = self.torch, self.dist
+        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=backend.device)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return np.stack([p.cpu().numpy() for p in parts])
+
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None):
         """variable-size all-to-all of a tensor that is already grouped by destination"""
         torch, dist = self.torch, self.dist
         send_counts = [int(c) for c in send_counts]
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(c) for c in rc.cpu().tolist()]
+        if recv_counts is None:
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv_counts = [int(c) for c in rc.cpu().tolist()]
+        else:
+            recv_counts = [int(c) for c in recv_counts]
         recv = backend.empty(sum(recv_counts), dtype)
         ch = max(1, self.CHUNK_BYTES // send.element_size())
-        rounds = self.all_reduce_max((max(send_counts + recv_counts) + ch - 1) // ch, backend)
+        # the largest single message of ANY rank decides the number of rounds; with the counts matrix
+        # known everywhere this needs no collective (callers pass global_max), else one all-reduce
+        local_max = max(send_counts + recv_counts)
+        gmax = getattr(self, "_global_max_hint", None)
+        rounds = (int(gmax) + ch - 1) // ch if gmax is not None else self.all_reduce_max((local_max + ch - 1) // ch, backend)
         soff = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
         roff = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
         if rounds <= 1:
@@ -178,13 +193,15 @@ class TorchComm:
         backend.sync()
         return recv
 
-    def all_gather_v(self, t, dtype, backend):
+    def all_gather_v(self, t, dtype, backend, sizes=None):
         """all-gather of per-rank tensors of different lengths, concatenated in rank order"""
         torch, dist = self.torch, self.dist
-        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-        sizes = [torch.empty_like(n) for _ in range(self.world)]
-        dist.all_gather(sizes, n, group=self.group)
-        sizes = [int(s.item()) for s in sizes]
+        if sizes is None:
+            n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+            got = [torch.empty_like(n) for _ in range(self.world)]
+            dist.all_gather(got, n, group=self.group)
+            sizes = [int(x.item()) for x in got]
+        sizes = [int(x) for x in sizes]
         mx = max(sizes)
         if mx == 0:
             return backend.empty(0, dtype)
@@ -194,7 +211,7 @@ class TorchComm:
             pad[t.numel():] = 0
         parts = [backend.empty(mx, dtype) for _ in range(self.world)]
         dist.all_gather(parts, pad, group=self.group)
-        out = torch.cat([p[:s] for p, s in zip(parts, sizes)])
+        out = torch.cat([p[:n_] for p, n_ in zip(parts, sizes)])
         backend.sync()
         return out
 
@@ -236,13 +253,23 @@ class ShardedLayer:
 
     # ---- the pipeline --------------------------------------------------------------------------------------
     def par_scan_device(self):
+        import time
         torch, G, be, comm = self.torch, self.world, self.backend, self.comm
         d_s = self.split_depth
+        t_prev = [time.perf_counter()]
+        stages = {}
+
+        def lap(name):  # host-side stage clock (every backend call is complete on return)
+            now = time.perf_counter()
+            stages[name] = stages.get(name, 0.0) + (now - t_prev[0]) * 1e3
+            t_prev[0] = now
         # 2. balanced contiguous Morton ranges from the all-reduced cell histogram; the same reduction
         #    tells whether EVERY rank's ids can carry their box codes and knows all of them
         can_pack, all_known = be.local_can_pack_box()
         hist = np.concatenate([be.local_cell_histogram(d_s).astype(np.int64), [1 if can_pack else 0, 1 if all_known else 0]])
+        lap("cell_hist")
         hist_all = comm.all_reduce_sum(hist, be)
+        lap("allreduce_hist")
         pack = int(hist_all[-2]) == G
         all_known = pack and int(hist_all[-1]) == G
         hist_all = hist_all[:-2]
@@ -250,17 +277,28 @@ class ShardedLayer:
         # 3. entries -> owners (fine), boundary keys -> everyone (coarse)
         counts, keys, ids = be.local_partition_entries(d_s, lut, G, pack)
         n_fine = int(counts[:G].sum())
-        rk = comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be)
-        ri = comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be)
-        ck = comm.all_gather_v(keys[n_fine:n_fine + int(counts[G])], torch.int64, be)
-        ci = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be)
+        lap("partition_entries")
+        cm = comm.all_gather_counts(counts, be)                      # cm[src][dst], cm[src][G] = coarse
+        comm._global_max_hint = int(cm[:, :G].max())
+        recv_counts = cm[:, self.rank]
+        rk = comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be, recv_counts)
+        ri = comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be, recv_counts)
+        comm._global_max_hint = None
+        coarse_sizes = cm[:, G]
+        ck = comm.all_gather_v(keys[n_fine:n_fine + int(counts[G])], torch.int64, be, coarse_sizes)
+        ci = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be, coarse_sizes)
+        lap("exchange_entries")
         # received chunks arrive in rank order and every rank's entries are in id order, so equal index
         # values carry non-decreasing ids (fine and coarse entries never share an index value)
         be.shard_set_entries([(rk, ri), (ck, ci)], pack, all_known)
+        lap("shard_set_entries")
         # 4. local sort + scan (single pass); coarse-coarse pairs only once.  With box codes every pair
         #    is emitted by exactly one entry on exactly one rank, so no duplicate ever crosses the wire.
         raw, unique = be.shard_scan_pairs(d_s, self.rank == 0)
-        unique = comm.all_reduce_max(0 if unique else 1, be) == 0
+        lap("sort_and_scan")
+        # the final step may skip dedup only if EVERY rank suppressed its duplicates at the source
+        # (one tiny all-reduce: a wrong assumption here would corrupt the result, not just slow it)
+        unique = comm.all_reduce_max(0 if (unique and pack and all_known) else 1, be) == 0
         # 5. raw pairs -> owner of the first id, then sort + dedup per id range
         if self.n_global is not None:
             max_id = int(self.n_global) - 1
@@ -268,14 +306,21 @@ class ShardedLayer:
             max_id = max(comm.all_reduce_max(self.max_id_local, be), 0)
         bounds = id_range_bounds(max_id, G)
         pcounts, grouped = be.partition_pairs(raw, bounds)
-        rp = comm.all_to_all_v(grouped, pcounts, torch.int64, be)
+        lap("partition_pairs")
+        pm = comm.all_gather_counts(pcounts, be)
+        comm._global_max_hint = int(pm.max())
+        rp = comm.all_to_all_v(grouped, pcounts, torch.int64, be, pm[:, self.rank])
+        comm._global_max_hint = None
+        lap("exchange_pairs")
         lo = 0 if self.rank == 0 else int(bounds[self.rank - 1])
         hi = max_id if self.rank == G - 1 else int(bounds[self.rank]) - 1
         varying = (_varying_bits(lo, max(hi, lo)) << 32) | _varying_bits(0, max_id)
         out = be.sort_unique_packed(rp, varying, unique)
+        lap("sort_pairs")
         self.last = {"entries_local": int(counts.sum()), "entries_shard": int(rk.numel() + ck.numel()),
                      "coarse": int(ck.numel()), "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
-                     "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique)}
+                     "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique),
+                     "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
         return out
 
     # reference names

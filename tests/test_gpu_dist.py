@@ -41,7 +41,10 @@ class ThreadComm:
     def all_reduce_max(self, value, backend):
         return max(self._exchange(int(value)))
 
-    def all_to_all_v(self, send, send_counts, dtype, backend):
+    def all_gather_counts(self, counts, backend):
+        return np.stack(self._exchange(np.asarray([int(c) for c in counts], dtype=np.int64)))
+
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None):
         import torch
         offs = np.concatenate([[0], np.cumsum([int(c) for c in send_counts])])
         vals = self._exchange([send[int(offs[d]):int(offs[d + 1])].clone() for d in range(self.world)])
@@ -51,7 +54,7 @@ class ThreadComm:
         self.sh.barrier.wait()
         return out
 
-    def all_gather_v(self, t, dtype, backend):
+    def all_gather_v(self, t, dtype, backend, sizes=None):
         import torch
         vals = self._exchange(t.clone())
         out = torch.cat(vals) if sum(v.numel() for v in vals) else backend.empty(0, dtype)
