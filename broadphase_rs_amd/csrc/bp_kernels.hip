@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     }
     __syncthreads();
     const u32 total = s_cursor;
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
+    if (threadIdx.x == 0) {
+        if (dbg & 8) s_base = (u64)blockIdx.x * FUSED_STAGE;  // timing experiment: no shared cursor
+        else s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
+    }
     __syncthreads();
     const u64 base = s_base;
     if (total == 0 || base + total > out_cap) return;  // capacity is checked by the host afterwards

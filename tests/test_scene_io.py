@@ -1,0 +1,77 @@
+"""BR_SCENE reader/writer against the layout of data/src/lib.rs:19-49 and
+the file sizes the reference's own inputs have (the Git-LFS pointers record them)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from broadphase_rs_amd import scenes
+from broadphase_rs_amd.scene_io import Scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# sizes of the reference's input scenes (tests/data/inputs/*.br_scene, from their LFS pointers)
+REFERENCE_INPUT_SIZES = {100: 2844, 300: 8444, 1000: 28044, 3000: 84044, 10000: 280044, 30000: 840044, 100000: 2800044}
+
+
+def test_v1_0_layout_matches_the_reference_input_file_sizes():
+    for n, size in REFERENCE_INPUT_SIZES.items():
+        if n > 10000:
+            assert 44 + 28 * n == size
+            continue
+        sysb, bounds, ids = scenes.gen_boxes(n, seed=0)
+        blob = Scene(system_bounds=sysb, bounds=bounds, ids=ids).assemble(version=(1, 0))
+        assert len(blob) == size == 44 + 28 * n
+        back = Scene.parse(blob)
+        assert back.version == (1, 0) and not back.layer_sorted and len(back.layer_keys) == 0
+        assert np.array_equal(back.bounds, bounds) and np.array_equal(back.ids, ids)
+        assert np.array_equal(back.system_bounds, sysb)
+
+
+def test_v1_2_round_trip_and_exact_bytes():
+    sysb, bounds, ids = scenes.gen_boxes(50, seed=3)
+    s = Scene(system_bounds=sysb, bounds=bounds, ids=ids, layer_min_depth=3,
+              layer_keys=np.array([5, 0x3800000000000003], np.uint64), layer_ids=np.array([7, 9], np.uint32),
+              layer_sorted=True, collisions=np.array([[1, 0], [4, 2]], np.uint32), hits=np.array([3], np.uint32),
+              nearest=(4, 1.5))
+    blob = s.assemble()
+    # header 12 + bounds 24 + (8 + 28 n) + layer (4 + 8 + 12 m + 1) + collisions (8 + 8 p) + hits (8 + 4 h) + Some (1 + 8)
+    assert len(blob) == 12 + 24 + 8 + 28 * 50 + 4 + 8 + 12 * 2 + 1 + 8 + 16 + 8 + 4 + 9
+    assert blob[:12] == b"BR_SCENE\x01\x00\x02\x00"
+    t = Scene.parse(blob)
+    assert t.layer_min_depth == 3 and t.layer_sorted and t.nearest == (4, 1.5)
+    assert t.layer_keys.tolist() == [5, 0x3800000000000003] and t.layer_ids.tolist() == [7, 9]
+    assert t.collisions.tolist() == [[1, 0], [4, 2]] and t.hits.tolist() == [3]
+    assert t.assemble() == blob
+    assert len(Scene.parse(s.assemble(version=(1, 1))).collisions) == 0
+    with pytest.raises(ValueError):
+        Scene.parse(b"NOTSCENE" + blob[8:])
+    with pytest.raises(ValueError):
+        Scene.parse(blob[:8] + b"\x01\x00\x03\x00" + blob[12:])
+
+
+def test_gen_inputs_tool(tmp_path):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_validation_data.py"), "--gen-inputs", str(tmp_path)])
+    for n, size in REFERENCE_INPUT_SIZES.items():
+        p = tmp_path / ("boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % n)
+        assert p.stat().st_size == size
+
+
+@pytest.mark.gpu
+def test_validation_pipeline_files_match_oracle(tmp_path):
+    """gen_validation_data on the GPU path: the three golden files of tests/test_layer.rs"""
+    import oracle
+    sysb, bounds, ids = scenes.gen_boxes(10000, seed=0)
+    inp = tmp_path / "in.br_scene"
+    Scene(system_bounds=sysb, bounds=bounds, ids=ids).save(str(inp), version=(1, 0))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_validation_data.py"), str(inp), str(tmp_path)])
+    ref = oracle.OracleLayer(oracle.INDEX64_3D, 0)
+    ref.extend(sysb, bounds, ids)
+    a = Scene.load(str(tmp_path / "0_layer_unsorted.br_scene"))
+    assert np.array_equal(a.layer_keys, ref.keys) and np.array_equal(a.layer_ids, ref.ids) and not a.layer_sorted
+    ref.sort()
+    b = Scene.load(str(tmp_path / "1_layer_sorted.br_scene"))
+    assert np.array_equal(b.layer_keys, ref.keys) and np.array_equal(b.layer_ids, ref.ids) and b.layer_sorted
+    c = Scene.load(str(tmp_path / "2_layer_collisions.br_scene"))
+    assert np.array_equal(c.collisions, ref.scan())
