@@ -1313,7 +1313,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // tile geometry, selectable at run time for A/B measurements (BP_RS_CONFIG=0..3)
 struct RsConfig { int threads, items; };
-static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {1024, 16}, {1024, 16}};
+static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {1024, 16}, {1024, 16}, {512, 12}, {512, 10}, {768, 8}};
 static int rs_config_id() {
     static int id = -1;
     if (id < 0) {
@@ -1349,6 +1349,9 @@ static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t
         case 4: radix_onesweep_kernel<K, V, 1024, 16, DigitFn, true><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 6: radix_onesweep_kernel<K, V, 512, 12, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 7: radix_onesweep_kernel<K, V, 512, 10, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 8: radix_onesweep_kernel<K, V, 768, 8, DigitFn><<<tiles, 768, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
         default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
     }
     return hipGetLastError();
