@@ -32,7 +32,7 @@ struct DevScalars {
     unsigned int err;              // KERR_* bits below
     unsigned int n_invalid;        // objects outside the system bounds
     unsigned int id_max;           // largest id handed to the last extend (valid or not)
-    unsigned int pad_;
+    unsigned int id_min;           // smallest id handed to the last extend
 };
 enum : unsigned {
     EXT_IDS_DECREASE = 1u,   // some id is smaller than its predecessor in append order
@@ -48,7 +48,7 @@ enum : unsigned {
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
 struct BlockAux {
     unsigned long long key_or, key_and;
-    unsigned int depth_mask, flags, err, n_invalid, id_or, id_and, id_max, pad_;
+    unsigned int depth_mask, flags, err, n_invalid, id_or, id_and, id_max, id_min;
 };
 
 // Per-entry description of its object's cell set, when that set is a box of at most 2 cells per

@@ -106,6 +106,15 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 }
 
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u32 t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
 __device__ __forceinline__ void range_or_and(u32 lo, u32 n, u32& o, u32& a) {
     const u32 hi = lo + n - 1u;
     const u32 x = lo ^ hi;
@@ -122,10 +131,11 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
                                                                   BlockAux* __restrict__ aux, DevScalars* sc) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
     __shared__ u32 s_sum[ENC_THREADS / 64], s_dm[ENC_THREADS / 64], s_fl[ENC_THREADS / 64], s_er[ENC_THREADS / 64],
-        s_inv[ENC_THREADS / 64], s_ior[ENC_THREADS / 64], s_iand[ENC_THREADS / 64], s_imax[ENC_THREADS / 64];
+        s_inv[ENC_THREADS / 64], s_ior[ENC_THREADS / 64], s_iand[ENC_THREADS / 64], s_imax[ENC_THREADS / 64],
+        s_imin[ENC_THREADS / 64];
     __shared__ u64 s_kor[ENC_THREADS / 64], s_kand[ENC_THREADS / 64];
     const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
-    u32 cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0;
+    u32 cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
     u64 kor = 0, kand = ~0ull;
     if (i < n) {
         const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
             else if (id == prev) flags |= EXT_IDS_REPEAT;
         }
         imax = id;
+        imin = id;
         if (c.overflow && c.valid) err |= KERR_COUNT_OVERFLOW;
         if (!c.valid) inv = 1;
         cnt = c.count;
@@ -167,10 +178,11 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
     // workgroup reduction -> one BlockAux + one block sum per workgroup (no atomics)
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const u32 ws = wave_sum_u32(cnt), wd = wave_or_u32(dmask), wf = wave_or_u32(flags), we = wave_or_u32(err),
-              wi = wave_sum_u32(inv), wo = wave_or_u32(ior), wa = wave_and_u32(iand), wm = wave_max_u32(imax);
+              wi = wave_sum_u32(inv), wo = wave_or_u32(ior), wa = wave_and_u32(iand), wm = wave_max_u32(imax),
+              wn = wave_min_u32(imin);
     const u64 wko = wave_or_u64(kor), wka = wave_and_u64(kand);
     if (lane == 0) {
-        s_sum[w] = ws; s_dm[w] = wd; s_fl[w] = wf; s_er[w] = we; s_inv[w] = wi; s_ior[w] = wo; s_iand[w] = wa; s_imax[w] = wm;
+        s_sum[w] = ws; s_dm[w] = wd; s_fl[w] = wf; s_er[w] = we; s_inv[w] = wi; s_ior[w] = wo; s_iand[w] = wa; s_imax[w] = wm; s_imin[w] = wn;
         s_kor[w] = wko; s_kand[w] = wka;
     }
     __syncthreads();
@@ -178,12 +190,13 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
         u64 tot = 0;
         BlockAux b;
         b.key_or = 0; b.key_and = ~0ull; b.depth_mask = 0; b.flags = 0; b.err = 0; b.n_invalid = 0; b.id_or = 0;
-        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.pad_ = 0;
+        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.id_min = 0xFFFFFFFFu;
         for (int k = 0; k < ENC_THREADS / 64; ++k) {
             tot += s_sum[k];
             b.key_or |= s_kor[k]; b.key_and &= s_kand[k]; b.depth_mask |= s_dm[k]; b.flags |= s_fl[k];
             b.err |= s_er[k]; b.n_invalid += s_inv[k]; b.id_or |= s_ior[k]; b.id_and &= s_iand[k];
             b.id_max = s_imax[k] > b.id_max ? s_imax[k] : b.id_max;
+            b.id_min = s_imin[k] < b.id_min ? s_imin[k] : b.id_min;
         }
         block_sums[blockIdx.x] = tot;
         aux[blockIdx.x] = b;
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __res
     __shared__ u64 s_carry;
     __shared__ u64 r_kor[SBS_THREADS / 64], r_kand[SBS_THREADS / 64];
     __shared__ u32 r_dm[SBS_THREADS / 64], r_fl[SBS_THREADS / 64], r_er[SBS_THREADS / 64], r_inv[SBS_THREADS / 64],
-        r_ior[SBS_THREADS / 64], r_iand[SBS_THREADS / 64], r_imax[SBS_THREADS / 64];
+        r_ior[SBS_THREADS / 64], r_iand[SBS_THREADS / 64], r_imax[SBS_THREADS / 64], r_imin[SBS_THREADS / 64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -280,17 +293,19 @@ __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __res
     }
     if (aux) {  // fold the per-workgroup partials of encode_count
         u64 kor = 0, kand = ~0ull;
-        u32 dm = 0, fl = 0, er = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0;
+        u32 dm = 0, fl = 0, er = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
         for (size_t i = threadIdx.x; i < n; i += SBS_THREADS) {
             const BlockAux b = aux[i];
             kor |= b.key_or; kand &= b.key_and; dm |= b.depth_mask; fl |= b.flags; er |= b.err; inv += b.n_invalid;
-            ior |= b.id_or; iand &= b.id_and; imax = b.id_max > imax ? b.id_max : imax;
+            ior |= b.id_or; iand &= b.id_and; imax = b.id_max > imax ? b.id_max : imax; imin = b.id_min < imin ? b.id_min : imin;
         }
         kor = wave_or_u64(kor); kand = wave_and_u64(kand); dm = wave_or_u32(dm); fl = wave_or_u32(fl);
         er = wave_or_u32(er); inv = wave_sum_u32(inv); ior = wave_or_u32(ior); iand = wave_and_u32(iand);
         imax = wave_max_u32(imax);
+        imin = wave_min_u32(imin);
         if (lane == 0) {
             r_imax[w] = imax;
+            r_imin[w] = imin;
             r_kor[w] = kor; r_kand[w] = kand; r_dm[w] = dm; r_fl[w] = fl; r_er[w] = er; r_inv[w] = inv;
             r_ior[w] = ior; r_iand[w] = iand;
         }
@@ -300,6 +315,7 @@ __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __res
                 sc->key_or |= r_kor[k]; sc->key_and &= r_kand[k]; sc->depth_mask |= r_dm[k]; sc->flags |= r_fl[k];
                 sc->err |= r_er[k]; sc->n_invalid += r_inv[k]; sc->id_or |= r_ior[k]; sc->id_and &= r_iand[k];
                 sc->id_max = r_imax[k] > sc->id_max ? r_imax[k] : sc->id_max;
+                sc->id_min = r_imin[k] < sc->id_min ? r_imin[k] : sc->id_min;
             }
         }
     }

@@ -53,7 +53,7 @@ struct bp_layer {
     bool have_ids = false;      // anything appended since the last clear
     bool order_ok = true;       // equal keys are already id-ascending in current order
     bool ids_distinct = true;   // no id occurs on two objects (skip rule cannot fire)
-    uint32_t max_id = 0;
+    uint32_t max_id = 0, min_id = 0xFFFFFFFFu;   // id range of everything appended since the last clear
     uint64_t key_or = 0, key_and = ~0ull;
     uint32_t id_or = 0, id_and = 0xFFFFFFFFu;
     uint32_t depth_mask = 0;
@@ -222,6 +222,7 @@ int sc_reset(bp_layer* L) {  // neutral elements for every reduction
     std::memset(h, 0, sizeof(DevScalars));
     h->key_and = ~0ull;
     h->id_and = 0xFFFFFFFFu;
+    h->id_min = 0xFFFFFFFFu;
     HIP_TRY(L, hipMemcpyAsync(L->d_sc.p, h, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
     return BP_OK;
 }
@@ -251,6 +252,7 @@ void reset_tree_facts(bp_layer* L) {
     L->order_ok = true;
     L->ids_distinct = true;
     L->max_id = 0;
+    L->min_id = 0xFFFFFFFFu;
     L->key_or = 0; L->key_and = ~0ull;
     L->id_or = 0; L->id_and = 0xFFFFFFFFu;
     L->depth_mask = 0;
@@ -306,6 +308,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     if (sc.flags & EXT_BOX_UNKNOWN) L->box_all_known = false;
     L->have_ids = true;
     L->max_id = std::max(L->max_id, sc.id_max);
+    L->min_id = std::min(L->min_id, sc.id_min);
     if (add == 0) return BP_OK;
     BP_TRY(ensure_tree_capacity(L, L->m + add));
     {
@@ -342,6 +345,7 @@ int absorb_raw_entries(bp_layer* L, const uint64_t* d_keys, const uint32_t* d_id
     L->ids_distinct = false;
     L->have_ids = true;
     L->max_id = 0xFFFFFFFFu;
+    L->min_id = 0;
     return BP_OK;
 }
 
@@ -401,7 +405,8 @@ int sort_tree(bp_layer* L) {
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
             BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
-            const bool ride = box_can_ride(L);
+            // the finish kernel orders equal keys by id itself, so the codes may ride without order_ok
+            const bool ride = L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
             BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, plan.n_passes)));
             BP_TRY(sc_reset(L));
             int res = 0;
@@ -827,19 +832,24 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
             L->box_all_known = false;
         }
         BP_TRY(sync_stream(L));
-        // facts: the union keeps whatever both sides can still prove
+        // facts: the union keeps whatever both sides can still prove.  The crate's intended pattern
+        // -- a static layer merged into each frame's dynamic layer (src/layer.rs:123-126) -- has
+        // disjoint id ranges, which keeps ids provably distinct and the fast kernels selected.
         const bool was_empty = (L->m == 0);
         L->key_or |= other->key_or; L->key_and &= other->key_and;
         L->id_or |= other->id_or; L->id_and &= other->id_and;
         L->depth_mask |= other->depth_mask;
         if (was_empty) {
-            L->order_ok = other->order_ok; L->ids_distinct = other->ids_distinct; L->max_id = other->max_id;
-            L->have_ids = other->have_ids;
+            L->order_ok = other->order_ok; L->ids_distinct = other->ids_distinct;
+            L->max_id = other->max_id; L->min_id = other->min_id; L->have_ids = other->have_ids;
         } else {
-            L->order_ok = false;
-            L->ids_distinct = false;
+            const bool other_after = L->have_ids && other->have_ids && L->max_id < other->min_id;
+            const bool other_before = L->have_ids && other->have_ids && other->max_id < L->min_id;
+            L->ids_distinct = L->ids_distinct && other->ids_distinct && (other_after || other_before);
+            L->order_ok = L->order_ok && other->order_ok && other_after;  // appended ids must not go down
             L->max_id = std::max(L->max_id, other->max_id);
-            L->have_ids = true;
+            L->min_id = std::min(L->min_id, other->min_id);
+            L->have_ids = L->have_ids || other->have_ids;
         }
         L->m += m;
     }
@@ -1174,7 +1184,7 @@ int bp_layer_clone(const bp_layer_t* src, bp_layer_t** out) {
     L->box_valid = src->box_valid && (src->m == 0 || src->box[src->cur].p != nullptr);
     L->box_all_known = src->box_all_known;
     L->m = src->m; L->sorted = src->sorted;
-    L->have_ids = src->have_ids; L->order_ok = src->order_ok; L->ids_distinct = src->ids_distinct; L->max_id = src->max_id;
+    L->have_ids = src->have_ids; L->order_ok = src->order_ok; L->ids_distinct = src->ids_distinct; L->max_id = src->max_id; L->min_id = src->min_id;
     L->key_or = src->key_or; L->key_and = src->key_and; L->id_or = src->id_or; L->id_and = src->id_and;
     L->depth_mask = src->depth_mask;
     L->stats.entries = L->m;

@@ -174,7 +174,15 @@ def test_merge_clone_eq_and_clear():
     assert dyn_g.min_depth == 0 and dyn_r.min_depth == 0 and not dyn_g.sorted
     assert snapshot != dyn_g
     assert_tree_equal(dyn_g, dyn_r, "merge")
+    # disjoint id ranges: ids stay provably distinct across the merge, so the fast kernels stay selected
+    assert dyn_g.stats()["flags"] & 2
     assert_pairs_equal(dyn_g.par_scan(), dyn_r.scan(), "scan after merge")
+    assert dyn_g.stats()["raw_pairs"] == dyn_g.stats()["pairs"]      # duplicates suppressed at the source
+    # overlapping id ranges (the same layer merged twice): nothing can be assumed, result still exact
+    dyn_g.merge(static_g); dyn_r.merge(static_r)
+    assert dyn_g.stats()["flags"] & 2 == 0
+    assert_tree_equal(dyn_g, dyn_r, "merge of overlapping ids")
+    assert_pairs_equal(dyn_g.par_scan(), dyn_r.scan(), "scan after merging overlapping ids")
     # merging a sorted layer into an empty sorted layer still clears the sorted flag (layer.rs:137)
     e_g, e_r = both(2, 0)
     e_g.merge(static_g); e_r.merge(static_r)
