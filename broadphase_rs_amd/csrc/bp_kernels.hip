@@ -473,7 +473,7 @@ template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool
 __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
-                                                                    u64* status, u32* tile_counter, DevScalars* sc, int dbg,
+                                                                    u64* status, u32* tile_counter, DevScalars* sc,
                                                                     const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out) {
     constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
     static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     __shared__ u32 s_tile;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_tile = (dbg & 2) ? blockIdx.x : atomicAdd(tile_counter, 1u);  // ticket: tile t only ever waits on tiles < t
+    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);  // ticket: tile t only ever waits on tiles < t
 #pragma unroll
     for (int j = tid; j < RS_WAVES * RS_BINS; j += RS_THREADS) {
         (&s_cnt[0][0])[j] = 0;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     if (tid < RS_BINS) {
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) total += s_cnt[ww][tid];
-        if (tile != 0 && !(dbg & 1)) st_store(my_status, ST_FLAG_AGG | (u64)total);
+        if (tile != 0) st_store(my_status, ST_FLAG_AGG | (u64)total);
     }
     u32 tile_total;
     const u32 tile_off = block_excl_scan_u32<RS_THREADS>(total, s_ws, tile_total);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     // ---- 6. look-back: global base of every digit = bin_base + sum of the predecessors' counts ---
     if (tid < RS_BINS) {
         u64 excl = 0;
-        if (tile == 0 || (dbg & 1)) {
+        if (tile == 0) {
             st_store(my_status, ST_FLAG_PRE | (u64)total);
         } else {
             // LB_BATCH independent status loads per step (one fabric round trip per step instead of
@@ -1002,23 +1002,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
         }
     }
     u32 mine = 0;
-    const int dbg = p.general;  // timing experiments only (general is always 0 on this path)
-    if (active && (dbg & 3)) {
-        u32 acc = 0;
-        walk_ancestors<KIND>(p.keys, i, key, (dbg & 2) ? (p.depth_mask & (1u << key_depth<KIND>(key))) : p.depth_mask,
-                             [&](u32 lo, u32 hi, u32) { acc += hi - lo; });
-        if (acc == 0xFFFFFFFFu) s_pairs[0] = acc;
-    } else if (active && (dbg & 4)) {
-        u32 acc = 0;
-        walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
-            for_run_desc(lo, hi, [&](u32 j) {
-                const u32 idj = p.ids[j];
-                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
-                acc += idj;
-            });
-        });
-        if (acc == 0xFFFFFFFFu) s_pairs[0] = acc;
-    } else if (active) {
+    if (active) {
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
             for_run_desc(lo, hi, [&](u32 j) {
                 const u32 idj = p.ids[j];
@@ -1031,10 +1015,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     }
     __syncthreads();
     const u32 total = s_cursor;
-    if (threadIdx.x == 0) {
-        if (dbg & 8) s_base = (u64)blockIdx.x * FUSED_STAGE;  // timing experiment: no shared cursor
-        else s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
-    }
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
     __syncthreads();
     const u64 base = s_base;
     if (total == 0 || base + total > out_cap) return;  // capacity is checked by the host afterwards
@@ -1356,19 +1337,16 @@ template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr) {
     const unsigned tiles = (unsigned)rs_num_tiles(n);
-    static int dbg_env = -1;
-    if (dbg_env < 0) { const char* e = getenv("BP_RS_DEBUG"); dbg_env = e ? atoi(e) : 0; }
-    const int dbg = StageBytes<V>::value == 0 ? dbg_env : 0;  // timing experiments: keys-only passes only
     switch (rs_config_id()) {
-        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 3: radix_onesweep_kernel<K, V, 512, 16, DigitFn, true><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 4: radix_onesweep_kernel<K, V, 1024, 16, DigitFn, true><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 6: radix_onesweep_kernel<K, V, 512, 12, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 7: radix_onesweep_kernel<K, V, 512, 10, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        case 8: radix_onesweep_kernel<K, V, 768, 8, DigitFn><<<tiles, 768, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
-        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, dbg, bi, bo); break;
+        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 3: radix_onesweep_kernel<K, V, 512, 16, DigitFn, true><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 4: radix_onesweep_kernel<K, V, 1024, 16, DigitFn, true><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 6: radix_onesweep_kernel<K, V, 512, 12, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 7: radix_onesweep_kernel<K, V, 512, 10, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        case 8: radix_onesweep_kernel<K, V, 768, 8, DigitFn><<<tiles, 768, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
+        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
     }
     return hipGetLastError();
 }

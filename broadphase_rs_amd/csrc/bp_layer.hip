@@ -613,12 +613,10 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.coarse_depth = coarse_depth;
     p.emit_coarse = emit_coarse;
     p.general = 0;
-    { const char* e = getenv("BP_SCAN_DEBUG"); if (e) p.general = atoi(e); }  // timing experiments only
     p.skip = nullptr;
     p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
-    if (p.general & 8) cap = std::max<size_t>(cap, (scan_blocks(L->m) + 1) * 3072);  // timing experiment
     for (int attempt = 0; attempt < 3; ++attempt) {
         BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
         cap = L->pairs[0].cap / sizeof(uint64_t);
