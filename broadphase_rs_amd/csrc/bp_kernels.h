@@ -140,12 +140,19 @@ struct ScanParams {
     const uint8_t* box;     // [m] per-entry cell-box code (BOX_*), or nullptr: emit every raw pair
                             // non-null: a pair is emitted once, from the minimal-key cell of the
                             // deeper object that lies in any cell of the other (exact dedup at source)
+    const float* filt_bounds;  // built-in narrow-phase predicate (fused scan only): rows of 2*dim f32 indexed BY ID,
+    uint32_t filt_rows;        // keep (id, id_) iff the inclusive boxes overlap (src/geom.rs:112-119); nullptr: keep all
 };
 hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream);
 hipError_t launch_scan_count(int kind, ScanParams p, uint32_t* counts, unsigned long long* block_sums,
                              hipStream_t stream);
 hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, const unsigned long long* block_offs,
                             uint64_t* pairs_out, hipStream_t stream);
+
+// keep the packed pairs whose boxes (rows of `bounds` indexed by id) overlap; arbitrary output order;
+// sc->total (zeroed by the host) = number kept
+hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, uint64_t* out, DevScalars* sc,
+                                    hipStream_t stream);
 
 // single-pass scan for the paths that sort the raw stream afterwards: pairs in arbitrary order,
 // sc->total (zeroed by the host) = number of pairs produced; if it exceeds out_cap nothing past

@@ -979,9 +979,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, c
 // is flushed with coalesced stores.  A workgroup whose pairs do not fit the stage reserves first
 // and walks a second time writing straight to HBM (rare: deep power-law stacks).
 constexpr u32 FUSED_STAGE = 3072;  // pairs per workgroup staged in LDS (24 KB)
-template <int KIND>
+// Bounds::overlaps (src/geom.rs:112-119): inclusive; written with negated comparisons, so NaN overlaps
+template <int DIM> __device__ __forceinline__ bool boxes_overlap(const float* __restrict__ a, const float* __restrict__ b) {
+    bool ov = true;
+#pragma unroll
+    for (int ax = 0; ax < DIM; ++ax) {
+        if (a[ax] > b[DIM + ax] || a[DIM + ax] < b[ax]) ov = false;
+    }
+    return ov;
+}
+
+template <int KIND, bool FILT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, u64* __restrict__ out, u64 out_cap,
                                                                   DevScalars* sc) {
+    constexpr int FDIM = (int)KT<KIND>::DIM;
     __shared__ u64 s_pairs[FUSED_STAGE];
     __shared__ u32 s_cursor;
     __shared__ u64 s_base;
@@ -1001,12 +1012,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
             if (p.box) bx.init(key, p.box[i]);
         }
     }
+    float mybox[2 * FDIM];
+    if (FILT && active) {
+#pragma unroll
+        for (int q = 0; q < 2 * FDIM; ++q) mybox[q] = p.filt_bounds[(size_t)(u32)(hi_id >> 32) * (2 * FDIM) + q];
+    }
     u32 mine = 0;
     if (active) {
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
             for_run_desc(lo, hi, [&](u32 j) {
                 const u32 idj = p.ids[j];
                 if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
                 if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)idj;
                 ++mine;
@@ -1030,8 +1047,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
             for_run_desc(lo, hi, [&](u32 j) {
                 if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                const u32 idj = p.ids[j];
+                if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
-                out[base + slot] = hi_id | (u64)p.ids[j];
+                out[base + slot] = hi_id | (u64)idj;
             });
         });
     }
@@ -1214,6 +1233,33 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
         if (PACKED) box_out[dst] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
     }
     if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds,
+                                                                u64* __restrict__ out, DevScalars* sc) {
+    constexpr int ITEMS = 4;
+    __shared__ u64 s_keep[256 * ITEMS];
+    __shared__ u32 s_cursor;
+    __shared__ u64 s_base;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 256 * ITEMS;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < n) {
+            const u64 v = in[i];
+            const float* a = bounds + (size_t)(u32)(v >> 32) * (2 * DIM);
+            const float* b = bounds + (size_t)(u32)v * (2 * DIM);
+            if (boxes_overlap<DIM>(a, b)) s_keep[atomicAdd(&s_cursor, 1u)] = v;
+        }
+    }
+    __syncthreads();
+    const u32 total = s_cursor;
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&sc->total, (u64)total) : 0ull;
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < total; k += 256) out[s_base + k] = s_keep[k];
 }
 
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2* __restrict__ in, size_t n, u64* __restrict__ out) {
@@ -1499,7 +1545,11 @@ hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, cons
 hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t out_cap, DevScalars* sc, hipStream_t stream) {
     if (p.m == 0) return hipSuccess;
     const unsigned g = (unsigned)scan_blocks(p.m);
-    BP_DISPATCH_KIND(kind, (scan_fused_kernel<K><<<g, SCAN_THREADS, 0, stream>>>(p, (u64*)pairs_out, (u64)out_cap, sc)));
+    if (p.filt_bounds) {
+        BP_DISPATCH_KIND(kind, (scan_fused_kernel<K, true><<<g, SCAN_THREADS, 0, stream>>>(p, (u64*)pairs_out, (u64)out_cap, sc)));
+    } else {
+        BP_DISPATCH_KIND(kind, (scan_fused_kernel<K, false><<<g, SCAN_THREADS, 0, stream>>>(p, (u64*)pairs_out, (u64)out_cap, sc)));
+    }
     return hipGetLastError();
 }
 
@@ -1534,6 +1584,15 @@ hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* i
     else
         tree_segment_finish_kernel<false><<<g, SEG_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, m, seg_shift, (u64*)keys_out,
                                                                           ids_out, box_out, sc);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, uint64_t* out, DevScalars* sc,
+                                    hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)((n + 1023) / 1024);
+    if (dim == 3) filter_pairs_aabb_kernel<3><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, (u64*)out, sc);
+    else filter_pairs_aabb_kernel<2><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, (u64*)out, sc);
     return hipGetLastError();
 }
 

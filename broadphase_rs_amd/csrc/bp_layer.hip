@@ -465,6 +465,8 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
     p.emit_coarse = emit_coarse;
     p.general = L->ids_distinct ? 0 : 1;
     p.skip = nullptr;
+    p.filt_bounds = nullptr;
+    p.filt_rows = 0;
     p.box = (source_dedup && !p.general && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
     if (p.general) {
@@ -599,7 +601,8 @@ int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_un
 }
 
 // raw pairs in ARBITRARY order (they are sorted afterwards): one walk per entry, workgroup-staged
-int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup) {
+int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup, const float* filt_bounds = nullptr,
+                      uint32_t filt_rows = 0) {
     BP_TRY(sort_tree(L));
     L->n_raw = 0;
     L->raw_is_unique = false;
@@ -614,6 +617,8 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.emit_coarse = emit_coarse;
     p.general = 0;
     p.skip = nullptr;
+    p.filt_bounds = filt_bounds;
+    p.filt_rows = filt_rows;
     p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
@@ -939,6 +944,63 @@ int bp_layer_scan_filtered(bp_layer_t* L, bp_filter_fn filter, void* user, const
 }
 int bp_layer_par_scan_filtered(bp_layer_t* L, bp_filter_fn filter, void* user, const uint32_t** pairs, size_t* n_pairs) {
     return bp_layer_scan_filtered(L, filter, user, pairs, n_pairs);
+}
+
+// scan_filtered with the built-in AABB narrow-phase predicate; result in L->out_pairs
+static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_rows) {
+    if (!bounds) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: null bounds");
+    if (L->m && (!L->have_ids || L->max_id == 0xFFFFFFFFu || (size_t)L->max_id >= n_rows))
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: bounds need one row per id (ids must be bounded by n_rows)");
+    const KindInfo ki = kind_info(L->kind);
+    const float* d_bounds = bounds;
+    if (!is_device_ptr(bounds)) {
+        const size_t bytes = n_rows * 2 * ki.dim * sizeof(float);
+        BP_TRY(ensure_dev(L, L->in_bounds, bytes));
+        HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, bounds, bytes, hipMemcpyHostToDevice, L->stream));
+        d_bounds = (const float*)L->in_bounds.p;
+    }
+    if (L->ids_distinct) {  // predicate evaluated inside the single-pass scan, before anything is sorted
+        BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
+        if (L->n_raw == 0) BP_TRY(sync_stream(L));
+        return BP_OK;
+    }
+    // literal path: raw stream (skip rule applied), then the predicate as a compaction pass
+    BP_TRY(scan_raw_device(L, 0, 1));
+    const size_t n = L->n_raw;
+    size_t kept = 0;
+    if (n) {
+        BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+        BP_TRY(sc_reset(L));
+        {
+            ProfScope ps(L, BP_K_MISC);
+            HIP_TRY(L, launch_filter_pairs_aabb((int)ki.dim, (const uint64_t*)L->pairs[0].p, n, d_bounds, (uint64_t*)L->pairs[1].p,
+                                                (DevScalars*)L->d_sc.p, L->stream));
+        }
+        DevScalars sc;
+        BP_TRY(sc_fetch(L, &sc));
+        kept = (size_t)sc.total;
+    }
+    L->n_raw = kept;
+    BP_TRY(sort_unique_pairs_in(L, (uint64_t*)L->pairs[1].p, kept, (((unsigned long long)(L->id_or ^ L->id_and)) << 32) | (L->id_or ^ L->id_and), false));
+    if (kept == 0) BP_TRY(sync_stream(L));
+    return BP_OK;
+}
+
+int bp_layer_scan_filtered_aabb_device(bp_layer_t* L, const float* bounds_by_id, size_t n_rows, const uint32_t** d_pairs, size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_filtered_aabb_impl(L, bounds_by_id, n_rows));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_scan_filtered_aabb(bp_layer_t* L, const float* bounds_by_id, size_t n_rows, const uint32_t** pairs, size_t* n_pairs) {
+    if (!L || !pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_filtered_aabb_impl(L, bounds_by_id, n_rows));
+    return pairs_to_host(L, pairs, n_pairs);
 }
 
 int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in, size_t n, const uint32_t** d_pairs,

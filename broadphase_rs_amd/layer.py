@@ -67,7 +67,7 @@ EXPORTS = [
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
-    "bp_layer_sort_packed_device",
+    "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
 ]
 
 
@@ -164,6 +164,8 @@ def load_library():
                                                            C.c_int, u64p, C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_scan_shard_pairs_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
     L.bp_layer_sort_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
+    L.bp_layer_scan_filtered_aabb.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
+    L.bp_layer_scan_filtered_aabb_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_partition_pairs_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_uint32, u64p, C.POINTER(vp)]
     L.bp_layer_sort_unique_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
@@ -350,6 +352,28 @@ class Layer:
 
     def par_scan_filtered(self, filt):  # src/layer.rs:493-520
         return self._filtered("bp_layer_par_scan_filtered", filt)
+
+    def _bounds_arg(self, bounds_by_id):
+        dim = self.index.dim
+        if _is_device_tensor(bounds_by_id):
+            if bounds_by_id.element_size() != 4 or not bounds_by_id.is_contiguous():
+                raise ValueError("bounds must be contiguous f32")
+            return bounds_by_id.data_ptr(), int(bounds_by_id.numel()) // (2 * dim), bounds_by_id
+        b = np.ascontiguousarray(np.asarray(bounds_by_id, dtype=np.float32).reshape(-1, 2 * dim))
+        return b.ctypes.data, len(b), b
+
+    def scan_filtered_aabb(self, bounds_by_id):
+        """scan_filtered(|a, b| bounds[a].overlaps(bounds[b])) with the predicate evaluated on the device"""
+        ptr, rows, keep = self._bounds_arg(bounds_by_id)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_filtered_aabb(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def scan_filtered_aabb_device(self, bounds_by_id):
+        ptr, rows, keep = self._bounds_arg(bounds_by_id)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_filtered_aabb_device(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self)
 
     def iter(self):  # src/layer.rs:79-81
         keys, ids = self.tree()

@@ -103,6 +103,17 @@ int bp_layer_scan_filtered(bp_layer_t *layer, bp_filter_fn filter, void *user, c
 int bp_layer_par_scan_filtered(bp_layer_t *layer, bp_filter_fn filter, void *user, const uint32_t **pairs,
                                size_t *n_pairs);
 
+/* scan_filtered with the narrow-phase box test as a built-in DEVICE predicate (SURVEY.md 8(f) #3;
+ * the example runs its narrow phase on the host over the candidate list, examples/main.rs:459-479):
+ * same result as scan_filtered(|id, id_| bounds[id].overlaps(bounds[id_])) with Bounds::overlaps
+ * of src/geom.rs:112-119 (inclusive).  bounds_by_id: n_rows rows of 2*dim f32 (min then max), row r
+ * = the box of object id r (host or device memory, detected); every id in the layer must be
+ * < n_rows.  The predicate runs inside the scan, before any pair is sorted. */
+int bp_layer_scan_filtered_aabb(bp_layer_t *layer, const float *bounds_by_id, size_t n_rows, const uint32_t **pairs,
+                                size_t *n_pairs);
+int bp_layer_scan_filtered_aabb_device(bp_layer_t *layer, const float *bounds_by_id, size_t n_rows,
+                                       const uint32_t **d_pairs, size_t *n_pairs);
+
 /* Raw output of scan_impl (src/layer.rs:550-573) before sort+dedup, in emission order; used by
  * parity tests and by scan_filtered.  Host-visible, interleaved (id, id_). */
 int bp_layer_scan_raw(bp_layer_t *layer, const uint32_t **pairs, size_t *n_raw);

@@ -337,3 +337,33 @@ def test_powerlaw_200k_overflows_stage_and_segments():
     assert_pairs_equal(got, exp, "powerlaw scan")
     st = gpu.stats()
     assert st["raw_pairs"] == len(exp)                      # still exactly unique at the source
+
+
+def _aabb_overlap(bounds, pairs, dim):
+    a, b = bounds[pairs[:, 0]], bounds[pairs[:, 1]]
+    keep = np.ones(len(pairs), dtype=bool)
+    for ax in range(dim):
+        keep &= ~((a[:, ax] > b[:, dim + ax]) | (a[:, dim + ax] < b[:, ax]))   # geom.rs:112-119
+    return keep
+
+
+@pytest.mark.parametrize("kind,n", [(2, 50000), (0, 20000)])
+def test_builtin_aabb_predicate_equals_host_filter(kind, n):
+    """scan_filtered with the narrow-phase box test on the device == filtering the reference list"""
+    sysb, bounds, ids = make_scene(kind, n, seed=17)
+    dim = KINDS[kind].dim
+    gpu, ref = both(kind, 4 if kind == 0 else 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    full = ref.scan()
+    exp = full[_aabb_overlap(bounds, full, dim)]
+    assert 0 < len(exp) < len(full) // 2
+    assert_pairs_equal(gpu.scan_filtered_aabb(bounds), exp, "device AABB predicate (fused scan)")
+    # same through the literal path (ids that cannot be proven distinct): shuffled append order, repeated extend
+    perm = np.random.default_rng(3).permutation(n)
+    gpu2, ref2 = both(kind, 4 if kind == 0 else 0)
+    gpu2.extend(sysb, bounds[perm], ids[perm]); ref2.extend(sysb, bounds[perm], ids[perm])
+    assert gpu2.stats()["flags"] & 2 == 0
+    full2 = ref2.scan()
+    assert_pairs_equal(gpu2.scan_filtered_aabb(bounds), full2[_aabb_overlap(bounds, full2, dim)], "device AABB predicate (literal path)")
+    with pytest.raises(bp.BroadphaseError):
+        gpu.scan_filtered_aabb(bounds[: n // 2])          # not one row per id
