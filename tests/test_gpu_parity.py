@@ -367,3 +367,20 @@ def test_builtin_aabb_predicate_equals_host_filter(kind, n):
     assert_pairs_equal(gpu2.scan_filtered_aabb(bounds), full2[_aabb_overlap(bounds, full2, dim)], "device AABB predicate (literal path)")
     with pytest.raises(bp.BroadphaseError):
         gpu.scan_filtered_aabb(bounds[: n // 2])          # not one row per id
+
+
+def test_large_ids_cannot_carry_box_codes_and_still_match():
+    # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
+    # source after the sort; the full pair sort + dedup must produce the identical list
+    sysb, bounds, ids = scenes.gen_boxes(40000, seed=23)
+    big = (ids.astype(np.uint64) * 53687 + 3_000_000_000).astype(np.uint32)      # strictly increasing, up to ~5.1e9 mod 2^32
+    big = np.sort(np.unique(big))[: len(ids)]
+    assert len(big) == len(ids) and big.max() >= (1 << 27)
+    gpu, ref = both(2)
+    gpu.extend(sysb, bounds, big); ref.extend(sysb, bounds, big)
+    gpu.par_sort(); ref.sort()
+    assert_tree_equal(gpu, ref, "sort with ids >= 2^27")
+    exp = ref.scan()
+    assert_pairs_equal(gpu.par_scan(), exp, "scan with ids >= 2^27")
+    st = gpu.stats()
+    assert st["flags"] == 3 and st["raw_pairs"] > st["pairs"] == len(exp)      # raw stream had duplicates: dedup ran
