@@ -45,6 +45,7 @@ struct bp_layer {
     DevBuf box[2];               // per-entry BOX_* code, aligned with keys/ids while box_valid
     bool box_valid = true;       // box[cur] describes the entries in their current order
     bool box_all_known = true;   // no BOX_UNKNOWN code present
+    bool ids_packed = false;     // ids[cur] still carry box codes in bits 27..31 (bp_layer_commit_entries)
     int cur = 0;
     size_t m = 0;
     bool sorted = true;
@@ -258,6 +259,7 @@ void reset_tree_facts(bp_layer* L) {
     L->depth_mask = 0;
     L->box_valid = true;
     L->box_all_known = true;
+    L->ids_packed = false;
 }
 
 uint64_t* cur_keys(bp_layer* L) { return (uint64_t*)L->keys[L->cur].p; }
@@ -267,6 +269,19 @@ int ensure_tree_capacity(bp_layer* L, size_t entries) {
     BP_TRY(ensure_dev(L, L->keys[L->cur], entries * sizeof(uint64_t), L->m * sizeof(uint64_t)));
     BP_TRY(ensure_dev(L, L->ids[L->cur], entries * sizeof(uint32_t), L->m * sizeof(uint32_t)));
     BP_TRY(ensure_dev(L, L->box[L->cur], entries, L->m));
+    return BP_OK;
+}
+
+// ids committed with their box codes still packed are split before anything but the sort reads them
+int ensure_unpacked(bp_layer* L) {
+    if (!L->ids_packed) return BP_OK;
+    if (L->m) {
+        BP_TRY(ensure_dev(L, L->box[L->cur], L->m));
+        HIP_TRY(L, launch_split_box(cur_ids(L), (uint8_t*)L->box[L->cur].p, L->m, L->stream));
+        BP_TRY(sync_stream(L));
+    }
+    L->ids_packed = false;
+    L->box_valid = true;
     return BP_OK;
 }
 
@@ -382,7 +397,7 @@ int sort_tree_full(bp_layer* L, bool payload_already_packed) {
 }
 
 int sort_tree(bp_layer* L) {
-    if (L->sorted) return BP_OK;  // src/layer.rs:148, 161
+    if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
     static const bool no_finish = getenv("BP_NO_TREE_FINISH") != nullptr;  // A/B switch for measurements
     L->stats.tree_sort_passes = 0;
     if (L->m > 1) {
@@ -406,7 +421,8 @@ int sort_tree(bp_layer* L) {
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
             BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
             // the finish kernel orders equal keys by id itself, so the codes may ride without order_ok
-            const bool ride = L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
+            const bool packed_in = L->ids_packed;  // already packed by the sender (bp_layer_commit_entries)
+            const bool ride = packed_in || (L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0);
             BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, plan.n_passes)));
             BP_TRY(sc_reset(L));
             int res = 0;
@@ -415,7 +431,7 @@ int sort_tree(bp_layer* L) {
             // first pass packs the box codes into the payload; the finish kernel splits them off again
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
-                                  ride ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr));
+                                  (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr));
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             {
@@ -437,10 +453,15 @@ int sort_tree(bp_layer* L) {
                 L->cur = dst;
                 L->box_valid = ride;
             }
+            L->ids_packed = false;
             done = true;
         }
-        if (!done) BP_TRY(sort_tree_full(L, false));
+        if (!done) {
+            BP_TRY(sort_tree_full(L, L->ids_packed));
+            L->ids_packed = false;
+        }
     }
+    BP_TRY(ensure_unpacked(L));
     L->sorted = true;
     L->order_ok = true;  // a (key, id)-sorted array satisfies the stable-sort precondition again
     return BP_OK;
@@ -797,6 +818,7 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     DeviceGuard g(L->device);
     const bool dk = is_device_ptr(keys), di = is_device_ptr(ids);
     if (dk != di) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_append_entries: keys and ids must live in the same memory space");
+    BP_TRY(ensure_unpacked(L));
     BP_TRY(ensure_tree_capacity(L, L->m + m));
     const hipMemcpyKind kind = dk ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, keys, m * sizeof(uint64_t), kind, L->stream));
@@ -815,6 +837,8 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
     if (L->kind != other->kind) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_merge: index kinds differ");
     if (L->device != other->device) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_merge: layers live on different devices");
     DeviceGuard g(L->device);
+    BP_TRY(ensure_unpacked(L));
+    BP_TRY(ensure_unpacked(const_cast<bp_layer*>(other)));
     if (other->min_depth < L->min_depth) {  // src/layer.rs:131-134 (warn! + lower)
         fprintf(stderr, "[broadphase_amd] warning: merging layer of lesser min_depth (lhs: %u, rhs: %u)\n", L->min_depth,
                 other->min_depth);
@@ -1048,6 +1072,56 @@ int bp_layer_can_pack_box(const bp_layer_t* L, int* can) {
     return BP_OK;
 }
 
+int bp_layer_get_facts(const bp_layer_t* L, bp_facts* out) {
+    if (!L || !out) return BP_ERR_INVALID_ARG;
+    out->key_or = L->key_or; out->key_and = L->key_and;
+    out->id_or = L->id_or; out->id_and = L->id_and;
+    out->id_min = L->min_id; out->id_max = L->max_id;
+    out->depth_mask = L->depth_mask;
+    out->flags = (L->order_ok ? BP_FACT_ORDER_OK : 0u) | (L->ids_distinct ? BP_FACT_IDS_DISTINCT : 0u) |
+                 (box_can_ride(L) ? BP_FACT_IDS_CARRY_BOX : 0u) | (L->box_all_known ? BP_FACT_BOX_ALL_KNOWN : 0u);
+    return BP_OK;
+}
+
+int bp_layer_begin_entries(bp_layer_t* L, size_t m, uint64_t** d_keys, uint32_t** d_ids) {
+    if (!L || !d_keys || !d_ids) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_begin_entries: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(bp_layer_clear(L));
+    BP_TRY(ensure_tree_capacity(L, std::max<size_t>(m, 1)));
+    *d_keys = cur_keys(L);
+    *d_ids = cur_ids(L);
+    return BP_OK;
+}
+
+int bp_layer_commit_entries(bp_layer_t* L, size_t m, const bp_facts* f) {
+    if (!L || !f) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: null argument");
+    if (L->m != 0) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: call bp_layer_begin_entries first");
+    if (m * sizeof(uint64_t) > L->keys[L->cur].cap) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: more entries than begun");
+    if (m == 0) return BP_OK;
+    L->m = m;
+    L->sorted = false;
+    L->stats.entries = m;
+    L->key_or = f->key_or; L->key_and = f->key_and;
+    L->id_or = f->id_or; L->id_and = f->id_and;
+    L->depth_mask = f->depth_mask;
+    L->min_id = f->id_min; L->max_id = f->id_max;
+    L->have_ids = true;
+    L->order_ok = (f->flags & BP_FACT_ORDER_OK) != 0;
+    L->ids_distinct = (f->flags & BP_FACT_IDS_DISTINCT) != 0;
+    if (f->flags & BP_FACT_IDS_CARRY_BOX) {
+        L->ids_packed = true;
+        L->box_valid = false;  // the codes are inside the ids until the sort splits them off
+        L->box_all_known = (f->flags & BP_FACT_BOX_ALL_KNOWN) != 0;
+    } else {
+        DeviceGuard g(L->device);
+        HIP_TRY(L, hipMemsetAsync(L->box[L->cur].p, (int)BOX_UNKNOWN, m, L->stream));
+        BP_TRY(sync_stream(L));
+        L->box_valid = true;
+        L->box_all_known = false;
+    }
+    return BP_OK;
+}
+
 int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist, size_t n_cells) {
     if (!L || !hist) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_cell_histogram: null argument");
     const KindInfo ki = kind_info(L->kind);
@@ -1084,6 +1158,7 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: bad split_depth / n_cells / n_dest");
     if (pack_box && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
     DeviceGuard g(L->device);
+    BP_TRY(ensure_unpacked(L));
     const int other = L->cur ^ 1;
     for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = 0;
     BP_TRY(ensure_dev(L, L->keys[other], std::max<size_t>(L->m, 1) * sizeof(uint64_t)));
@@ -1192,6 +1267,7 @@ int bp_layer_sort_unique_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t
 
 int bp_layer_tree_device(bp_layer_t* L, const uint64_t** d_keys, const uint32_t** d_ids, size_t* m, int* sorted) {
     if (!L) return BP_ERR_INVALID_ARG;
+    { DeviceGuard g(L->device); BP_TRY(ensure_unpacked(L)); }
     if (d_keys) *d_keys = cur_keys(L);
     if (d_ids) *d_ids = cur_ids(L);
     if (m) *m = L->m;
@@ -1202,6 +1278,7 @@ int bp_layer_tree_device(bp_layer_t* L, const uint64_t** d_keys, const uint32_t*
 int bp_layer_tree(bp_layer_t* L, const uint64_t** keys, const uint32_t** ids, size_t* m, int* sorted) {
     if (!L) return BP_ERR_INVALID_ARG;
     DeviceGuard g(L->device);
+    BP_TRY(ensure_unpacked(L));
     BP_TRY(ensure_host(L, L->h_keys, std::max<size_t>(L->m * sizeof(uint64_t), 8)));
     BP_TRY(ensure_host(L, L->h_ids, std::max<size_t>(L->m * sizeof(uint32_t), 8)));
     if (L->m) {
@@ -1229,6 +1306,7 @@ int bp_layer_set_tree(bp_layer_t* L, uint32_t min_depth, const uint64_t* keys, c
 
 int bp_layer_clone(const bp_layer_t* src, bp_layer_t** out) {
     if (!src || !out) return BP_ERR_INVALID_ARG;
+    { DeviceGuard g0(src->device); BP_TRY(ensure_unpacked(const_cast<bp_layer*>(src))); }
     BP_TRY(bp_layer_create(out, src->kind, src->min_depth, src->m, 0, src->device));
     bp_layer* L = *out;
     DeviceGuard g(L->device);

@@ -82,6 +82,17 @@ class HipBackend:
     def local_can_pack_box(self):
         return self.local.can_pack_box()
 
+    def local_facts(self):
+        return self.local.get_facts()
+
+    def shard_begin(self, m):
+        """device buffers of the shard layer for m incoming entries: (keys int64 tensor, ids int32 tensor)"""
+        k, i = self.shard.begin_entries(m)
+        return k.as_torch(), i.as_torch()
+
+    def shard_commit(self, m, facts):
+        self.shard.commit_entries(m, facts)
+
     def local_partition_entries(self, split_depth, lut, n_ranks, pack_box=False):
         counts, keys, ids = self.local.partition_entries_device(split_depth, lut, n_ranks, pack_box)
         return counts, keys.as_torch(), ids.as_torch()
@@ -154,7 +165,7 @@ class TorchComm:
         dist.all_gather(parts, mine, group=self.group)
         return np.stack([p.cpu().numpy() for p in parts])
 
-    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None):
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None):
         """variable-size all-to-all of a tensor that is already grouped by destination"""
         torch, dist = self.torch, self.dist
         send_counts = [int(c) for c in send_counts]
@@ -165,7 +176,7 @@ class TorchComm:
             recv_counts = [int(c) for c in rc.cpu().tolist()]
         else:
             recv_counts = [int(c) for c in recv_counts]
-        recv = backend.empty(sum(recv_counts), dtype)
+        recv = out[: sum(recv_counts)] if out is not None else backend.empty(sum(recv_counts), dtype)
         ch = max(1, self.CHUNK_BYTES // send.element_size())
         # the largest single message of ANY rank decides the number of rounds; with the counts matrix
         # known everywhere this needs no collective (callers pass global_max), else one all-reduce
@@ -263,35 +274,57 @@ class ShardedLayer:
             now = time.perf_counter()
             stages[name] = stages.get(name, 0.0) + (now - t_prev[0]) * 1e3
             t_prev[0] = now
-        # 2. balanced contiguous Morton ranges from the all-reduced cell histogram; the same reduction
-        #    tells whether EVERY rank's ids can carry their box codes and knows all of them
-        can_pack, all_known = be.local_can_pack_box()
-        hist = np.concatenate([be.local_cell_histogram(d_s).astype(np.int64), [1 if can_pack else 0, 1 if all_known else 0]])
+        # 2. balanced contiguous Morton ranges from the all-reduced cell histogram
+        hist = be.local_cell_histogram(d_s).astype(np.int64)
         lap("cell_hist")
         hist_all = comm.all_reduce_sum(hist, be)
         lap("allreduce_hist")
-        pack = int(hist_all[-2]) == G
-        all_known = pack and int(hist_all[-1]) == G
-        hist_all = hist_all[:-2]
         lut = choose_owner_lut(hist_all[:-1], G)
-        # 3. entries -> owners (fine), boundary keys -> everyone (coarse)
+        # every rank's facts travel with its counts (one all-gather): who can pack box codes into the
+        # ids, id ranges, OR/AND of keys and ids -- the receiving shard layers need no re-reduction
+        lf = be.local_facts()
+        can_pack = bool(lf["flags"] & 4)
+        fvec = [lf["key_or"], lf["key_and"], lf["id_or"], lf["id_and"], lf["id_min"], lf["id_max"], lf["depth_mask"], lf["flags"]]
+        # 3. entries -> owners (fine), boundary keys -> everyone (coarse).  Packing must be decided
+        #    before the partition, by every rank alike: a first tiny all-gather of the flags
+        fm = comm.all_gather_counts(fvec, be)
+        nonempty = fm[:, 4] <= fm[:, 5]                                  # id_min <= id_max: the rank has entries
+        flags_all = fm[:, 7]
+        pack = bool(np.all((flags_all[nonempty] & 4) != 0)) if nonempty.any() else False
+        all_known = pack and bool(np.all((flags_all[nonempty] & 8) != 0))
         counts, keys, ids = be.local_partition_entries(d_s, lut, G, pack)
         n_fine = int(counts[:G].sum())
         lap("partition_entries")
-        cm = comm.all_gather_counts(counts, be)                      # cm[src][dst], cm[src][G] = coarse
-        comm._global_max_hint = int(cm[:, :G].max())
+        cm = comm.all_gather_counts(counts, be)                          # cm[src][dst], cm[src][G] = coarse
         recv_counts = cm[:, self.rank]
-        rk = comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be, recv_counts)
-        ri = comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be, recv_counts)
-        comm._global_max_hint = None
         coarse_sizes = cm[:, G]
-        ck = comm.all_gather_v(keys[n_fine:n_fine + int(counts[G])], torch.int64, be, coarse_sizes)
-        ci = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be, coarse_sizes)
+        n_recv, n_coarse = int(recv_counts.sum()), int(coarse_sizes.sum())
+        sk, si = be.shard_begin(n_recv + n_coarse)
+        comm._global_max_hint = int(cm[:, :G].max())
+        comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be, recv_counts, out=sk)
+        comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be, recv_counts, out=si)
+        comm._global_max_hint = None
+        if n_coarse:
+            sk[n_recv:] = comm.all_gather_v(keys[n_fine:n_fine + int(counts[G])], torch.int64, be, coarse_sizes)
+            si[n_recv:] = comm.all_gather_v(ids[n_fine:n_fine + int(counts[G])], torch.int32, be, coarse_sizes)
+            be.sync()
         lap("exchange_entries")
-        # received chunks arrive in rank order and every rank's entries are in id order, so equal index
-        # values carry non-decreasing ids (fine and coarse entries never share an index value)
-        be.shard_set_entries([(rk, ri), (ck, ci)], pack, all_known)
-        lap("shard_set_entries")
+        # facts of the union.  Chunks arrive in rank order and every rank's entries are in its own
+        # append order, so the order / distinctness facts hold iff they hold locally everywhere and
+        # the ranks' id ranges ascend with the rank (fine and coarse entries never share an index value)
+        ne = np.flatnonzero(nonempty)
+        ascending = bool(np.all(fm[ne[:-1], 5] < fm[ne[1:], 4])) if len(ne) > 1 else True
+        facts = {
+            "key_or": int(np.bitwise_or.reduce(fm[:, 0])), "key_and": int(np.bitwise_and.reduce(fm[ne, 1])) if len(ne) else 0,
+            "id_or": int(np.bitwise_or.reduce(fm[:, 2])), "id_and": int(np.bitwise_and.reduce(fm[ne, 3])) if len(ne) else 0,
+            "id_min": int(fm[ne, 4].min()) if len(ne) else 0, "id_max": int(fm[ne, 5].max()) if len(ne) else 0,
+            "depth_mask": int(np.bitwise_or.reduce(fm[:, 6])),
+            "flags": (1 if (ascending and bool(np.all((flags_all[ne] & 1) != 0))) else 0)
+                     | (2 if (ascending and bool(np.all((flags_all[ne] & 2) != 0))) else 0)
+                     | (4 if pack else 0) | (8 if all_known else 0),
+        }
+        be.shard_commit(n_recv + n_coarse, facts)
+        lap("shard_commit")
         # 4. local sort + scan (single pass); coarse-coarse pairs only once.  With box codes every pair
         #    is emitted by exactly one entry on exactly one rank, so no duplicate ever crosses the wire.
         raw, unique = be.shard_scan_pairs(d_s, self.rank == 0)
@@ -317,8 +350,8 @@ class ShardedLayer:
         varying = (_varying_bits(lo, max(hi, lo)) << 32) | _varying_bits(0, max_id)
         out = be.sort_unique_packed(rp, varying, unique)
         lap("sort_pairs")
-        self.last = {"entries_local": int(counts.sum()), "entries_shard": int(rk.numel() + ck.numel()),
-                     "coarse": int(ck.numel()), "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
+        self.last = {"entries_local": int(counts.sum()), "entries_shard": n_recv + n_coarse,
+                     "coarse": n_coarse, "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
                      "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique),
                      "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
         return out

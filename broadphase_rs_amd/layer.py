@@ -44,6 +44,14 @@ class BroadphaseError(RuntimeError):
         self.status = status
 
 
+class _Facts(C.Structure):
+    _fields_ = [("key_or", C.c_uint64), ("key_and", C.c_uint64), ("id_or", C.c_uint32), ("id_and", C.c_uint32),
+                ("id_min", C.c_uint32), ("id_max", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32)]
+
+
+FACT_ORDER_OK, FACT_IDS_DISTINCT, FACT_IDS_CARRY_BOX, FACT_BOX_ALL_KNOWN = 1, 2, 4, 8
+
+
 class _Stats(C.Structure):
     _fields_ = [("objects_valid", C.c_uint64), ("objects_invalid", C.c_uint64), ("entries", C.c_uint64),
                 ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("tree_sort_passes", C.c_uint32),
@@ -68,6 +76,7 @@ EXPORTS = [
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
+    "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
 ]
 
 
@@ -164,6 +173,9 @@ def load_library():
                                                            C.c_int, u64p, C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_scan_shard_pairs_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
     L.bp_layer_sort_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
+    L.bp_layer_get_facts.argtypes = [vp, C.POINTER(_Facts)]
+    L.bp_layer_begin_entries.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.bp_layer_commit_entries.argtypes = [vp, C.c_size_t, C.POINTER(_Facts)]
     L.bp_layer_scan_filtered_aabb.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_scan_filtered_aabb_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_partition_pairs_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_uint32, u64p, C.POINTER(vp)]
@@ -446,6 +458,21 @@ class Layer:
         hist = np.zeros(n_cells + 1, dtype=np.uint64)
         self._check(self._L.bp_layer_cell_histogram(self._h, split_depth, hist.ctypes.data_as(C.POINTER(C.c_uint64)), n_cells))
         return hist
+
+    def get_facts(self):
+        f = _Facts()
+        self._check(self._L.bp_layer_get_facts(self._h, C.byref(f)))
+        return {name: int(getattr(f, name)) for name, _ in _Facts._fields_}
+
+    def begin_entries(self, m):
+        """clear, then device buffers for m entries the caller fills (keys u64[m], ids u32[m])"""
+        k, i = C.c_void_p(), C.c_void_p()
+        self._check(self._L.bp_layer_begin_entries(self._h, m, C.byref(k), C.byref(i)))
+        return DeviceArray(k.value, (m,), np.uint64, self), DeviceArray(i.value, (m,), np.uint32, self)
+
+    def commit_entries(self, m, facts):
+        f = _Facts(**{k: int(v) for k, v in facts.items()})
+        self._check(self._L.bp_layer_commit_entries(self._h, m, C.byref(f)))
 
     def can_pack_box(self):
         """(ids can carry box codes, all box codes known)"""

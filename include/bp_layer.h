@@ -157,6 +157,23 @@ enum { BP_FACT_ORDER_OK = 1u, BP_FACT_IDS_DISTINCT = 2u, BP_FACT_IDS_CARRY_BOX =
  * layer's. */
 int bp_layer_append_entries_assume(bp_layer_t *layer, const uint64_t *keys, const uint32_t *ids, size_t m,
                                    uint32_t facts);
+/* What a layer knows about its entries; travels with them across the exchange.  OR fields may
+ * contain extra bits and AND fields fewer (a superset description is always safe). */
+typedef struct bp_facts {
+    uint64_t key_or, key_and;   /* OR / AND of the index values               */
+    uint32_t id_or, id_and;     /* OR / AND of the ids (without box-code bits) */
+    uint32_t id_min, id_max;
+    uint32_t depth_mask;        /* bit d set <=> an entry of depth d may exist */
+    uint32_t flags;             /* BP_FACT_*                                   */
+} bp_facts;
+int bp_layer_get_facts(const bp_layer_t *layer, bp_facts *out);
+/* Replace the tree by m entries the caller writes itself (e.g. as the output of an all-to-all):
+ * begin clears the layer and returns device pointers to keys[m] / ids[m]; commit publishes them
+ * with the facts the caller vouches for.  With BP_FACT_IDS_CARRY_BOX the ids stay packed until
+ * the next sort splits the codes off (any other access to the entries unpacks first). */
+int bp_layer_begin_entries(bp_layer_t *layer, size_t m, uint64_t **d_keys, uint32_t **d_ids);
+int bp_layer_commit_entries(bp_layer_t *layer, size_t m, const bp_facts *facts);
+
 /* entries per Morton cell at split_depth: hist[n_cells + 1] (host), last slot = coarse entries
  * (depth < split_depth).  n_cells must be 2^(dim * split_depth) and <= 4096. */
 int bp_layer_cell_histogram(bp_layer_t *layer, uint32_t split_depth, uint64_t *hist, size_t n_cells);

@@ -61,6 +61,29 @@ class OracleBackend:
     def local_can_pack_box(self):
         return False, False
 
+    def local_facts(self):
+        keys, ids = self.local.keys, self.local.ids
+        if len(keys) == 0:
+            return {"key_or": 0, "key_and": (1 << 63) - 1, "id_or": 0, "id_and": 0xFFFFFFFF, "id_min": 0xFFFFFFFF, "id_max": 0,
+                    "depth_mask": 0, "flags": 3}
+        asc = bool(np.all(np.diff(ids.astype(np.int64)) >= 0))
+        return {"key_or": int(np.bitwise_or.reduce(keys)), "key_and": int(np.bitwise_and.reduce(keys)),
+                "id_or": int(np.bitwise_or.reduce(ids)), "id_and": int(np.bitwise_and.reduce(ids)),
+                "id_min": int(ids.min()), "id_max": int(ids.max()),
+                "depth_mask": int(np.bitwise_or.reduce(np.uint64(1) << (keys & np.uint64((1 << self.db) - 1)))),
+                "flags": (1 if asc else 0) | 2}
+
+    def shard_begin(self, m):
+        self._sk = torch.zeros(m, dtype=torch.int64)
+        self._si = torch.zeros(m, dtype=torch.int32)
+        return self._sk, self._si
+
+    def shard_commit(self, m, facts):
+        assert not (facts["flags"] & 4)
+        self.shard.clear()
+        if m:
+            self.shard.append_entries(self._sk.numpy().view(np.uint64)[:m], self._si.numpy().view(np.uint32)[:m])
+
     def local_partition_entries(self, split_depth, lut, n_ranks, pack_box=False):
         assert not pack_box
         keys, ids = self.local.keys, self.local.ids

@@ -44,15 +44,19 @@ class ThreadComm:
     def all_gather_counts(self, counts, backend):
         return np.stack(self._exchange(np.asarray([int(c) for c in counts], dtype=np.int64)))
 
-    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None):
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None):
         import torch
         offs = np.concatenate([[0], np.cumsum([int(c) for c in send_counts])])
         vals = self._exchange([send[int(offs[d]):int(offs[d + 1])].clone() for d in range(self.world)])
         parts = [vals[src][self.rank] for src in range(self.world)]
-        out = torch.cat(parts) if sum(p.numel() for p in parts) else backend.empty(0, dtype)
+        n = sum(p.numel() for p in parts)
+        res = torch.cat(parts) if n else backend.empty(0, dtype)
+        if out is not None:
+            out[:n] = res
+            res = out[:n]
         backend.sync()
         self.sh.barrier.wait()
-        return out
+        return res
 
     def all_gather_v(self, t, dtype, backend, sizes=None):
         import torch
