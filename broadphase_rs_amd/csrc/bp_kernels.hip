@@ -787,86 +787,80 @@ __device__ __forceinline__ void walk_ancestors(const u64* __restrict__ keys, u32
 // zero / lowest one.  So per axis only the counts of trailing zeros and trailing ones of the
 // coordinate are kept, taken straight from the Morton code (no decode).
 template <int KIND> struct BoxCtx {
+    // scalars only (per-axis arrays in a long-lived struct end up in scratch memory)
     u32 depth;
-    u32 tz[3], to[3];  // trailing zeros / trailing ones of this cell's coordinate, per axis (<= depth)
-    u32 t[3];          // own box code per axis: 0 single, 1 lower of two, 2 upper of two
-    u32 earlier;       // bit (kx + 2 ky + 4 kz): that cell of the box exists and sorts before this one
+    u32 earlier;   // non-zero <=> some cell of the box sorts before this one (else nothing is ever suppressed)
+    u32 two;       // axes on which the box has two cells (3-bit mask)
+    u32 needpat;   // per axis (2-bit field): the ancestor's code that keeps the OTHER cell inside
+    u32 table;     // bit O (3-bit axis set "other cell is inside the ancestor's box"): suppressed
+    u32 thr;       // per axis (8-bit field): the other cell leaves a depth-(depth - sh) ancestor cell iff field >= sh
 
     __device__ __forceinline__ void init(u64 key, u32 code) {
         constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
         constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
         depth = key_depth<KIND>(key);
+        earlier = 0; two = 0; needpat = 0; table = 0; thr = 0;
+        if (code == BOX_UNKNOWN) return;  // unknown box: behave as a single-cell object (never suppressed)
         const u64 md = depth == 0 ? 0ull : ((key >> DB) >> (DIM * (AB - depth)));  // DIM * depth Morton bits
         const u64 valid = depth == 0 ? 0ull : ((1ull << (DIM * depth)) - 1ull);
-#pragma unroll
-        for (u32 ax = 0; ax < 3; ++ax) { tz[ax] = depth; to[ax] = depth; t[ax] = 0; }
-#pragma unroll
-        for (u32 ax = 0; ax < DIM; ++ax) {
-            const u64 ones = (md >> ax) & LANE;
-            const u64 zeros = (~(md >> ax)) & LANE & (valid >> ax);
-            const u32 z = ones ? (u32)__builtin_ctzll(ones) : DIM * depth;
-            const u32 o = zeros ? (u32)__builtin_ctzll(zeros) : DIM * depth;
-            tz[ax] = DIM == 3 ? (z * 171u) >> 9 : z >> 1;   // / DIM
-            to[ax] = DIM == 3 ? (o * 171u) >> 9 : o >> 1;
-        }
-        earlier = 0;
-        if (code == BOX_UNKNOWN) return;  // unknown box: behave as a single-cell object (never suppressed)
-        t[0] = code & 3u; t[1] = (code >> 2) & 3u; t[2] = (code >> 4) & 3u;
-        // cell k of the box = this cell + delta, delta_ax = k_ax - (t_ax == 2).  It differs from this
-        // cell most significantly at bit (to or tz) of the axis that moved up or down; the axis with
-        // the largest interleaved bit position decides the Morton order.
-#pragma unroll
-        for (u32 k = 1; k < 8; ++k) {
-            int best = -1;
-            bool less = false;
-            bool exists = true;
-#pragma unroll
-            for (u32 ax = 0; ax < 3; ++ax) {
-                const u32 kk = (k >> ax) & 1u;
-                const u32 self = t[ax] == 2u ? 1u : 0u;
-                if (kk >= (t[ax] ? 2u : 1u)) exists = false;
-                if (kk != self) {
-                    const bool up = kk > self;
-                    const int pos = (int)((up ? to[ax] : tz[ax]) * DIM + ax);
-                    if (pos > best) { best = pos; less = !up; }
-                }
-            }
-            if (exists && best >= 0 && less) earlier |= 1u << k;
-        }
-        // bit 0 is cell (0,0,0) of the box: handled by the loop only for k >= 1
+        // per axis: own code, and the position of the most significant bit in which the OTHER cell of
+        // the box differs from this one = trailing ones (other is one step up) / zeros (one step down)
+        const u32 t0 = code & 3u, t1 = (code >> 2) & 3u, t2 = (code >> 4) & 3u;
+        u32 f0 = 0, f1 = 0, f2 = 0;
         {
-            int best = -1;
-            bool less = false;
-#pragma unroll
-            for (u32 ax = 0; ax < 3; ++ax) {
-                if (t[ax] == 2u) {  // this cell is the upper one: cell 0 is one step down on this axis
-                    const int pos = (int)(tz[ax] * DIM + ax);
-                    if (pos > best) { best = pos; less = true; }
-                }
-            }
-            if (best >= 0 && less) earlier |= 1u;
+            const u64 src = t0 == 1u ? ((~md) & LANE & valid) : (md & LANE);
+            const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * depth;
+            f0 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
         }
+        {
+            const u64 src = t1 == 1u ? ((~(md >> 1)) & LANE & (valid >> 1)) : ((md >> 1) & LANE);
+            const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * depth;
+            f1 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
+        }
+        if (DIM == 3) {
+            const u64 src = t2 == 1u ? ((~(md >> 2)) & LANE & (valid >> 2)) : ((md >> 2) & LANE);
+            const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * depth;
+            f2 = (c * 171u) >> 9;
+        }
+        two = (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u);
+        needpat = (t0 == 1u ? 1u : 2u) | ((t1 == 1u ? 1u : 2u) << 2) | ((t2 == 1u ? 1u : 2u) << 4);
+        thr = f0 | (f1 << 8) | (f2 << 16);
+        // Morton position of the deciding bit per axis, and whether moving to the other cell goes DOWN
+        const int p0 = (int)(f0 * DIM + 0u), p1 = (int)(f1 * DIM + 1u), p2 = (int)(f2 * DIM + 2u);
+        const bool dn0 = t0 == 2u, dn1 = t1 == 2u, dn2 = t2 == 2u;
+        // diffset bit D (set of axes that differ from this cell): that cell exists and sorts earlier
+        u32 ds = 0;
+        if (t0 && dn0) ds |= 1u << 1;
+        if (t1 && dn1) ds |= 1u << 2;
+        if (t2 && dn2) ds |= 1u << 4;
+        if (t0 && t1 && (p1 > p0 ? dn1 : dn0)) ds |= 1u << 3;
+        if (t0 && t2 && (p2 > p0 ? dn2 : dn0)) ds |= 1u << 5;
+        if (t1 && t2 && (p2 > p1 ? dn2 : dn1)) ds |= 1u << 6;
+        if (t0 && t1 && t2) {
+            const bool d = (p2 > p1 && p2 > p0) ? dn2 : (p1 > p0 ? dn1 : dn0);
+            if (d) ds |= 1u << 7;
+        }
+        earlier = ds;
+        // table[O] = some earlier cell differs from this one only on axes in O (subset closure of ds)
+        u32 tb = ds;
+        tb |= (tb & 0x55u) << 1;
+        tb |= (tb & 0x33u) << 2;
+        tb |= (tb & 0x0Fu) << 4;
+        table = tb;
     }
-    // ancestor entry at depth dd <= depth with box code `code`: is the pair emitted elsewhere?
-    __device__ __forceinline__ bool suppressed(u32 dd, u32 code) const {
+    // axes on which the other cell of the box leaves the depth-dd ancestor cell (per run)
+    __device__ __forceinline__ u32 crossing(u32 dd) const {
         const u32 sh = depth - dd;
-        const u32 cb = code == BOX_UNKNOWN ? 0u : code;  // unknown: the ancestor's own cell only
-        const u32 tb[3] = {cb & 3u, (cb >> 2) & 3u, (cb >> 4) & 3u};
-        u32 inside = 0xFFu;
-        const u32 pat0[3] = {0x55u, 0x33u, 0x0Fu}, pat1[3] = {0xAAu, 0xCCu, 0xF0u};
-#pragma unroll
-        for (u32 ax = 0; ax < 3; ++ax) {
-            const u32 self_pat = t[ax] == 2u ? pat1[ax] : pat0[ax];
-            u32 m = self_pat;  // this cell lies in the ancestor's cell by construction
-            if (t[ax] != 0u) {
-                const bool up = t[ax] == 1u;  // the other cell of the box is one step up / down
-                const bool crosses = (up ? to[ax] : tz[ax]) >= sh;
-                const bool other_inside = !crosses || tb[ax] == (up ? 1u : 2u);
-                if (other_inside) m |= (pat0[ax] | pat1[ax]) & ~self_pat;
-            }
-            inside &= m;
-        }
-        return (inside & earlier) != 0;
+        return ((thr & 0xFFu) >= sh ? 1u : 0u) | (((thr >> 8) & 0xFFu) >= sh ? 2u : 0u) | (((thr >> 16) & 0xFFu) >= sh ? 4u : 0u);
+    }
+    // ancestor entry with box code `code` in a run whose crossing mask is cr: is the pair emitted elsewhere?
+    __device__ __forceinline__ bool suppressed(u32 cr, u32 code) const {
+        const u32 cb = code == BOX_UNKNOWN ? 0u : code;       // unknown: the ancestor's own cell only
+        const u32 x = cb ^ needpat;
+        const u32 m = ~(x | (x >> 1)) & 0x15u;                // field == 0 <=> the ancestor's box covers the other cell
+        const u32 match = (m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u);
+        const u32 inside = (~cr | match) & two;
+        return ((table >> inside) & 1u) != 0;
     }
 };
 
@@ -916,7 +910,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_count_kernel(ScanParams p, 
                 bx.init(key, p.box[i]);
                 walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
                     if (bx.earlier == 0) { cnt += hi - lo; return; }
-                    for_run_desc(lo, hi, [&](u32 j) { cnt += bx.suppressed(dd, p.box[j]) ? 0u : 1u; });
+                    const u32 cr = bx.crossing(dd);
+                    for_run_desc(lo, hi, [&](u32 j) { cnt += bx.suppressed(cr, p.box[j]) ? 0u : 1u; });
                 });
             } else {
                 walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32) { cnt += hi - lo; });
@@ -954,9 +949,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_emit_kernel(ScanParams p, c
         BoxCtx<KIND> bx;
         bx.init(key, p.box[i]);
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            const u32 cr = bx.crossing(dd);
             for_run_desc(lo, hi, [&](u32 j) {
                 const u32 idj = p.ids[j];
-                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                if (bx.earlier != 0 && bx.suppressed(cr, p.box[j])) return;
                 --pos;
                 out[pos] = hi_id | (u64)idj;
             });
@@ -1020,9 +1016,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     u32 mine = 0;
     if (active) {
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            const u32 cr = bx.crossing(dd);
             for_run_desc(lo, hi, [&](u32 j) {
                 const u32 idj = p.ids[j];
-                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                if (bx.earlier != 0 && bx.suppressed(cr, p.box[j])) return;
                 if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
                 if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)idj;
@@ -1045,8 +1042,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     __syncthreads();
     if (active && mine) {
         walk_ancestors<KIND>(p.keys, i, key, p.depth_mask, [&](u32 lo, u32 hi, u32 dd) {
+            const u32 cr = bx.crossing(dd);
             for_run_desc(lo, hi, [&](u32 j) {
-                if (bx.earlier != 0 && bx.suppressed(dd, p.box[j])) return;
+                if (bx.earlier != 0 && bx.suppressed(cr, p.box[j])) return;
                 const u32 idj = p.ids[j];
                 if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
