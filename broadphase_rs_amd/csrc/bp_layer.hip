@@ -88,9 +88,10 @@ thread_local std::string g_last_global_error;
 
 int fail(bp_layer* L, int code, const char* what, hipError_t e = hipSuccess) {
     char buf[512];
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
         snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
-    else
+        (void)hipGetLastError();  // reported here: must not resurface in the next call's launch check
+    } else
         snprintf(buf, sizeof buf, "%s", what);
     if (L) L->err = buf;
     g_last_global_error = buf;
@@ -135,6 +136,9 @@ int ensure_dev(bp_layer* L, DevBuf& b, size_t bytes, size_t keep_bytes = 0) {
         e = hipMalloc(&q, want);
         if (e != hipSuccess) return fail(L, BP_ERR_OOM, "hipMalloc", e);
     }
+    // a side buffer (box codes) can be shorter than the tree it belongs to while its contents are
+    // not in use: only what the old block actually holds can be carried over
+    keep_bytes = std::min(keep_bytes, b.cap);
     if (keep_bytes && b.p) {
         e = hipMemcpyAsync(q, b.p, keep_bytes, hipMemcpyDeviceToDevice, L->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(L->stream);

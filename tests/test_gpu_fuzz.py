@@ -1,0 +1,116 @@
+"""Randomised differential test: random sequences of Layer operations on the HIP layer and on the
+oracle side by side.  Targets the bookkeeping that selects kernels (id order / distinctness facts,
+box codes, sorted flag, ping-pong buffers) rather than any single kernel."""
+import numpy as np
+import pytest
+
+import oracle
+import broadphase_rs_amd as bp
+from broadphase_rs_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree(gpu, ref, what):
+    k, i = gpu.tree()
+    assert len(k) == len(ref), "%s: %d entries vs %d" % (what, len(k), len(ref))
+    assert np.array_equal(k, ref.keys) and np.array_equal(i, ref.ids), what
+    assert gpu.sorted == ref.sorted, what
+
+
+def _scan(gpu, ref, what, rng):
+    exp = ref.scan()
+    mode = rng.integers(0, 4)
+    if mode == 0:
+        got = np.array(gpu.scan())
+    elif mode == 1:
+        got = np.array(gpu.par_scan())
+    elif mode == 2:
+        got = gpu.scan_device().to_numpy()
+    else:
+        got = np.array(gpu.scan_filtered(lambda a, b: True))
+    assert got.shape == exp.shape and np.array_equal(got, exp), what
+    assert gpu.sorted and ref.sorted
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_operation_sequences(seed):
+    rng = np.random.default_rng(1000 + seed)
+    min_depth = int(rng.choice([0, 0, 0, 3, 6]))
+    n_pool = int(rng.choice([3000, 8000, 20000, 120000]))
+    kind = [bp.Index64_3D, bp.Index64_3D, bp.Index64_2D, bp.Index32_2D][seed % 4 if seed >= 12 else 0]
+    if seed % 4 == 3:
+        sysb, bounds, _ = scenes.gen_boxes_powerlaw(n_pool, seed=seed, alpha=2.0)
+    else:
+        sysb, bounds, _ = scenes.gen_boxes(n_pool, seed=seed)
+    if kind.dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2])
+        min_depth = min(min_depth, 3)
+        bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    layers = [(bp.Layer(kind, min_depth), oracle.OracleLayer(kind.kind, min_depth)) for _ in range(2)]
+    next_id = [0]
+    log = []
+
+    def extend(which):
+        g, r = layers[which]
+        n = int(rng.integers(1, n_pool // 3))
+        rows = rng.integers(0, n_pool, size=n)
+        style = rng.integers(0, 5)
+        if style <= 1:      # fresh ascending ids (the fast-path case)
+            ids = np.arange(next_id[0], next_id[0] + n, dtype=np.uint32)
+            next_id[0] += n
+        elif style == 2:    # shuffled but distinct
+            ids = rng.permutation(np.arange(next_id[0], next_id[0] + n, dtype=np.uint32))
+            next_id[0] += n
+        elif style == 3:    # ids reused across objects (several boxes per id)
+            ids = rng.integers(0, max(next_id[0], 50), size=n).astype(np.uint32)
+        else:               # ascending but restarting from a lower value
+            start = int(rng.integers(0, max(next_id[0], 1)))
+            ids = np.arange(start, start + n, dtype=np.uint32)
+            next_id[0] = max(next_id[0], start + n)
+        b = bounds[rows].copy()
+        if rng.random() < 0.2:
+            b[: max(1, n // 50), b.shape[1] // 2:] += np.float32(1e6)      # some objects fall outside the system bounds
+        g.extend(sysb, b, ids); r.extend(sysb, b, ids)
+        log.append("extend[%d] n=%d style=%d" % (which, n, style))
+        _tree(g, r, " | ".join(log[-6:]))
+
+    for _step in range(int(rng.integers(6, 14))):
+      try:
+        op = rng.integers(0, 10)
+        which = int(rng.integers(0, 2))
+        g, r = layers[which]
+        if op <= 3:
+            extend(which)
+        elif op == 4:
+            (g.par_sort if rng.random() < 0.5 else g.sort)(); r.sort()
+            log.append("sort[%d]" % which)
+            _tree(g, r, " | ".join(log[-6:]))
+        elif op == 5:
+            log.append("scan[%d]" % which)
+            _scan(g, r, " | ".join(log[-6:]), rng)
+        elif op == 6:
+            g.clear(); r.clear()
+            log.append("clear[%d]" % which)
+            assert len(g) == 0 and g.sorted
+        elif op == 7:
+            og, orf = layers[1 - which]
+            g.merge(og); r.merge(orf)
+            log.append("merge[%d<-%d]" % (which, 1 - which))
+            _tree(g, r, " | ".join(log[-6:]))
+            assert g.min_depth == r.min_depth
+        elif op == 8:
+            c = g.clone()
+            assert c == g
+            layers[which] = (c, r)       # keep working on the clone
+            log.append("clone[%d]" % which)
+        else:
+            raw_g = np.array(g.scan_raw()).reshape(-1, 2)
+            raw_r, _ = r.scan_raw()
+            log.append("scan_raw[%d]" % which)
+            assert np.array_equal(raw_g, raw_r), " | ".join(log[-6:])
+      except bp.BroadphaseError as e:
+        raise AssertionError("%s after: %s" % (e, " | ".join(log))) from e
+    for which in range(2):
+        g, r = layers[which]
+        _scan(g, r, "final scan[%d] after %s" % (which, " | ".join(log[-8:])), rng)
