@@ -33,6 +33,7 @@ struct DevScalars {
     unsigned int n_invalid;        // objects outside the system bounds
     unsigned int id_max;           // largest id handed to the last extend (valid or not)
     unsigned int id_min;           // smallest id handed to the last extend
+    unsigned int big_count;        // expanding scan: slices on the long-range work list
 };
 enum : unsigned {
     EXT_IDS_DECREASE = 1u,   // some id is smaller than its predecessor in append order
@@ -43,6 +44,7 @@ enum : unsigned {
     KERR_LOOKBACK_TIMEOUT = 1u,  // a decoupled look-back spin hit its bound
     KERR_COUNT_OVERFLOW = 2u,    // an object expands to more cells than a launch can index
     KERR_SEGMENT_TOO_LONG = 4u,  // segment_finish: one first id owns more pairs than its window holds
+    KERR_BIGLIST_OVERFLOW = 8u,  // expanding scan: more long-range slices than the work list holds
 };
 
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
@@ -106,7 +108,12 @@ size_t radix_workspace_bytes(size_t n, int n_passes);
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
-                      int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr);
+                      int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
+                      const uint32_t* blockfill = nullptr, size_t extent = 0);
+// blockfill / extent (key-only sorts): keys0 is the block-structured output of the expanding scan --
+// `extent` slots in blocks of SX_BLOCK, of which only the first blockfill[b] of block b hold a
+// record (n records in all).  The histogram and the first pass read around the holes; the result is
+// dense.  The workspace must be sized for `extent`.
 
 // ---- multi-GPU bucketing: one stable one-sweep pass with a custom digit (<= 256 buckets) --------
 // entries -> owner rank by Morton cell at split_depth (lut on the device), coarse entries
@@ -158,6 +165,30 @@ hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const
 // sc->total (zeroed by the host) = number of pairs produced; if it exceeds out_cap nothing past
 // the capacity was written and the host re-runs with a larger buffer
 hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t out_cap, DevScalars* sc, hipStream_t stream);
+
+// Expanding scan (default for distinct ids): the pair set of launch_scan_fused, candidates enumerated
+// per ANCESTOR entry as the contiguous range of entries its cell contains.  idctx[m]: per-entry
+// id << 32 | suppression context, written by launch_entry_ctx (box == nullptr: nothing is suppressed;
+// entries of depth < inactive_below never act as the deeper side).
+// Output is BLOCK-STRUCTURED: out_blocks blocks of SX_BLOCK slots; blockfill[g] (zeroed by the
+// caller) = records present at the start of block g.  shards (zeroed by the caller): SX_SHARDS block
+// cursors followed by SX_SHARDS pair counts; shard s hands out blocks s, s + SX_SHARDS, ...  The
+// caller derives  pairs = sum(counts),  extent = max(cursor) * SX_SHARDS * SX_BLOCK  and re-runs with
+// more blocks when extent exceeds the capacity.  big_list: scratch for big_cap u64 work items;
+// KERR_BIGLIST_OVERFLOW in sc->err means the result is incomplete (use scan_fused).
+constexpr uint32_t SX_BLOCK = 256;
+constexpr int SX_SHARDS = 64;
+constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
+hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
+                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
+hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
+                              uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
+                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream);
+// dense copy of a block-structured stream (consumers that cannot read around the holes):
+// block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
+hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,
+                                 const unsigned long long* block_offs, uint64_t* out, hipStream_t stream);
+hipError_t launch_blockfill_to_u64(const uint32_t* blockfill, size_t n_blocks, unsigned long long* out, hipStream_t stream);
 
 // ---- dedup (K8): reference src/layer.rs:474,517 --------------------------------------------------
 constexpr int UQ_THREADS = 256;

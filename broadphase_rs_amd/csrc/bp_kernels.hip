@@ -351,6 +351,7 @@ constexpr u64 ST_FLAG_AGG = 1ull << 62;   // tile-local digit count published
 constexpr u64 ST_FLAG_PRE = 2ull << 62;   // inclusive prefix over tiles 0..t published
 constexpr u64 ST_VALUE = (1ull << 62) - 1ull;
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
+constexpr u32 HOLE_BLOCK = 256;  // records per block of a block-structured input (expanding scan output)
 
 __device__ __forceinline__ void st_store(u64* p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -364,12 +365,17 @@ constexpr int HIST_MAX_BLOCKS = 1024;
 
 __global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __restrict__ keys,
                                                                   const u32* __restrict__ vals, size_t n,
-                                                                  RadixPlan plan, u64* __restrict__ hist) {
+                                                                  RadixPlan plan, u64* __restrict__ hist,
+                                                                  const u32* __restrict__ blockfill) {
     __shared__ u32 h[RS_MAX_PASSES * RS_BINS];
     const int np = plan.n_passes;
     for (int j = threadIdx.x; j < np * RS_BINS; j += HIST_THREADS) h[j] = 0;
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS) {
+        if (blockfill) {  // 64 consecutive records per wave: the block is wave-uniform
+            const u32 blk = __builtin_amdgcn_readfirstlane((u32)(i / HOLE_BLOCK));
+            if ((u32)(i & (HOLE_BLOCK - 1u)) >= blockfill[blk]) continue;  // hole
+        }
         const u64 k = keys[i];
         const u32 v = vals ? vals[i] : 0u;
         for (int p = 0; p < np; ++p) {
@@ -474,7 +480,8 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
                                                                     u64* status, u32* tile_counter, DevScalars* sc,
-                                                                    const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out) {
+                                                                    const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out,
+                                                                    const u32* __restrict__ blockfill, size_t n_out) {
     constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
     static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
@@ -498,13 +505,31 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     const u32 tile_n = (u32)((n - base) < (size_t)RS_TILE ? (n - base) : (size_t)RS_TILE);
 
     // ---- 1. load: wave w owns RS_ITEMS * 64 consecutive records, 64 per round (coalesced) -------
+    // blockfill != nullptr: the input is the block-structured raw pair stream of the expanding scan
+    // (HOLE_BLOCK records per block, only the first blockfill[b] of block b exist); the pass reads
+    // around the holes and its output is dense (n_out records).
     K key[RS_ITEMS];
     u32 packed[RS_ITEMS];  // digit | rank-in-(wave,digit) << 8, later the tile-local destination
+    u32 vmask = 0;         // bit r: record r of this lane exists
     const u32 wbase = (u32)w * (64 * RS_ITEMS) + (u32)lane;
+    // a wave's 64 records of one round lie in one block, and its RS_ITEMS rounds in consecutive blocks:
+    // the fills are wave-uniform (scalar loads)
+    static_assert((64 * RS_ITEMS) % HOLE_BLOCK == 0 && RS_TILE % HOLE_BLOCK == 0, "waves must not straddle blocks");
+    constexpr int WAVE_BLOCKS = 64 * RS_ITEMS / (int)HOLE_BLOCK;
+    u32 fill[WAVE_BLOCKS];
+    if (blockfill) {
+        const size_t blk0 = (size_t)__builtin_amdgcn_readfirstlane((u32)((base + (size_t)w * (64 * RS_ITEMS)) / HOLE_BLOCK));
+        const size_t n_blk = (n + HOLE_BLOCK - 1) / HOLE_BLOCK;
+#pragma unroll
+        for (int q = 0; q < WAVE_BLOCKS; ++q) fill[q] = blk0 + q < n_blk ? blockfill[blk0 + q] : 0u;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 li = wbase + (u32)r * 64u;
-        key[r] = li < tile_n ? keys_in[base + li] : (K)0;
+        bool valid = li < tile_n;
+        if (blockfill) valid = valid && (li & (HOLE_BLOCK - 1u)) < fill[r * 64 / (int)HOLE_BLOCK];
+        vmask |= valid ? (1u << r) : 0u;
+        key[r] = valid ? keys_in[base + li] : (K)0;
     }
     u64* my_status = status + (size_t)tile * RS_BINS + tid;
 
@@ -516,8 +541,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     const u64 lanebit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        const u32 li = wbase + (u32)r * 64u;
-        const bool valid = li < tile_n;
+        const bool valid = (vmask >> r) & 1u;
         const u32 dg = digit(key[r]);
         u64 peers = 0;
         u32 old = 0;
@@ -577,8 +601,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     K* stage_k = reinterpret_cast<K*>(s_stage);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        const u32 li = wbase + (u32)r * 64u;
-        if (li < tile_n) {
+        if ((vmask >> r) & 1u) {
             const u32 dg = packed[r] & 0xFFu;
             const u32 pos = s_cnt[w][dg] + (packed[r] >> 8);
             packed[r] = pos;  // keep the tile-local destination for the payload phase
@@ -637,12 +660,12 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     for (int k = 0; k < RS_ITEMS; ++k) {
         const u32 li = (u32)k * RS_THREADS + (u32)tid;
         out_dg[k] = 0;
-        if (li < tile_n) {
+        if (li < tile_total) {  // the tile's existing records, now contiguous in LDS
             const K kk = stage_k[li];
             const u32 dg = digit(kk);
             out_dg[k] = dg;
             size_t g = (size_t)(s_glob[dg] + (u64)li);
-            if (g < n) keys_out[g] = kk;  // g < n always holds unless a look-back timed out
+            if (g < n_out) keys_out[g] = kk;  // always holds unless a look-back timed out
         }
     }
     if constexpr (HAS_VAL) {
@@ -650,7 +673,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
             const u32 li = wbase + (u32)r * 64u;
-            if (li < tile_n) {
+            if ((vmask >> r) & 1u) {
                 val[r] = vals_in[base + li];
                 if constexpr (sizeof(V) == 4) {
                     if (box_in) val[r] |= (V)box_to_packed(box_in[base + li]) << BOX_ID_BITS;  // first pass: pack
@@ -661,16 +684,15 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
         V* stage_v = reinterpret_cast<V*>(s_stage);
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
-            const u32 li = wbase + (u32)r * 64u;
-            if (li < tile_n) stage_v[packed[r]] = val[r];
+            if ((vmask >> r) & 1u) stage_v[packed[r]] = val[r];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RS_ITEMS; ++k) {
             const u32 li = (u32)k * RS_THREADS + (u32)tid;
-            if (li < tile_n) {
+            if (li < tile_total) {
                 size_t g = (size_t)(s_glob[out_dg[k]] + (u64)li);
-                if (g < n) {
+                if (g < n_out) {
                     V v = stage_v[li];
                     if constexpr (sizeof(V) == 4) {
                         if (box_out) {  // last pass: unpack
@@ -1055,6 +1077,266 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 }
 
 // =================================================================================================
+// Expanding scan (default): the same pair set as scan_fused, enumerated from the ANCESTOR's side.
+//
+// In the sorted tree the entries contained in the cell of entry j (and the later entries of the
+// same cell) are exactly the contiguous range (j, end_j) with end_j = first index whose key is
+// >= (key_j & level_mask(d_j)) + one cell span at depth d_j: a key in that interval has j's Morton
+// prefix and cannot have a smaller depth (it would sort before j).  So no per-level searches are
+// needed: one forward gallop per entry gives end_j, and the raw stream is all (i, j), j < i < end_j.
+// The ranges of the 64 entries a wave owns are concatenated (prefix sum) and the candidates are
+// dealt to the lanes one per step, so lanes stay busy whatever the mix of range lengths; a
+// candidate costs one 8-byte load of entry i's {id, suppression context} word.  Kept pairs are
+// compacted with a ballot into a per-wave LDS stage and flushed with one atomic per ~500 pairs.
+// Ranges of SX_BIG or more candidates (large objects) are cut into slices on a work list and
+// spread over the whole grid by scan_expand_big_kernel.
+// =================================================================================================
+// Per-entry word: id << 32 | ctx.  ctx packs what BoxCtx needs for a candidate test:
+//   bits  0..14  g_axis = depth - (trailing count), 5 bits per axis: the box's other cell on that axis
+//                leaves the ancestor cell of depth dd  <=>  dd >= g_axis
+//   bits 15..21  BoxCtx::table >> 1 (bit 0 of the table is never set)
+//   bits 22..27  box code (0 when unknown: own cell only)
+//   bit  28      entry takes no part as the deeper side (shard scans: coarse entry)
+//   bits 29..31  BoxCtx::two
+constexpr u32 CTX_INACTIVE = 1u << 28;
+template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 code, u32 inactive_below) {
+    BoxCtx<KIND> bx;
+    bx.init(key, code);
+    const u32 d = bx.depth;
+    const u32 g0 = d - (bx.thr & 0xFFu), g1 = d - ((bx.thr >> 8) & 0xFFu), g2 = d - ((bx.thr >> 16) & 0xFFu);
+    u32 c = g0 | (g1 << 5) | (g2 << 10) | ((bx.table >> 1) << 15) | (bx.two << 29);
+    if (code != BOX_UNKNOWN) c |= (code & 63u) << 22;
+    if (d < inactive_below) c |= CTX_INACTIVE;
+    return c;
+}
+// is candidate (entry i with context ctx_i, ancestor j of depth dd with box code cb_j) the emitting combo?
+__device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 cb_j, u32 dd) {
+    if (ctx_i & CTX_INACTIVE) return false;
+    const u32 table = ((ctx_i >> 15) & 0x7Fu) << 1;
+    if (table == 0) return true;
+    const u32 cr = (dd >= (ctx_i & 31u) ? 1u : 0u) | (dd >= ((ctx_i >> 5) & 31u) ? 2u : 0u) | (dd >= ((ctx_i >> 10) & 31u) ? 4u : 0u);
+    const u32 x = cb_j ^ ((ctx_i >> 22) & 63u);            // axes with two cells: code == needpat
+    const u32 mm = ~(x | (x >> 1)) & 0x15u;
+    const u32 match = (mm & 1u) | ((mm >> 1) & 2u) | ((mm >> 2) & 4u);
+    const u32 inside = (~cr | match) & (ctx_i >> 29);
+    return ((table >> inside) & 1u) == 0;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void entry_ctx_kernel(const u64* __restrict__ keys, const u32* __restrict__ ids,
+                                                        const uint8_t* __restrict__ box, size_t m, u32 inactive_below,
+                                                        u64* __restrict__ idctx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const u32 code = box ? (u32)box[i] : (u32)BOX_UNKNOWN;
+    idctx[i] = ((u64)ids[i] << 32) | (u64)make_entry_ctx<KIND>(keys[i], code, inactive_below);
+}
+
+constexpr int SX_THREADS = 256;
+constexpr int SX_WAVES = SX_THREADS / 64;
+constexpr u32 SX_STAGE = 2 * SX_BLOCK;  // per-wave LDS ring: two output blocks
+constexpr u32 SX_BIG = 16384;           // ranges at least this long go to the work list, in slices of this size
+static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
+
+struct ExpandParams {
+    const u64* keys;
+    const u64* idctx;
+    size_t m;
+    u64* out;          // block-structured: block g = slots [g * SX_BLOCK, (g + 1) * SX_BLOCK)
+    u64 out_blocks;    // capacity in blocks
+    u32* blockfill;    // [out_blocks] zeroed by the host; records present in each block
+    u64* shards;       // [SX_SHARDS] block cursors, then [SX_SHARDS] pair counts (zeroed by the host)
+    DevScalars* sc;
+    u64* big_list;     // j | slice << 32 (slice s covers candidates [s * SX_BIG, (s + 1) * SX_BIG) of j's range)
+    u32 big_cap;
+    u32 n_waves;       // waves of the main kernel's grid (chunk stride)
+    const float* filt_bounds;
+};
+
+// first index > j whose key is >= upper (m if none); keys[j] < upper
+__device__ __forceinline__ u32 range_end(const u64* __restrict__ keys, u32 m, u32 j, u64 upper) {
+    constexpr int G = 7;
+    u64 pv[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const u64 pos = (u64)j + (1u << k);
+        pv[k] = pos < m ? keys[pos] : ~0ull;
+    }
+    u32 lo = j, hi = 0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        if (!found) {
+            if (pv[k] >= upper) { found = true; hi = (u32)min((u64)j + (1u << k), (u64)m); }
+            else lo = j + (1u << k);
+        }
+    }
+    if (!found) {
+        u64 step = 128;
+        for (;;) {
+            const u64 pos = (u64)j + step;
+            if (pos >= m) { hi = m; break; }
+            if (keys[pos] >= upper) { hi = (u32)pos; break; }
+            lo = (u32)pos;
+            step <<= 1;
+        }
+    }
+    while (hi - lo > 1) {  // keys[lo] < upper <= keys[hi] (hi == m: virtual +inf)
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] >= upper) hi = mid;
+        else lo = mid;
+    }
+    return hi;
+}
+
+template <int KIND> __device__ __forceinline__ u64 cell_upper(u64 key) {
+    constexpr u32 DIM = KT<KIND>::DIM, TOP = KT<KIND>::DIM * KT<KIND>::AB + KT<KIND>::DB;
+    const u32 d = key_depth<KIND>(key);
+    if (d == 0) return ~0ull;  // the root cell holds everything
+    return (key & level_mask<KIND>(d)) + (1ull << (TOP - DIM * d));
+}
+
+// Per-wave output stage.  One device-scope atomic on ONE address costs ~11 ns of serialised service
+// (88 / us for the whole chip), which at one reservation per ~500 pairs was 3/4 of this kernel's
+// time.  So the output is block-structured: a wave stages pairs in an LDS ring of two SX_BLOCK-pair
+// halves and writes every completed half as one whole block; blocks are handed out by SX_SHARDS
+// independent cursors (shard s owns blocks s, s + SX_SHARDS, ...), so the atomics spread over 64
+// addresses.  Only a wave's last block is partial (blockfill says how much of it exists) and the
+// shards end a few blocks apart; the first pass of the pair sort reads around those holes.
+struct WaveStage {
+    u64* buf;      // LDS ring, SX_STAGE slots
+    u32 wp;        // pairs pushed so far (wave-uniform)
+    u32 shard;
+    __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
+        __builtin_amdgcn_wave_barrier();
+        u64 k = 0;
+        if (lane_id() == 0) k = atomicAdd(&p.shards[shard], 1ull);
+        const u64 g = (((u64)__builtin_amdgcn_readfirstlane((u32)(k >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)k)) * SX_SHARDS + shard;
+        if (g < p.out_blocks) {  // capacity is checked by the host afterwards (from the cursors)
+#pragma unroll
+            for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                const u32 k2 = q * 64u + (u32)lane_id();
+                if (k2 < count) p.out[g * SX_BLOCK + k2] = buf[half * SX_BLOCK + k2];
+            }
+            if (lane_id() == 0) p.blockfill[g] = count;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
+        const u64 mask = __ballot(keep);
+        const u32 n = (u32)__popcll(mask);
+        if (n == 0) return;
+        if (keep) buf[(wp + (u32)__popcll(mask & ((1ull << lane_id()) - 1ull))) & (SX_STAGE - 1u)] = pair;
+        const u32 before = wp / SX_BLOCK;
+        wp += n;
+        if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
+    }
+    __device__ __forceinline__ void finish(const ExpandParams& p) {
+        const u32 rem = wp & (SX_BLOCK - 1u);
+        if (rem) write_block(p, (wp / SX_BLOCK) & 1u, rem);
+        if (wp && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)wp);
+    }
+};
+
+template <int KIND, bool FILT>
+__global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p) {
+    constexpr int FDIM = (int)KT<KIND>::DIM;
+    __shared__ u32 s_incl[SX_WAVES][64];
+    __shared__ uint4 s_rec[SX_WAVES][64];
+    __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
+    const int w = (int)(threadIdx.x >> 6), lane = lane_id();
+    const u32 m = (u32)p.m;
+    const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
+    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS};
+    for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
+        const u32 j = (u32)base + (u32)lane;
+        u32 c = 0, idj = 0, cbdd = 0;
+        if (j < m) {
+            const u64 key = p.keys[j];
+            const u64 wj = p.idctx[j];
+            idj = (u32)(wj >> 32);
+            cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
+            const u32 end = range_end(p.keys, m, j, cell_upper<KIND>(key));
+            c = end - j - 1u;
+            if (c >= SX_BIG) {
+                const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
+                const u32 at = atomicAdd(&p.sc->big_count, ns);
+                if ((u64)at + ns <= p.big_cap) {
+                    for (u32 sl = 0; sl < ns; ++sl) p.big_list[at + sl] = (u64)j | ((u64)sl << 32);
+                } else {
+                    atomicOr(&p.sc->err, (u32)KERR_BIGLIST_OVERFLOW);
+                }
+                c = 0;
+            }
+        }
+        const u32 incl = wave_incl_scan_u32(c);
+        const u32 total = __shfl(incl, 63, 64);
+        if (total == 0) continue;  // wave-uniform
+        s_incl[w][lane] = incl;
+        s_rec[w][lane] = make_uint4(incl - c, idj, cbdd, 0u);
+        __builtin_amdgcn_wave_barrier();
+        for (u32 b = 0; b < total; b += 64) {
+            const u32 k = b + (u32)lane;
+            const bool act = k < total;
+            const u32 kk = act ? k : total - 1u;
+            // owner = first lane whose inclusive sum exceeds kk
+            u32 o = 0;
+#pragma unroll
+            for (u32 stp = 32; stp > 0; stp >>= 1) {
+                if (s_incl[w][o + stp - 1u] <= kk) o += stp;
+            }
+            const uint4 r = s_rec[w][o];
+            const u32 i = (u32)base + o + 1u + (kk - r.x);
+            const u64 wi = p.idctx[i];
+            bool keep = act && ctx_keep((u32)wi, r.z & 63u, r.z >> 8);
+            if (FILT && keep)
+                keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)r.y * (2 * FDIM));
+            st.push(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)r.y, p);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    st.finish(p);
+}
+
+// work-list slices of the long ranges: one slice per workgroup iteration
+template <int KIND, bool FILT>
+__global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParams p) {
+    constexpr int FDIM = (int)KT<KIND>::DIM;
+    __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
+    __shared__ u32 s_end;
+    const int w = (int)(threadIdx.x >> 6);
+    const u32 m = (u32)p.m;
+    const u32 n_items = min(p.sc->big_count, p.big_cap);
+    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS};
+    for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const u64 item = p.big_list[it];
+        const u32 j = (u32)item, slice = (u32)(item >> 32);
+        const u64 key = p.keys[j];
+        const u64 wj = p.idctx[j];
+        __syncthreads();
+        if (threadIdx.x == 0) s_end = range_end(p.keys, m, j, cell_upper<KIND>(key));
+        __syncthreads();
+        const u32 end = s_end;
+        const u32 idj = (u32)(wj >> 32), cb = ((u32)wj >> 22) & 63u, dd = key_depth<KIND>(key);
+        const u64 first = (u64)j + 1u + (u64)slice * SX_BIG;
+        const u64 last = min(first + SX_BIG, (u64)end);
+        for (u64 i0 = first; i0 < last; i0 += SX_THREADS) {  // workgroup-uniform trip count
+            const u64 i = i0 + threadIdx.x;
+            bool keep = false;
+            u64 wi = 0;
+            if (i < last) {
+                wi = p.idctx[i];
+                keep = ctx_keep((u32)wi, cb, dd);
+                if (FILT && keep)
+                    keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)idj * (2 * FDIM));
+            }
+            st.push(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
+        }
+    }
+    st.finish(p);
+}
+
+// =================================================================================================
 // dedup: Vec::dedup on the sorted pair list (src/layer.rs:474, 517)
 // =================================================================================================
 __global__ __launch_bounds__(UQ_THREADS) void unique_count_kernel(const u64* __restrict__ a, size_t n,
@@ -1352,19 +1634,9 @@ RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned 
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// tile geometry, selectable at run time for A/B measurements (BP_RS_CONFIG=0..3)
-struct RsConfig { int threads, items; };
-static const RsConfig RS_CONFIGS[] = {{512, 16}, {256, 16}, {1024, 8}, {512, 16}, {1024, 16}, {1024, 16}, {512, 12}, {512, 10}, {768, 8}};
-static int rs_config_id() {
-    static int id = -1;
-    if (id < 0) {
-        const char* e = getenv("BP_RS_CONFIG");
-        id = e ? atoi(e) : 0;
-        if (id < 0 || id >= (int)(sizeof(RS_CONFIGS) / sizeof(RS_CONFIGS[0]))) id = 0;
-    }
-    return id;
-}
-static size_t rs_tile_size() { return (size_t)RS_CONFIGS[rs_config_id()].threads * RS_CONFIGS[rs_config_id()].items; }
+// tile geometry: 512 threads x 16 records (8192-record tiles, 2 workgroups per CU)
+constexpr int RS_THREADS_DEF = 512, RS_ITEMS_DEF = 16;
+static size_t rs_tile_size() { return (size_t)RS_THREADS_DEF * RS_ITEMS_DEF; }
 static size_t rs_num_tiles(size_t n) { return (n + rs_tile_size() - 1) / rs_tile_size(); }
 
 size_t radix_workspace_bytes(size_t n, int n_passes) {
@@ -1379,44 +1651,41 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
-                                  u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr) {
+                                  u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr,
+                                  const u32* blockfill = nullptr, size_t n_out = 0) {
+    // n: extent of the input (tiles are cut from it); n_out: records that exist (== n without holes)
     const unsigned tiles = (unsigned)rs_num_tiles(n);
-    switch (rs_config_id()) {
-        case 1: radix_onesweep_kernel<K, V, 256, 16, DigitFn><<<tiles, 256, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 3: radix_onesweep_kernel<K, V, 512, 16, DigitFn, true><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 4: radix_onesweep_kernel<K, V, 1024, 16, DigitFn, true><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 2: radix_onesweep_kernel<K, V, 1024, 8, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 5: radix_onesweep_kernel<K, V, 1024, 16, DigitFn><<<tiles, 1024, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 6: radix_onesweep_kernel<K, V, 512, 12, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 7: radix_onesweep_kernel<K, V, 512, 10, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        case 8: radix_onesweep_kernel<K, V, 768, 8, DigitFn><<<tiles, 768, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-        default: radix_onesweep_kernel<K, V, 512, 16, DigitFn><<<tiles, 512, 0, stream>>>(ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo); break;
-    }
+    if (!blockfill) n_out = n;
+    radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn><<<tiles, RS_THREADS_DEF, 0, stream>>>(
+        ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
     return hipGetLastError();
 }
 
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
-                      int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out) {
+                      int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
+                      const uint32_t* blockfill, size_t extent) {
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
-    if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (radix_workspace_bytes(n, np) > workspace_bytes) return hipErrorInvalidValue;
+    if (!blockfill) extent = n;
+    if (extent < n || (blockfill && vals0)) return hipErrorInvalidValue;
+    if (extent >= 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (radix_workspace_bytes(extent, np) > workspace_bytes) return hipErrorInvalidValue;
     unsigned char* ws = (unsigned char*)workspace;
     u64* hist = (u64*)ws;
     u64* bin_base = hist + (size_t)np * RS_BINS;
     u32* counters = (u32*)(bin_base + (size_t)np * RS_BINS);
     u64* status = (u64*)((unsigned char*)counters + align_up((size_t)np * sizeof(u32), 256));
-    const size_t tiles = rs_num_tiles(n);
+    const size_t tiles = rs_num_tiles(extent);
     hipError_t e;
 
     if (mark) mark(mark_ctx, class_hist);
-    e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(n, np), stream);
+    e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(extent, np), stream);
     if (e != hipSuccess) return e;
-    radix_hist_kernel<<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
-        (const u64*)keys0, vals0, n, plan, hist);
+    radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
+        (const u64*)keys0, vals0, extent, plan, hist, blockfill);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<np, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1431,7 +1700,10 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         u64* st = status + (size_t)p * tiles * RS_BINS;
         u32* tc = counters + p;
         if (!vals0) {
-            e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
+            const bool holes = blockfill && p == 0;  // only the first pass sees the block-structured input
+            e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, holes ? extent : n,
+                                            ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream, nullptr, nullptr,
+                                            holes ? blockfill : nullptr, n);
         } else if (plan.from_val[p]) {
             e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else {
@@ -1548,6 +1820,72 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
     } else {
         BP_DISPATCH_KIND(kind, (scan_fused_kernel<K, false><<<g, SCAN_THREADS, 0, stream>>>(p, (u64*)pairs_out, (u64)out_cap, sc)));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
+                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    const unsigned g = (unsigned)((m + 255) / 256);
+    switch (kind) {
+        case 0: entry_ctx_kernel<0><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
+        case 1: entry_ctx_kernel<1><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
+        default: entry_ctx_kernel<2><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
+    }
+    return hipGetLastError();
+}
+
+template <int KIND>
+static hipError_t launch_scan_expand_kind(const ExpandParams& p, unsigned grid, hipStream_t stream) {
+    if (p.filt_bounds) {
+        scan_expand_kernel<KIND, true><<<grid, SX_THREADS, 0, stream>>>(p);
+        scan_expand_big_kernel<KIND, true><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
+    } else {
+        scan_expand_kernel<KIND, false><<<grid, SX_THREADS, 0, stream>>>(p);
+        scan_expand_big_kernel<KIND, false><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
+                              uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
+                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    // persistent waves: enough workgroups to fill the chip (7 per CU fit by LDS), never more than the work
+    const size_t chunks = (m + 63) / 64;
+    const unsigned grid = (unsigned)std::min<size_t>((chunks + SX_WAVES - 1) / SX_WAVES, 256 * 7);
+    ExpandParams p;
+    p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
+    p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
+    p.n_waves = grid * SX_WAVES; p.filt_bounds = filt_bounds;
+    switch (kind) {
+        case 0: return launch_scan_expand_kind<0>(p, grid, stream);
+        case 1: return launch_scan_expand_kind<1>(p, grid, stream);
+        default: return launch_scan_expand_kind<2>(p, grid, stream);
+    }
+}
+
+__global__ __launch_bounds__(256) void blockfill_to_u64_kernel(const u32* __restrict__ f, size_t nb, u64* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nb) out[i] = f[i];
+}
+__global__ __launch_bounds__(256) void compact_blocks_kernel(const u64* __restrict__ in, size_t nb, const u32* __restrict__ fill,
+                                                             const u64* __restrict__ offs, u64* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per block
+    if (g >= nb) return;
+    const u32 cnt = fill[g];
+    const u64 o = offs[g];
+    for (u32 k = (u32)lane_id(); k < cnt; k += 64) out[o + k] = in[g * SX_BLOCK + k];
+}
+hipError_t launch_blockfill_to_u64(const uint32_t* blockfill, size_t n_blocks, unsigned long long* out, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    blockfill_to_u64_kernel<<<(unsigned)((n_blocks + 255) / 256), 256, 0, stream>>>(blockfill, n_blocks, (u64*)out);
+    return hipGetLastError();
+}
+hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,
+                                 const unsigned long long* block_offs, uint64_t* out, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    compact_blocks_kernel<<<(unsigned)((n_blocks + 3) / 4), 256, 0, stream>>>((const u64*)in, n_blocks, blockfill, (const u64*)block_offs,
+                                                                             (u64*)out);
     return hipGetLastError();
 }
 

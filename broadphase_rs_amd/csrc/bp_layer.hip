@@ -69,6 +69,15 @@ struct bp_layer {
     HostBuf h_sc, h_pairs, h_keys, h_ids, h_raw;
     size_t n_raw = 0, n_pairs = 0;
     bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
+    DevBuf idctx, big_list;             // expanding scan: per-entry id << 32 | suppression context; long-range work list
+    DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
+    HostBuf h_shards;
+    bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
+    size_t raw_extent = 0;
+    uint64_t epoch = 1;                 // bumped whenever the sorted tree's content may have changed
+    uint64_t ctx_epoch = 0;             // epoch idctx was computed for (0: never), with ...
+    uint32_t ctx_thr = 0;               // ... entries of depth < ctx_thr inactive and ...
+    bool ctx_box = false;               // ... the box codes in use
 
     bp_stats stats{};
     bool prof_on = false;
@@ -402,6 +411,7 @@ int sort_tree_full(bp_layer* L, bool payload_already_packed) {
 
 int sort_tree(bp_layer* L) {
     if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
+    ++L->epoch;
     static const bool no_finish = getenv("BP_NO_TREE_FINISH") != nullptr;  // A/B switch for measurements
     L->stats.tree_sort_passes = 0;
     if (L->m > 1) {
@@ -476,6 +486,7 @@ int sort_tree(bp_layer* L) {
 int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup = false) {
     BP_TRY(sort_tree(L));  // src/layer.rs:465, 499
     L->n_raw = 0;
+    L->raw_holes = false;
     if (L->m == 0) return BP_OK;
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     const size_t nb = scan_blocks(L->m);
@@ -525,26 +536,31 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
 
 // sort + dedup of n packed pairs sitting in buf0 (scratch partner: L->pairs[1]) -> L->out_pairs
 // (interleaved), L->n_pairs
-int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false);
+int make_raw_dense(bp_layer* L);
+// holes: buf0 == pairs[0] holds the block-structured stream (L->blockfill, L->raw_extent)
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false,
+                         bool holes = false);
 
 // n DISTINCT packed pairs in buf0: radix sort on the first id only, then rank-sort the small
 // equal-first-id segments in LDS while writing the ABI layout (3 passes + 1 kernel instead of
 // 6 passes + 1 kernel).  Falls back to the full-width sort when a segment is too long.
-int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying) {
+int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes = false) {
     static const bool disabled = getenv("BP_NO_SEGMENT_FINISH") != nullptr;  // A/B switch
     const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
-    if (disabled || n < 2) return sort_unique_pairs_in(L, buf0, n, varying, true);
     const RadixPlan plan = make_radix_plan(hi_var, 0, 0);
+    if (disabled || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
     uint64_t* bufs[2] = {buf0, nullptr};
     BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
     bufs[1] = (uint64_t*)L->pairs[1].p;
     BP_TRY(sc_reset(L));
-    if (plan.n_passes > 0) {
-        BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(n, plan.n_passes)));
+    {
+        const size_t extent = holes ? L->raw_extent : n;
+        BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
-                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT));
+                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent));
     }
     BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
     {
@@ -562,11 +578,16 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     return BP_OK;
 }
 
-int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique) {
+int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique, bool holes) {
     L->n_pairs = 0;
     L->stats.pairs = 0;
     if (n == 0) return BP_OK;
     const RadixPlan plan = make_radix_plan(varying, 0, 0);
+    if (holes && !(plan.n_passes > 0 && n > 1)) {  // no pass to read around the holes
+        BP_TRY(make_raw_dense(L));
+        buf0 = (uint64_t*)L->pairs[0].p;
+        holes = false;
+    }
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
     uint64_t* bufs[2] = {buf0, nullptr};
@@ -574,11 +595,13 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
         DevBuf& partner = (buf0 == (uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];  // never buf0 itself
         BP_TRY(ensure_dev(L, partner, n * sizeof(uint64_t)));
         bufs[1] = (uint64_t*)partner.p;
-        const size_t wsb = radix_workspace_bytes(n, plan.n_passes);
+        const size_t extent = holes ? L->raw_extent : n;
+        const size_t wsb = radix_workspace_bytes(extent, plan.n_passes);
         BP_TRY(ensure_dev(L, L->radix_ws, wsb));
         BP_TRY(sc_reset(L));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
-                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT));
+                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent));
     } else {
         BP_TRY(sc_reset(L));
     }
@@ -619,18 +642,22 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
     return BP_OK;
 }
 
-int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false) {
+int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false, bool holes = false) {
     const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
-    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying);
-    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, false);
+    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes);
+    return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, false, holes);
 }
 
 // raw pairs in ARBITRARY order (they are sorted afterwards): one walk per entry, workgroup-staged
+// allow_holes: the caller's next step reads around the holes of the expanding scan's block-structured
+// output (sort_unique_pairs); otherwise pairs[0] is made dense before returning
+int make_raw_dense(bp_layer* L);
 int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup, const float* filt_bounds = nullptr,
-                      uint32_t filt_rows = 0) {
+                      uint32_t filt_rows = 0, bool allow_holes = false) {
     BP_TRY(sort_tree(L));
     L->n_raw = 0;
     L->raw_is_unique = false;
+    L->raw_holes = false;
     if (L->m == 0) return BP_OK;
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     ScanParams p;
@@ -646,11 +673,63 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.filt_rows = filt_rows;
     p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
+    static const bool no_expand = getenv("BP_NO_EXPAND_SCAN") != nullptr;  // A/B switch for measurements
+    bool expand = !no_expand;
+    if (expand) {
+        // per-entry {id, suppression context} words; recomputed only when the tree or the mode changed
+        const uint32_t thr = emit_coarse ? 0u : coarse_depth;
+        const bool with_box = p.box != nullptr;
+        if (L->ctx_epoch != L->epoch || L->ctx_thr != thr || L->ctx_box != with_box) {
+            BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
+            ProfScope ps(L, BP_K_SCAN_COUNT);
+            HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), p.box, L->m, thr, (uint64_t*)L->idctx.p, L->stream));
+            L->ctx_epoch = L->epoch; L->ctx_thr = thr; L->ctx_box = with_box;
+        }
+        BP_TRY(ensure_dev(L, L->big_list, std::max<size_t>(65536, L->m / 16) * sizeof(uint64_t)));
+    }
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
         cap = L->pairs[0].cap / sizeof(uint64_t);
         BP_TRY(sc_reset(L));
+        if (expand) {
+            const size_t out_blocks = cap / SX_BLOCK;
+            const size_t shard_bytes = 2 * SX_SHARDS * sizeof(uint64_t);
+            BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->shards, shard_bytes));
+            BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
+            HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
+            HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+            {
+                ProfScope ps(L, BP_K_SCAN_EMIT);
+                HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds,
+                                              (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p,
+                                              (uint64_t*)L->big_list.p,
+                                              (uint32_t)std::min<size_t>(L->big_list.cap / sizeof(uint64_t), 0xFFFFFFFFu),
+                                              (DevScalars*)L->d_sc.p, L->stream));
+            }
+            HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
+            DevScalars sc;
+            BP_TRY(sc_fetch(L, &sc));
+            if (sc.err & KERR_BIGLIST_OVERFLOW) {  // pathological nesting: the per-entry walk handles it
+                expand = false;
+                continue;
+            }
+            const uint64_t* sh = (const uint64_t*)L->h_shards.p;
+            uint64_t kmax = 0, total = 0;
+            for (int i = 0; i < SX_SHARDS; ++i) { kmax = std::max<uint64_t>(kmax, sh[i]); total += sh[SX_SHARDS + i]; }
+            const size_t extent_blocks = (size_t)kmax * SX_SHARDS;
+            if (extent_blocks <= out_blocks) {
+                L->n_raw = (size_t)total;
+                L->stats.raw_pairs = L->n_raw;
+                L->raw_holes = true;
+                L->raw_extent = extent_blocks * SX_BLOCK;
+                if (!allow_holes) BP_TRY(make_raw_dense(L));
+                return BP_OK;
+            }
+            cap = extent_blocks * SX_BLOCK + extent_blocks * SX_BLOCK / 16;  // the buffer was too small: grow and redo
+            continue;
+        }
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
             HIP_TRY(L, launch_scan_fused(L->kind, p, (uint64_t*)L->pairs[0].p, cap, (DevScalars*)L->d_sc.p, L->stream));
@@ -662,17 +741,35 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             L->stats.raw_pairs = L->n_raw;
             return BP_OK;
         }
-        cap = (size_t)sc.total + (size_t)sc.total / 16;  // the stage was too small: grow and redo
+        cap = (size_t)sc.total + (size_t)sc.total / 16;  // the buffer was too small: grow and redo
     }
     return fail(L, BP_ERR_KERNEL, "fused scan: output size did not converge");
+}
+
+// block-structured raw stream in pairs[0] -> dense (for consumers that cannot read around the holes)
+int make_raw_dense(bp_layer* L) {
+    if (!L->raw_holes) return BP_OK;
+    L->raw_holes = false;
+    if (L->n_raw == 0) return BP_OK;
+    const size_t nb = L->raw_extent / SX_BLOCK;
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
+    BP_TRY(ensure_dev(L, L->pairs[1], L->n_raw * sizeof(uint64_t)));
+    BP_TRY(sc_reset(L));
+    ProfScope ps(L, BP_K_MISC);
+    HIP_TRY(L, launch_blockfill_to_u64((const uint32_t*)L->blockfill.p, nb, (unsigned long long*)L->block_sums.p, L->stream));
+    HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, nullptr, (DevScalars*)L->d_sc.p, L->stream));
+    HIP_TRY(L, launch_compact_blocks((const uint64_t*)L->pairs[0].p, nb, (const uint32_t*)L->blockfill.p,
+                                     (const unsigned long long*)L->block_sums.p, (uint64_t*)L->pairs[1].p, L->stream));
+    std::swap(L->pairs[0], L->pairs[1]);
+    return BP_OK;
 }
 
 int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
     static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // A/B switches for measurements
     static const bool no_fused = getenv("BP_NO_FUSED_SCAN") != nullptr;
     if (L->ids_distinct && !no_fused) {
-        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup));
-        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
     }
@@ -988,8 +1085,8 @@ static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_ro
         d_bounds = (const float*)L->in_bounds.p;
     }
     if (L->ids_distinct) {  // predicate evaluated inside the single-pass scan, before anything is sorted
-        BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows));
-        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
+        BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows, true));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
     }
@@ -1304,6 +1401,7 @@ int bp_layer_set_tree(bp_layer_t* L, uint32_t min_depth, const uint64_t* keys, c
     L->min_depth = min_depth;
     if (m) BP_TRY(bp_layer_append_entries(L, keys, ids, m));
     L->sorted = sorted != 0;
+    ++L->epoch;
     if (L->sorted) L->order_ok = true;
     return BP_OK;
 }
