@@ -86,13 +86,23 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float f) {
 // ---- wave64 primitives --------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// wave-uniform value -> SGPR.  (__builtin_amdgcn_readfirstlane returns int: without the cast back to
+// unsigned a 64-bit composition sign-extends its low half.)
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    return ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32) | (uint64_t)uniform_u32((uint32_t)v);
+}
+
+// inclusive wave64 prefix sum on the DPP data path (no LDS crossbar): row shifts build the scan
+// inside each row of 16 lanes, the two row broadcasts carry the row totals forward
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
+    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes masked out or without a source get `old` (0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xE, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xC, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __r
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS) {
         if (blockfill) {  // 64 consecutive records per wave: the block is wave-uniform
-            const u32 blk = __builtin_amdgcn_readfirstlane((u32)(i / HOLE_BLOCK));
+            const u32 blk = uniform_u32((u32)(i / HOLE_BLOCK));
             if ((u32)(i & (HOLE_BLOCK - 1u)) >= blockfill[blk]) continue;  // hole
         }
         const u64 k = keys[i];
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     constexpr int WAVE_BLOCKS = 64 * RS_ITEMS / (int)HOLE_BLOCK;
     u32 fill[WAVE_BLOCKS];
     if (blockfill) {
-        const size_t blk0 = (size_t)__builtin_amdgcn_readfirstlane((u32)((base + (size_t)w * (64 * RS_ITEMS)) / HOLE_BLOCK));
+        const size_t blk0 = (size_t)uniform_u32((u32)((base + (size_t)w * (64 * RS_ITEMS)) / HOLE_BLOCK));
         const size_t n_blk = (n + HOLE_BLOCK - 1) / HOLE_BLOCK;
 #pragma unroll
         for (int q = 0; q < WAVE_BLOCKS; ++q) fill[q] = blk0 + q < n_blk ? blockfill[blk0 + q] : 0u;
@@ -1136,6 +1136,7 @@ constexpr int SX_THREADS = 256;
 constexpr int SX_WAVES = SX_THREADS / 64;
 constexpr u32 SX_STAGE = 2 * SX_BLOCK;  // per-wave LDS ring: two output blocks
 constexpr u32 SX_BIG = 16384;           // ranges at least this long go to the work list, in slices of this size
+constexpr u32 SX_RESERVE = 4;           // output blocks a wave reserves per atomic
 static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
 
 struct ExpandParams {
@@ -1158,9 +1159,10 @@ __device__ __forceinline__ u32 range_end(const u64* __restrict__ keys, u32 m, u3
     constexpr int G = 7;
     u64 pv[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) {
+    for (int k = 0; k < G; ++k) {  // unconditional loads (clamped index) so that all probes are in flight together
         const u64 pos = (u64)j + (1u << k);
-        pv[k] = pos < m ? keys[pos] : ~0ull;
+        const u64 v = keys[pos < m ? pos : (u64)m - 1u];
+        pv[k] = pos < m ? v : ~0ull;
     }
     u32 lo = j, hi = 0;
     bool found = false;
@@ -1207,11 +1209,19 @@ struct WaveStage {
     u64* buf;      // LDS ring, SX_STAGE slots
     u32 wp;        // pairs pushed so far (wave-uniform)
     u32 shard;
+    u64 next_k;    // blocks reserved from the shard's cursor and not yet used: [next_k, next_k + k_left)
+    u32 k_left;
     __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
         __builtin_amdgcn_wave_barrier();
-        u64 k = 0;
-        if (lane_id() == 0) k = atomicAdd(&p.shards[shard], 1ull);
-        const u64 g = (((u64)__builtin_amdgcn_readfirstlane((u32)(k >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)k)) * SX_SHARDS + shard;
+        if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
+            u64 k = 0;
+            if (lane_id() == 0) k = atomicAdd(&p.shards[shard], (u64)SX_RESERVE);
+            next_k = uniform_u64(k);
+            k_left = SX_RESERVE;
+        }
+        const u64 g = next_k * SX_SHARDS + shard;
+        ++next_k;
+        --k_left;
         if (g < p.out_blocks) {  // capacity is checked by the host afterwards (from the cursors)
 #pragma unroll
             for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
@@ -1241,13 +1251,15 @@ struct WaveStage {
 template <int KIND, bool FILT>
 __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
-    __shared__ u32 s_incl[SX_WAVES][64];
-    __shared__ uint4 s_rec[SX_WAVES][64];
+    constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
+    __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
+    __shared__ uint4 s_rec[SX_WAVES][64];  // owners with a non-empty range, compacted: {first candidate, id, code | depth << 8, lane}
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     const int w = (int)(threadIdx.x >> 6), lane = lane_id();
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
-    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS};
+    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u};
+    const u64 le_lane = (2ull << lane) - 1ull;  // bits 0..lane
     for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
         const u32 j = (u32)base + (u32)lane;
         u32 c = 0, idj = 0, cbdd = 0;
@@ -1269,29 +1281,49 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p)
                 c = 0;
             }
         }
+        const u64 nz = __ballot(c > 0);
+        if (nz == 0) continue;  // wave-uniform
+        const u32 n_nz = (u32)__popcll(nz);
         const u32 incl = wave_incl_scan_u32(c);
         const u32 total = __shfl(incl, 63, 64);
-        if (total == 0) continue;  // wave-uniform
-        s_incl[w][lane] = incl;
-        s_rec[w][lane] = make_uint4(incl - c, idj, cbdd, 0u);
-        __builtin_amdgcn_wave_barrier();
-        for (u32 b = 0; b < total; b += 64) {
-            const u32 k = b + (u32)lane;
-            const bool act = k < total;
-            const u32 kk = act ? k : total - 1u;
-            // owner = first lane whose inclusive sum exceeds kk
-            u32 o = 0;
-#pragma unroll
-            for (u32 stp = 32; stp > 0; stp >>= 1) {
-                if (s_incl[w][o + stp - 1u] <= kk) o += stp;
+        // The candidates of the 64 ranges, concatenated, are dealt to the lanes 64 per step.  Which
+        // owner a candidate belongs to = how many ranges end at or before it: every owner sets ONE
+        // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
+        // popcount and one 16-byte LDS read per lane -- no per-candidate search.
+        if (c > 0) s_rec[w][__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, cbdd, (u32)lane);
+        u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
+        for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
+            s_ends[w][lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            const u32 rel = incl - ss;  // this owner's range ends before candidate ss + rel
+            if (c > 0 && incl >= ss && rel < SUPER)
+                __hip_atomic_fetch_or(&s_ends[w][rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const u32 left = total - ss;
+            const u32 n_steps = left >= SUPER ? 64u : (left + 63u) >> 6;
+            // software pipeline: the {id, context} load of step b + 1 is in flight while step b is tested and pushed
+            struct Cand { u64 wi; u32 idj, cbdd; bool act; };
+            auto fetch = [&](u32 b) -> Cand {
+                const u64 e = uniform_u64(s_ends[w][b]);
+                const u32 k = ss + b * 64u + (u32)lane;
+                const bool act = k < total;
+                u32 ord = owners_done + (u32)__popcll(e & le_lane);
+                owners_done += (u32)__popcll(e);
+                if (!act) ord = n_nz - 1u;
+                const uint4 r = s_rec[w][ord];
+                const u32 i = (u32)base + r.w + 1u + ((act ? k : total - 1u) - r.x);
+                return Cand{p.idctx[i], r.y, r.z, act};
+            };
+            Cand cur = fetch(0);
+            for (u32 b = 0; b < n_steps; ++b) {
+                Cand nxt = cur;
+                if (b + 1 < n_steps) nxt = fetch(b + 1);
+                bool keep = cur.act && ctx_keep((u32)cur.wi, cur.cbdd & 63u, cur.cbdd >> 8);
+                if (FILT && keep)
+                    keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)cur.idj * (2 * FDIM));
+                st.push(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
+                cur = nxt;
             }
-            const uint4 r = s_rec[w][o];
-            const u32 i = (u32)base + o + 1u + (kk - r.x);
-            const u64 wi = p.idctx[i];
-            bool keep = act && ctx_keep((u32)wi, r.z & 63u, r.z >> 8);
-            if (FILT && keep)
-                keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)r.y * (2 * FDIM));
-            st.push(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)r.y, p);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1307,7 +1339,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     const int w = (int)(threadIdx.x >> 6);
     const u32 m = (u32)p.m;
     const u32 n_items = min(p.sc->big_count, p.big_cap);
-    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS};
+    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u};
     for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 item = p.big_list[it];
         const u32 j = (u32)item, slice = (u32)(item >> 32);
@@ -1835,8 +1867,26 @@ hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids,
     return hipGetLastError();
 }
 
+// resident workgroups of a persistent kernel = CUs x occupancy (queried once per kernel)
+template <typename Kern>
+static unsigned resident_blocks(Kern kernel, int threads) {
+    int dev = 0, cus = 256, per_cu = 4;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) == hipSuccess && nb > 0) per_cu = nb;
+    (void)hipGetLastError();
+    return (unsigned)(cus * per_cu);
+}
+
 template <int KIND>
-static hipError_t launch_scan_expand_kind(const ExpandParams& p, unsigned grid, hipStream_t stream) {
+static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream) {
+    static const unsigned res_plain = resident_blocks(scan_expand_kernel<KIND, false>, SX_THREADS);
+    static const unsigned res_filt = resident_blocks(scan_expand_kernel<KIND, true>, SX_THREADS);
+    const unsigned grid = (unsigned)std::min<size_t>(max_grid, p.filt_bounds ? res_filt : res_plain);
+    p.n_waves = grid * SX_WAVES;
     if (p.filt_bounds) {
         scan_expand_kernel<KIND, true><<<grid, SX_THREADS, 0, stream>>>(p);
         scan_expand_big_kernel<KIND, true><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
@@ -1850,17 +1900,17 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream) {
     if (m == 0) return hipSuccess;
-    // persistent waves: enough workgroups to fill the chip (7 per CU fit by LDS), never more than the work
+    // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
-    const unsigned grid = (unsigned)std::min<size_t>((chunks + SX_WAVES - 1) / SX_WAVES, 256 * 7);
+    const size_t max_grid = (chunks + SX_WAVES - 1) / SX_WAVES;
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
-    p.n_waves = grid * SX_WAVES; p.filt_bounds = filt_bounds;
+    p.n_waves = 0; p.filt_bounds = filt_bounds;
     switch (kind) {
-        case 0: return launch_scan_expand_kind<0>(p, grid, stream);
-        case 1: return launch_scan_expand_kind<1>(p, grid, stream);
-        default: return launch_scan_expand_kind<2>(p, grid, stream);
+        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream);
+        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream);
+        default: return launch_scan_expand_kind<2>(p, max_grid, stream);
     }
 }
 
