@@ -109,11 +109,13 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
-                      const uint32_t* blockfill = nullptr, size_t extent = 0);
+                      const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr);
 // blockfill / extent (key-only sorts): keys0 is the block-structured output of the expanding scan --
 // `extent` slots in blocks of SX_BLOCK, of which only the first blockfill[b] of block b hold a
 // record (n records in all).  The histogram and the first pass read around the holes; the result is
 // dense.  The workspace must be sized for `extent`.
+// ready_hist: n_passes x 256 digit counts of exactly this plan, already on the device (the expanding
+// scan counts them while it emits): the histogram kernel is skipped.
 
 // ---- multi-GPU bucketing: one stable one-sweep pass with a custom digit (<= 256 buckets) --------
 // entries -> owner rank by Morton cell at split_depth (lut on the device), coarse entries
@@ -179,11 +181,15 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 constexpr uint32_t SX_BLOCK = 256;
 constexpr int SX_SHARDS = 64;
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
+constexpr int SX_HIST_MAX = 4;      // digit histograms the scan can accumulate for the pair sort
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
-                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream);
+                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
+                              const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
+// hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
+// hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

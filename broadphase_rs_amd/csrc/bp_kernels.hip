@@ -1152,6 +1152,12 @@ struct ExpandParams {
     u32 big_cap;
     u32 n_waves;       // waves of the main kernel's grid (chunk stride)
     const float* filt_bounds;
+    // digit histograms of the emitted pairs for the sort that follows (saves its separate read of the
+    // stream): hist_passes <= SX_HIST_MAX rows of 256 u64 counters (zeroed by the host), row q counts
+    // digit (pair >> hist_shift[q]) & 255
+    u64* hist;
+    int hist_passes;
+    int hist_shift[SX_HIST_MAX];
 };
 
 // first index > j whose key is >= upper (m if none); keys[j] < upper
@@ -1211,6 +1217,7 @@ struct WaveStage {
     u32 shard;
     u64 next_k;    // blocks reserved from the shard's cursor and not yet used: [next_k, next_k + k_left)
     u32 k_left;
+    u32* hist;     // LDS, workgroup-wide: SX_HIST_MAX x 256 digit counters
     __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
         __builtin_amdgcn_wave_barrier();
         if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
@@ -1236,7 +1243,15 @@ struct WaveStage {
         const u64 mask = __ballot(keep);
         const u32 n = (u32)__popcll(mask);
         if (n == 0) return;
-        if (keep) buf[(wp + (u32)__popcll(mask & ((1ull << lane_id()) - 1ull))) & (SX_STAGE - 1u)] = pair;
+        if (keep) {
+            buf[(wp + (u32)__popcll(mask & ((1ull << lane_id()) - 1ull))) & (SX_STAGE - 1u)] = pair;
+#pragma unroll
+            for (int q = 0; q < SX_HIST_MAX; ++q) {
+                if (q < p.hist_passes)
+                    __hip_atomic_fetch_add(&hist[q * 256 + ((u32)(pair >> p.hist_shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         const u32 before = wp / SX_BLOCK;
         wp += n;
         if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
@@ -1248,6 +1263,18 @@ struct WaveStage {
     }
 };
 
+__device__ __forceinline__ void sx_hist_clear(u32* s_hist, const ExpandParams& p) {
+    for (int k = (int)threadIdx.x; k < p.hist_passes * 256; k += SX_THREADS) s_hist[k] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandParams& p) {
+    __syncthreads();
+    for (int k = (int)threadIdx.x; k < p.hist_passes * 256; k += SX_THREADS) {
+        const u32 c = s_hist[k];
+        if (c) atomicAdd(&p.hist[k], (u64)c);
+    }
+}
+
 template <int KIND, bool FILT>
 __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
@@ -1255,10 +1282,12 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p)
     __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
     __shared__ uint4 s_rec[SX_WAVES][64];  // owners with a non-empty range, compacted: {first candidate, id, code | depth << 8, lane}
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
+    __shared__ u32 s_hist[SX_HIST_MAX * 256];
+    sx_hist_clear(s_hist, p);
     const int w = (int)(threadIdx.x >> 6), lane = lane_id();
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
-    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u};
+    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist};
     const u64 le_lane = (2ull << lane) - 1ull;  // bits 0..lane
     for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
         const u32 j = (u32)base + (u32)lane;
@@ -1328,6 +1357,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p)
         __builtin_amdgcn_wave_barrier();
     }
     st.finish(p);
+    sx_hist_flush(s_hist, p);
 }
 
 // work-list slices of the long ranges: one slice per workgroup iteration
@@ -1335,11 +1365,14 @@ template <int KIND, bool FILT>
 __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
+    __shared__ u32 s_hist[SX_HIST_MAX * 256];
     __shared__ u32 s_end;
     const int w = (int)(threadIdx.x >> 6);
     const u32 m = (u32)p.m;
     const u32 n_items = min(p.sc->big_count, p.big_cap);
-    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u};
+    if (blockIdx.x >= n_items) return;  // workgroup-uniform: nothing on the list for this workgroup
+    sx_hist_clear(s_hist, p);
+    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u, s_hist};
     for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 item = p.big_list[it];
         const u32 j = (u32)item, slice = (u32)(item >> 32);
@@ -1366,6 +1399,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
         }
     }
     st.finish(p);
+    sx_hist_flush(s_hist, p);
 }
 
 // =================================================================================================
@@ -1697,7 +1731,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
-                      const uint32_t* blockfill, size_t extent) {
+                      const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist) {
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
@@ -1716,8 +1750,13 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     if (mark) mark(mark_ctx, class_hist);
     e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(extent, np), stream);
     if (e != hipSuccess) return e;
-    radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
-        (const u64*)keys0, vals0, extent, plan, hist, blockfill);
+    if (ready_hist) {  // the producer of the records already counted the digits of this plan
+        e = hipMemcpyAsync(hist, ready_hist, (size_t)np * RS_BINS * sizeof(u64), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    } else {
+        radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
+            (const u64*)keys0, vals0, extent, plan, hist, blockfill);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<np, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1898,7 +1937,8 @@ static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipSt
 }
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
-                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream) {
+                              uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
+                              const RadixPlan* hist_plan, unsigned long long* hist) {
     if (m == 0) return hipSuccess;
     // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
@@ -1907,6 +1947,12 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
     p.n_waves = 0; p.filt_bounds = filt_bounds;
+    p.hist = (u64*)hist; p.hist_passes = 0;
+    for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
+    if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
+        p.hist_passes = hist_plan->n_passes;
+        for (int q = 0; q < hist_plan->n_passes; ++q) p.hist_shift[q] = hist_plan->shift[q];
+    }
     switch (kind) {
         case 0: return launch_scan_expand_kind<0>(p, max_grid, stream);
         case 1: return launch_scan_expand_kind<1>(p, max_grid, stream);

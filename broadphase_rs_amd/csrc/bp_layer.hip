@@ -73,6 +73,9 @@ struct bp_layer {
     DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
     HostBuf h_shards;
     bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
+    DevBuf pair_hist;                   // digit counts of the raw stream, accumulated by the scan for pair_hist_plan
+    RadixPlan pair_hist_plan{};
+    bool pair_hist_valid = false;
     size_t raw_extent = 0;
     uint64_t epoch = 1;                 // bumped whenever the sorted tree's content may have changed
     uint64_t ctx_epoch = 0;             // epoch idctx was computed for (0: never), with ...
@@ -537,6 +540,27 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
 // sort + dedup of n packed pairs sitting in buf0 (scratch partner: L->pairs[1]) -> L->out_pairs
 // (interleaved), L->n_pairs
 int make_raw_dense(bp_layer* L);
+bool segment_finish_enabled() {
+    static const bool disabled = getenv("BP_NO_SEGMENT_FINISH") != nullptr;  // A/B switch
+    return !disabled;
+}
+// the plan the sort of a pair stream will use (distinct pairs: first id only, then segment finish)
+RadixPlan pair_sort_plan(unsigned long long varying, bool distinct) {
+    if (distinct && segment_finish_enabled()) {
+        const RadixPlan plan = make_radix_plan(varying & 0xFFFFFFFF00000000ull, 0, 0);
+        if (plan.n_passes > 0) return plan;
+    }
+    return make_radix_plan(varying, 0, 0);
+}
+// digit counts the scan left behind for exactly this plan (consumed by the first sort that asks)
+const unsigned long long* take_ready_hist(bp_layer* L, const RadixPlan& plan, bool holes) {
+    if (!L->pair_hist_valid) return nullptr;
+    L->pair_hist_valid = false;
+    if (!holes || plan.n_passes != L->pair_hist_plan.n_passes) return nullptr;
+    for (int i = 0; i < plan.n_passes; ++i)
+        if (plan.shift[i] != L->pair_hist_plan.shift[i] || plan.from_val[i] != L->pair_hist_plan.from_val[i]) return nullptr;
+    return (const unsigned long long*)L->pair_hist.p;
+}
 // holes: buf0 == pairs[0] holds the block-structured stream (L->blockfill, L->raw_extent)
 int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique = false,
                          bool holes = false);
@@ -545,10 +569,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 // equal-first-id segments in LDS while writing the ABI layout (3 passes + 1 kernel instead of
 // 6 passes + 1 kernel).  Falls back to the full-width sort when a segment is too long.
 int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes = false) {
-    static const bool disabled = getenv("BP_NO_SEGMENT_FINISH") != nullptr;  // A/B switch
     const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
     const RadixPlan plan = make_radix_plan(hi_var, 0, 0);
-    if (disabled || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
+    if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
     uint64_t* bufs[2] = {buf0, nullptr};
@@ -560,7 +583,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
         BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent));
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
     }
     BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
     {
@@ -601,7 +624,7 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
         BP_TRY(sc_reset(L));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent));
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
     } else {
         BP_TRY(sc_reset(L));
     }
@@ -652,12 +675,15 @@ int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_un
 // allow_holes: the caller's next step reads around the holes of the expanding scan's block-structured
 // output (sort_unique_pairs); otherwise pairs[0] is made dense before returning
 int make_raw_dense(bp_layer* L);
+// hist_plan: the radix plan of the pair sort that will follow (its digit histograms are then counted
+// by the scan itself and the sort skips its histogram kernel)
 int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup, const float* filt_bounds = nullptr,
-                      uint32_t filt_rows = 0, bool allow_holes = false) {
+                      uint32_t filt_rows = 0, bool allow_holes = false, const RadixPlan* hist_plan = nullptr) {
     BP_TRY(sort_tree(L));
     L->n_raw = 0;
     L->raw_is_unique = false;
     L->raw_holes = false;
+    L->pair_hist_valid = false;
     if (L->m == 0) return BP_OK;
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     ScanParams p;
@@ -700,13 +726,19 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
             HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
             HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+            const bool count_digits = allow_holes && hist_plan && hist_plan->n_passes > 0 && hist_plan->n_passes <= SX_HIST_MAX;
+            if (count_digits) {
+                BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+                HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+            }
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds,
                                               (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p,
                                               (uint64_t*)L->big_list.p,
                                               (uint32_t)std::min<size_t>(L->big_list.cap / sizeof(uint64_t), 0xFFFFFFFFu),
-                                              (DevScalars*)L->d_sc.p, L->stream));
+                                              (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
+                                              count_digits ? (unsigned long long*)L->pair_hist.p : nullptr));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
             DevScalars sc;
@@ -724,6 +756,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 L->stats.raw_pairs = L->n_raw;
                 L->raw_holes = true;
                 L->raw_extent = extent_blocks * SX_BLOCK;
+                if (count_digits) { L->pair_hist_plan = *hist_plan; L->pair_hist_valid = true; }
                 if (!allow_holes) BP_TRY(make_raw_dense(L));
                 return BP_OK;
             }
@@ -768,7 +801,11 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
     static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // A/B switches for measurements
     static const bool no_fused = getenv("BP_NO_FUSED_SCAN") != nullptr;
     if (L->ids_distinct && !no_fused) {
-        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true));
+        BP_TRY(sort_tree(L));  // settles box_valid, which decides whether the raw stream will be duplicate-free
+        const uint32_t idv = L->id_or ^ L->id_and;
+        const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv,
+                                              !no_source_dedup && L->box_valid && L->box_all_known);
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true, &plan));
         BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
@@ -1085,7 +1122,10 @@ static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_ro
         d_bounds = (const float*)L->in_bounds.p;
     }
     if (L->ids_distinct) {  // predicate evaluated inside the single-pass scan, before anything is sorted
-        BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows, true));
+        BP_TRY(sort_tree(L));
+        const uint32_t idv = L->id_or ^ L->id_and;
+        const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv, L->box_valid && L->box_all_known);
+        BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows, true, &plan));
         BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
