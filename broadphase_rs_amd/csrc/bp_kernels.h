@@ -67,6 +67,8 @@ struct SysBounds {
 
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
+constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_emit
+constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
 inline size_t enc_blocks(size_t n) { return (n + ENC_THREADS - 1) / ENC_THREADS; }
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
@@ -74,7 +76,10 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
                                unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream);
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
-                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream);
+                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
+                              const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
+// hist_plan / hist: also count the key digits of every emitted entry for the passes of hist_plan
+// (<= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller)
 
 // exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
 // partials are folded into *sc as well (single workgroup, no atomics)
@@ -88,6 +93,7 @@ hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* id
 // ---- radix sort (K4, K7): stands in for par_sort_unstable, src/layer.rs:149,516 ---------------
 constexpr int RS_BINS = 256;
 constexpr int RS_MAX_PASSES = 12;
+constexpr int SX_HIST_MAX = 4;      // digit histograms a producer kernel (encode, scan) can count for the sort that follows
 
 struct RadixPlan {
     int n_passes;
@@ -109,13 +115,15 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
-                      const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr);
+                      const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
+                      int ready_copies = 1);
 // blockfill / extent (key-only sorts): keys0 is the block-structured output of the expanding scan --
 // `extent` slots in blocks of SX_BLOCK, of which only the first blockfill[b] of block b hold a
 // record (n records in all).  The histogram and the first pass read around the holes; the result is
 // dense.  The workspace must be sized for `extent`.
 // ready_hist: n_passes x 256 digit counts of exactly this plan, already on the device (the expanding
-// scan counts them while it emits): the histogram kernel is skipped.
+// scan counts them while it emits): the histogram kernel is skipped.  ready_copies: the counts are spread
+// over that many arrays of SX_HIST_MAX x 256 u64 (summed here).
 
 // ---- multi-GPU bucketing: one stable one-sweep pass with a custom digit (<= 256 buckets) --------
 // entries -> owner rank by Morton cell at split_depth (lut on the device), coarse entries
@@ -181,7 +189,6 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 constexpr uint32_t SX_BLOCK = 256;
 constexpr int SX_SHARDS = 64;
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
-constexpr int SX_HIST_MAX = 4;      // digit histograms the scan can accumulate for the pair sort
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,

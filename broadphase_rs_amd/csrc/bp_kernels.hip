@@ -203,42 +203,82 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
     }
 }
 
+// digit histograms counted by a producer kernel for the radix sort that follows
+struct DigitCount {
+    u64* hist;       // [passes][256], zeroed by the host; nullptr / passes == 0: nothing to count
+    int passes;      // <= SX_HIST_MAX
+    int shift[SX_HIST_MAX];
+};
+
 template <int KIND>
 __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
                                                                  const u32* __restrict__ counts,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
-                                                                 uint8_t* __restrict__ box_out) {
+                                                                 uint8_t* __restrict__ box_out, DigitCount dc) {
     constexpr u32 DIM = KT<KIND>::DIM;
     __shared__ u32 s_ws[ENC_THREADS / 64];
-    const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
-    const u32 cnt = i < n ? counts[i] : 0u;
-    u32 total;
-    const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
-    if (cnt == 0) return;
-    const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
-    const u32 id = ids[i];
-    size_t pos = (size_t)block_offs[blockIdx.x] + excl;
-    if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
-        keys_out[pos] = 0ull;
-        ids_out[pos] = id;
-        if (box_out) box_out[pos] = 0;
-        return;
-    }
-    const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
-    // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
-    for (u32 z = 0; z < c.n[2]; ++z)
-        for (u32 y = 0; y < c.n[1]; ++y)
-            for (u32 x = 0; x < c.n[0]; ++x) {
-                keys_out[pos] = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
-                ids_out[pos] = id;
-                if (box_out) {
-                    const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
-                    box_out[pos] = boxy ? (uint8_t)(tx | (ty << 2) | (tz << 4)) : (uint8_t)BOX_UNKNOWN;
+    __shared__ u32 s_hist[SX_HIST_MAX * 256];
+    for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) s_hist[k] = 0;  // visible after the scan's barriers
+    auto count_digits = [&](u64 key) {
+#pragma unroll
+        for (int q = 0; q < SX_HIST_MAX; ++q) {
+            if (q < dc.passes)
+                __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(key >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup (block_offs is per block of ENC_THREADS objects)
+    for (int round = 0; round < ENC_ROUNDS; ++round) {
+        const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
+        if (blk * ENC_THREADS >= n) break;  // workgroup-uniform
+        const size_t i = blk * ENC_THREADS + threadIdx.x;
+        const u32 cnt = i < n ? counts[i] : 0u;
+        u32 total;
+        const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
+        if (cnt == 0) continue;
+        const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
+        const u32 id = ids[i];
+        size_t pos = (size_t)block_offs[blk] + excl;
+        if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
+            keys_out[pos] = 0ull;
+            ids_out[pos] = id;
+            if (box_out) box_out[pos] = 0;
+            count_digits(0ull);
+            continue;
+        }
+        const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
+        // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
+        for (u32 z = 0; z < c.n[2]; ++z)
+            for (u32 y = 0; y < c.n[1]; ++y)
+                for (u32 x = 0; x < c.n[0]; ++x) {
+                    const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
+                    keys_out[pos] = key;
+                    ids_out[pos] = id;
+                    if (box_out) {
+                        const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
+                        box_out[pos] = boxy ? (uint8_t)(tx | (ty << 2) | (tz << 4)) : (uint8_t)BOX_UNKNOWN;
+                    }
+                    count_digits(key);
+                    ++pos;
                 }
-                ++pos;
-            }
+    }
+    if (dc.passes) {  // workgroup-uniform.  One device atomic per bin per workgroup would serialise on the bin's
+        __syncthreads();  // address (~11 ns each): the workgroups spread over HIST_COPIES copies, summed by the sort
+        u64* copy = dc.hist + (size_t)(blockIdx.x % HIST_COPIES) * (SX_HIST_MAX * 256);
+        for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) {
+            const u32 v = s_hist[k];
+            if (v) atomicAdd(&copy[k], (u64)v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RS_BINS) void hist_reduce_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist) {
+    const size_t k = (size_t)blockIdx.x * RS_BINS + threadIdx.x;  // blockIdx.x = pass
+    u64 t = 0;
+    for (int c = 0; c < n_copies; ++c) t += copies[(size_t)c * (SX_HIST_MAX * 256) + k];
+    hist[k] = t;
 }
 
 // single-workgroup exclusive scan of per-block sums; folds the encode partials into *sc
@@ -1651,11 +1691,23 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
-                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream) {
+                              uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
+                              const RadixPlan* hist_plan, unsigned long long* hist) {
     if (n == 0) return hipSuccess;
-    const unsigned g = (unsigned)enc_blocks(n);
+    const unsigned g = (unsigned)((enc_blocks(n) + ENC_ROUNDS - 1) / ENC_ROUNDS);
+    DigitCount dc;
+    dc.hist = (u64*)hist; dc.passes = 0;
+    for (int q = 0; q < SX_HIST_MAX; ++q) dc.shift[q] = 0;
+    if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
+        bool key_digits_only = true;
+        for (int q = 0; q < hist_plan->n_passes; ++q) key_digits_only = key_digits_only && !hist_plan->from_val[q];
+        if (key_digits_only) {
+            dc.passes = hist_plan->n_passes;
+            for (int q = 0; q < hist_plan->n_passes; ++q) dc.shift[q] = hist_plan->shift[q];
+        }
+    }
     BP_DISPATCH_KIND(kind, (encode_emit_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                 block_offs, (u64*)keys_out, ids_out, box_out)));
+                                                                                 block_offs, (u64*)keys_out, ids_out, box_out, dc)));
     return hipGetLastError();
 }
 
@@ -1731,7 +1783,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
-                      const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist) {
+                      const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies) {
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
@@ -1751,8 +1803,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(extent, np), stream);
     if (e != hipSuccess) return e;
     if (ready_hist) {  // the producer of the records already counted the digits of this plan
-        e = hipMemcpyAsync(hist, ready_hist, (size_t)np * RS_BINS * sizeof(u64), hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return e;
+        hist_reduce_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist);
     } else {
         radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
             (const u64*)keys0, vals0, extent, plan, hist, blockfill);

@@ -73,6 +73,10 @@ struct bp_layer {
     DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
     HostBuf h_shards;
     bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
+    DevBuf tree_hist;                   // digit counts of the tree's keys, accumulated by encode for tree_hist_plan ...
+    RadixPlan tree_hist_plan{};
+    bool tree_hist_valid = false;       // ... while the tree is exactly what that one extend produced (m == tree_hist_m)
+    size_t tree_hist_m = 0;
     DevBuf pair_hist;                   // digit counts of the raw stream, accumulated by the scan for pair_hist_plan
     RadixPlan pair_hist_plan{};
     bool pair_hist_valid = false;
@@ -301,6 +305,8 @@ int ensure_unpacked(bp_layer* L) {
     return BP_OK;
 }
 
+bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, int* seg_shift_out);
+
 // ---- extend -------------------------------------------------------------------------------------------
 int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const float* d_bounds,
                   const uint32_t* d_ids, size_t n) {
@@ -342,12 +348,25 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     L->min_id = std::min(L->min_id, sc.id_min);
     if (add == 0) return BP_OK;
     BP_TRY(ensure_tree_capacity(L, L->m + add));
+    // first extend into an empty tree (the per-frame pattern): the plan of the coming tree sort is
+    // already known, so encode counts its digit histograms while the keys are in registers
+    RadixPlan hist_plan;
+    int seg_shift_unused = 0;
+    const bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
+                              hist_plan.n_passes <= SX_HIST_MAX;
+    L->tree_hist_valid = false;
+    if (count_digits) {
+        BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+        HIP_TRY(L, hipMemsetAsync(L->tree_hist.p, 0, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+    }
     {
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
-                                      (uint8_t*)L->box[L->cur].p + L->m, L->stream));
+                                      (uint8_t*)L->box[L->cur].p + L->m, L->stream, count_digits ? &hist_plan : nullptr,
+                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr));
     }
+    if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
     BP_TRY(sync_stream(L));
     L->m += add;
     L->sorted = false;  // src/layer.rs:119 (at least one valid object was appended)
@@ -412,27 +431,42 @@ int sort_tree_full(bp_layer* L, bool payload_already_packed) {
     return BP_OK;
 }
 
+// Partial tree sort: radix passes over the top key bits only, enough that the groups of equal prefix
+// hold ~4 entries on average; the groups are then rank-sorted by (key, id) in LDS.  Returns false
+// when the full-width sort should run instead.
+bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, int* seg_shift_out) {
+    static const bool no_finish = getenv("BP_NO_TREE_FINISH") != nullptr;  // A/B switch for measurements
+    const int top = varying ? 64 - __builtin_clzll(varying) : 0;
+    int want_bits = 8;
+    while (want_bits < 56 && ((unsigned long long)m >> (want_bits + 2)) != 0) want_bits += 8;
+    const int n_part = want_bits / 8;
+    const int seg_shift = top - 8 * n_part;
+    if (no_finish || m < 4096 || seg_shift <= 0 || (varying & ((1ull << seg_shift) - 1ull)) == 0) return false;
+    plan->n_passes = n_part;
+    for (int i = 0; i < RS_MAX_PASSES; ++i) { plan->shift[i] = 0; plan->from_val[i] = 0; }
+    for (int i = 0; i < n_part; ++i) plan->shift[i] = seg_shift + 8 * i;
+    *seg_shift_out = seg_shift;
+    return true;
+}
+bool same_plan(const RadixPlan& a, const RadixPlan& b) {
+    if (a.n_passes != b.n_passes) return false;
+    for (int i = 0; i < a.n_passes; ++i)
+        if (a.shift[i] != b.shift[i] || a.from_val[i] != b.from_val[i]) return false;
+    return true;
+}
+
 int sort_tree(bp_layer* L) {
     if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
     ++L->epoch;
-    static const bool no_finish = getenv("BP_NO_TREE_FINISH") != nullptr;  // A/B switch for measurements
     L->stats.tree_sort_passes = 0;
     if (L->m > 1) {
         const unsigned long long varying = L->key_or ^ L->key_and;
-        // Partial sort: radix passes over the top key bits only, enough that the groups of equal
-        // prefix hold ~4 entries on average; the groups are then rank-sorted by (key, id) in LDS.
-        int top = varying ? 64 - __builtin_clzll(varying) : 0;
-        int want_bits = 8;
-        while (want_bits < 56 && ((unsigned long long)L->m >> (want_bits + 2)) != 0) want_bits += 8;
-        const int n_part = want_bits / 8;
-        const int seg_shift = top - 8 * n_part;
-        const bool partial = !no_finish && L->m >= 4096 && seg_shift > 0 && (varying & ((1ull << seg_shift) - 1ull)) != 0;
+        RadixPlan plan;
+        int seg_shift = 0;
+        const bool partial = tree_partial_plan(L->m, varying, &plan, &seg_shift);
         bool done = false;
         if (partial) {
-            RadixPlan plan;
-            plan.n_passes = n_part;
-            for (int i = 0; i < RS_MAX_PASSES; ++i) { plan.shift[i] = 0; plan.from_val[i] = 0; }
-            for (int i = 0; i < n_part; ++i) plan.shift[i] = seg_shift + 8 * i;
+            const int n_part = plan.n_passes;
             L->stats.tree_sort_passes = (uint32_t)n_part;
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
@@ -446,9 +480,13 @@ int sort_tree(bp_layer* L) {
             uint64_t* kb[2] = {(uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p};
             uint32_t* vb[2] = {(uint32_t*)L->ids[L->cur].p, (uint32_t*)L->ids[other].p};
             // first pass packs the box codes into the payload; the finish kernel splits them off again
+            // digit counts left behind by encode_emit, if the tree is still exactly that extend's output
+            const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(plan, L->tree_hist_plan);
+            L->tree_hist_valid = false;
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
-                                  (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr));
+                                  (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
+                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES));
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             {
@@ -910,6 +948,7 @@ int bp_layer_destroy(bp_layer_t* L) {
 
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
+    L->tree_hist_valid = false;
     L->m = 0;
     L->sorted = true;  // src/layer.rs:84-88
     reset_tree_facts(L);
@@ -964,6 +1003,7 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
     L->box_all_known = false;
     BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
+    L->tree_hist_valid = false;
     L->m += m;
     L->sorted = false;
     L->stats.entries = L->m;
@@ -1016,7 +1056,8 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
             L->min_id = std::min(L->min_id, other->min_id);
             L->have_ids = L->have_ids || other->have_ids;
         }
-        L->m += m;
+        L->tree_hist_valid = false;
+    L->m += m;
     }
     L->sorted = false;  // unconditional: src/layer.rs:137
     L->stats.entries = L->m;
@@ -1239,6 +1280,7 @@ int bp_layer_commit_entries(bp_layer_t* L, size_t m, const bp_facts* f) {
     if (L->m != 0) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: call bp_layer_begin_entries first");
     if (m * sizeof(uint64_t) > L->keys[L->cur].cap) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: more entries than begun");
     if (m == 0) return BP_OK;
+    L->tree_hist_valid = false;
     L->m = m;
     L->sorted = false;
     L->stats.entries = m;
