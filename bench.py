@@ -193,11 +193,11 @@ def main():
         # duplicate suppression at the source it equals P.
         model = {
             "encode": 64.0 * n + 13.0 * M,                    # bounds+ids read twice, counts w+r, entries + box written
-            "tree_hist": 8.0 * M,
+            "tree_hist": 0.0,                                 # digits are counted inside encode_emit
             "tree_sort": 24.0 * M * pk + 25.0 * M,            # key+id per pass (r+w) + finish (12 r + 13 w)
-            "scan_count": 12.0 * M,
-            "scan_emit": 13.0 * M + 8.0 * P_raw,              # keys, ids, box read; packed pairs written
-            "pair_hist": 8.0 * P_raw,
+            "scan_count": 21.0 * M,                           # entry_ctx: key, id, box read; {id, context} word written
+            "scan_emit": 16.0 * M + 8.0 * P_raw,              # scan_expand: keys + {id, context} words read; packed pairs written
+            "pair_hist": 0.0,                                 # digits are counted inside the scan
             "pair_sort": 16.0 * P_raw * pp,
             "dedup": 16.0 * P_raw,                            # finish / unique: pairs read, ABI layout written
             "misc": 0.0,
@@ -210,10 +210,11 @@ def main():
         # dominant kernel = the kernel (by name) with the largest time per step.  Radix passes are
         # timed per launch, so a class total is launches x one kernel; the scan is a single launch.
         cand = {
-            "scan_fused_kernel (overlap scan, single pass)": ("scan_emit", 1.0, model["scan_emit"]),
+            "scan_expand_kernel (overlap scan, single pass)": ("scan_emit", 1.0, model["scan_emit"]),
+            "segment_finish_kernel (pair segments -> final list)": ("dedup", 1.0, model["dedup"]),
             "radix_onesweep_kernel<u64,NoVal> (pair-sort pass)": ("pair_sort", max(launches["pair_sort"], 1.0), 16.0 * P_raw),
         }
-        dom_name = max(cand, key=lambda k: per_step_ms[cand[k][0]])
+        dom_name = max(cand, key=lambda k: per_step_ms[cand[k][0]] / cand[k][1])  # largest time per LAUNCH
         dom_cls, dom_launches, bytes_per_launch = cand[dom_name]
         per_launch_ms = per_step_ms[dom_cls] / dom_launches
         achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
@@ -249,7 +250,7 @@ def main():
         # KiB, the guide's gfx950 correction); null when no such profile has been committed
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            key = "scan_fused_kernel" if dom_cls == "scan_emit" else "radix_onesweep_kernel<u64, NoVal"
+            key = {"scan_emit": "scan_expand_kernel", "dedup": "segment_finish_kernel"}.get(dom_cls, "radix_onesweep_kernel<u64, NoVal")
             hit = [v for k, v in tj.get("bytes_per_launch", {}).items() if k.startswith(key)]
             if hit and tj.get("objects") == n:
                 line["roofline"]["traffic"] = hit[0]

@@ -135,8 +135,10 @@ hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const 
 // ids[i] = packed & BOX_ID_MASK, box[i] = packed >> BOX_ID_BITS (in place on ids)
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream);
 // packed pairs -> owner rank of the first id; bounds[i] = first id owned by rank i+1
+// blockfill != nullptr: `in` is the block-structured output of the expanding scan (n = its extent, n_out records exist)
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
-                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream);
+                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream,
+                           const uint32_t* blockfill = nullptr, size_t n_out = 0);
 // entries per cell at split_depth; slot n_cells counts the coarse entries
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                             uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream);

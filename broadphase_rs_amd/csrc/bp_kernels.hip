@@ -433,12 +433,14 @@ __global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __r
 // one digit histogram with an arbitrary digit functor (partition passes)
 template <typename DigitFn>
 __global__ __launch_bounds__(HIST_THREADS) void digit_hist_kernel(const u64* __restrict__ keys, size_t n, DigitFn digit,
-                                                                  u64* __restrict__ hist) {
+                                                                  u64* __restrict__ hist, const u32* __restrict__ blockfill) {
     __shared__ u32 h[RS_BINS];
     for (int j = threadIdx.x; j < RS_BINS; j += HIST_THREADS) h[j] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS)
+    for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS) {
+        if (blockfill && (u32)(i & (HOLE_BLOCK - 1u)) >= blockfill[uniform_u32((u32)(i / HOLE_BLOCK))]) continue;  // hole
         atomicAdd(&h[digit(keys[i])], 1u);
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < RS_BINS; j += HIST_THREADS) {
         const u32 c = h[j];
@@ -1845,7 +1847,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
 template <typename V, typename DigitFn>
 static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, size_t n, DigitFn fn, void* workspace,
                                  size_t workspace_bytes, DevScalars* sc, const u64** d_hist, hipStream_t stream,
-                                 const uint8_t* box_in = nullptr) {
+                                 const uint8_t* box_in = nullptr, const u32* blockfill = nullptr, size_t n_out = 0) {
+    // blockfill: ki is block-structured (n = extent, n_out = records that exist); the output is dense
     if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (radix_workspace_bytes(n, 1) > workspace_bytes) return hipErrorInvalidValue;
     unsigned char* ws = (unsigned char*)workspace;
@@ -1857,11 +1860,11 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
     if (e != hipSuccess) return e;
     *d_hist = hist;
     if (n == 0) return hipSuccess;
-    digit_hist_kernel<DigitFn><<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(ki, n, fn, hist);
+    digit_hist_kernel<DigitFn><<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(ki, n, fn, hist, blockfill);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<1, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr);
+    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr, blockfill, n_out);
 }
 
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
@@ -1887,12 +1890,13 @@ hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t s
 }
 
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
-                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream) {
+                           size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream,
+                           const uint32_t* blockfill, size_t n_out) {
     PairOwnerDigit fn;
     fn.n = n_bounds;
     for (int i = 0; i < 15; ++i) fn.bounds[i] = i < n_bounds ? bounds[i] : 0xFFFFFFFFu;
     return partition_pass<NoVal, PairOwnerDigit>((const u64*)in, (u64*)out, (const NoVal*)nullptr, (NoVal*)nullptr, n, fn, workspace,
-                                                 workspace_bytes, sc, (const u64**)d_hist, stream);
+                                                 workspace_bytes, sc, (const u64**)d_hist, stream, nullptr, blockfill, n_out);
 }
 
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,

@@ -1409,31 +1409,59 @@ int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uin
     return BP_OK;
 }
 
-int bp_layer_partition_pairs_device(bp_layer_t* L, const uint64_t* d_packed, size_t n, const uint32_t* bounds, uint32_t n_bounds,
-                                    uint64_t* counts, const uint64_t** d_out) {
-    if (!L || !counts || !d_out || (n && !d_packed) || (n_bounds && !bounds) || n_bounds > 15)
-        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_pairs: bad argument");
-    DeviceGuard g(L->device);
+namespace {
+// n records at d_packed (block-structured when holes: extent slots, L->blockfill) -> grouped by owner rank
+int partition_pairs_impl(bp_layer* L, const uint64_t* d_packed, size_t n, bool holes, const uint32_t* bounds, uint32_t n_bounds,
+                         uint64_t* counts, const uint64_t** d_out) {
     for (uint32_t i = 0; i <= n_bounds; ++i) counts[i] = 0;
     // write into whichever pair buffer is not the input
     DevBuf& dst = (d_packed == (const uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];
     BP_TRY(ensure_dev(L, dst, std::max<size_t>(n, 1) * sizeof(uint64_t)));
     *d_out = (const uint64_t*)dst.p;
     if (n == 0) return BP_OK;
-    BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(n, 1)));
+    const size_t extent = holes ? L->raw_extent : n;
+    BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, 1)));
     BP_TRY(ensure_host(L, L->h_raw, 256 * sizeof(unsigned long long)));
     BP_TRY(sc_reset(L));
     const unsigned long long* d_hist = nullptr;
     {
         ProfScope ps(L, BP_K_MISC);
-        HIP_TRY(L, partition_pairs(d_packed, (uint64_t*)dst.p, n, bounds, (int)n_bounds, L->radix_ws.p, L->radix_ws.cap,
-                                   (DevScalars*)L->d_sc.p, &d_hist, L->stream));
+        HIP_TRY(L, partition_pairs(d_packed, (uint64_t*)dst.p, extent, bounds, (int)n_bounds, L->radix_ws.p, L->radix_ws.cap,
+                                   (DevScalars*)L->d_sc.p, &d_hist, L->stream, holes ? (const uint32_t*)L->blockfill.p : nullptr, n));
     }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));
     for (uint32_t i = 0; i <= n_bounds; ++i) counts[i] = ((const unsigned long long*)L->h_raw.p)[i];
     return BP_OK;
+}
+}  // namespace
+
+int bp_layer_partition_pairs_device(bp_layer_t* L, const uint64_t* d_packed, size_t n, const uint32_t* bounds, uint32_t n_bounds,
+                                    uint64_t* counts, const uint64_t** d_out) {
+    if (!L || !counts || !d_out || (n && !d_packed) || (n_bounds && !bounds) || n_bounds > 15)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_pairs: bad argument");
+    DeviceGuard g(L->device);
+    return partition_pairs_impl(L, d_packed, n, false, bounds, n_bounds, counts, d_out);
+}
+
+int bp_layer_scan_shard_partition_device(bp_layer_t* L, uint32_t coarse_depth, int emit_coarse, const uint32_t* bounds,
+                                         uint32_t n_bounds, uint64_t* counts, const uint64_t** d_out, size_t* n_raw, int* unique) {
+    if (!L || !counts || !d_out || !n_raw || !unique || (n_bounds && !bounds) || n_bounds > 15)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_shard_partition: bad argument");
+    DeviceGuard g(L->device);
+    if (L->ids_distinct) {
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, true, nullptr, 0, /*allow_holes=*/true));
+    } else {
+        BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
+        BP_TRY(sync_stream(L));
+        L->raw_is_unique = false;
+    }
+    *n_raw = L->n_raw;
+    *unique = L->raw_is_unique ? 1 : 0;
+    const bool holes = L->raw_holes;
+    L->raw_holes = false;  // consumed here: the partition pass reads around the holes
+    return partition_pairs_impl(L, (const uint64_t*)L->pairs[0].p, L->n_raw, holes, bounds, n_bounds, counts, d_out);
 }
 
 int bp_layer_sort_unique_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask,

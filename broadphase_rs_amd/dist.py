@@ -116,6 +116,11 @@ class HipBackend:
         counts, out = self.shard.partition_pairs_device(packed.data_ptr(), int(packed.numel()), bounds)
         return counts, out.as_torch()
 
+    def shard_scan_partition(self, coarse_depth, emit_coarse, bounds):
+        """shard_scan_pairs + partition_pairs in one device step -> (counts, grouped pairs, unique flag)"""
+        counts, out, unique = self.shard.scan_shard_partition_device(coarse_depth, emit_coarse, bounds)
+        return counts, out.as_torch(), unique
+
     def sort_unique_packed(self, packed, varying_mask, already_unique=False):
         if already_unique:
             return self.shard.sort_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
@@ -327,20 +332,28 @@ class ShardedLayer:
         lap("shard_commit")
         # 4. local sort + scan (single pass); coarse-coarse pairs only once.  With box codes every pair
         #    is emitted by exactly one entry on exactly one rank, so no duplicate ever crosses the wire.
-        raw, unique = be.shard_scan_pairs(d_s, self.rank == 0)
-        lap("sort_and_scan")
-        # the final step may skip dedup only if EVERY rank suppressed its duplicates at the source
-        # (one tiny all-reduce: a wrong assumption here would corrupt the result, not just slow it)
-        unique = comm.all_reduce_max(0 if (unique and pack and all_known) else 1, be) == 0
-        # 5. raw pairs -> owner of the first id, then sort + dedup per id range
+        #    The raw pairs go straight to the owner of their first id (5.): scan and bucketing are one
+        #    backend step where the backend can fuse them.
         if self.n_global is not None:
             max_id = int(self.n_global) - 1
         else:
             max_id = max(comm.all_reduce_max(self.max_id_local, be), 0)
         bounds = id_range_bounds(max_id, G)
-        pcounts, grouped = be.partition_pairs(raw, bounds)
-        lap("partition_pairs")
-        pm = comm.all_gather_counts(pcounts, be)
+        if hasattr(be, "shard_scan_partition"):
+            pcounts, grouped, unique = be.shard_scan_partition(d_s, self.rank == 0, bounds)
+            lap("sort_scan_partition")
+        else:
+            raw, unique = be.shard_scan_pairs(d_s, self.rank == 0)
+            lap("sort_and_scan")
+            pcounts, grouped = be.partition_pairs(raw, bounds)
+            lap("partition_pairs")
+        n_raw = int(np.asarray(pcounts).sum())
+        # the final step may skip dedup only if EVERY rank suppressed its duplicates at the source (a
+        # wrong assumption here would corrupt the result, not just slow it): the flag rides with the counts
+        mine = 0 if (unique and pack and all_known) else 1
+        pm_f = comm.all_gather_counts(list(np.asarray(pcounts, dtype=np.int64)) + [mine], be)
+        pm = pm_f[:, :G]
+        unique = bool(np.all(pm_f[:, G] == 0))
         comm._global_max_hint = int(pm.max())
         rp = comm.all_to_all_v(grouped, pcounts, torch.int64, be, pm[:, self.rank])
         comm._global_max_hint = None
@@ -351,7 +364,7 @@ class ShardedLayer:
         out = be.sort_unique_packed(rp, varying, unique)
         lap("sort_pairs")
         self.last = {"entries_local": int(counts.sum()), "entries_shard": n_recv + n_coarse,
-                     "coarse": n_coarse, "raw_pairs": int(raw.numel()), "raw_pairs_recv": int(rp.numel()),
+                     "coarse": n_coarse, "raw_pairs": n_raw, "raw_pairs_recv": int(rp.numel()),
                      "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique),
                      "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
         return out

@@ -73,7 +73,8 @@ EXPORTS = [
     "bp_layer_scan_shard_device", "bp_layer_sort_unique_pairs_device", "bp_layer_stats",
     "bp_layer_profile_enable", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
-    "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_sort_unique_packed_device",
+    "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
+    "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
     "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
@@ -179,6 +180,8 @@ def load_library():
     L.bp_layer_scan_filtered_aabb.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_scan_filtered_aabb_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_partition_pairs_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_uint32, u64p, C.POINTER(vp)]
+    L.bp_layer_scan_shard_partition_device.argtypes = [vp, C.c_uint32, C.c_int, u32p, C.c_uint32, u64p, C.POINTER(vp),
+                                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.bp_layer_sort_unique_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.bp_layer_profile_enable.argtypes = [vp, C.c_int]
@@ -501,6 +504,16 @@ class Layer:
         self._check(self._L.bp_layer_scan_shard_pairs_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
                                                              C.byref(n), C.byref(u)))
         return DeviceArray(p.value, (n.value,), np.uint64, self), bool(u.value)
+
+    def scan_shard_partition_device(self, coarse_depth, emit_coarse, bounds):
+        """scan + bucketing of the raw pairs by owner of the first id -> (counts, grouped packed pairs, unique flag)"""
+        bounds = np.ascontiguousarray(bounds, dtype=np.uint32)
+        counts = np.zeros(len(bounds) + 1, dtype=np.uint64)
+        out, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._check(self._L.bp_layer_scan_shard_partition_device(
+            self._h, coarse_depth, 1 if emit_coarse else 0, bounds.ctypes.data_as(C.POINTER(C.c_uint32)), len(bounds),
+            counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(out), C.byref(n), C.byref(u)))
+        return counts, DeviceArray(out.value, (n.value,), np.uint64, self), bool(u.value)
 
     def sort_packed_device(self, packed_ptr, n, varying_mask=0):
         p, m = C.c_void_p(), C.c_size_t()

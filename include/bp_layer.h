@@ -201,6 +201,12 @@ int bp_layer_scan_shard_pairs_device(bp_layer_t *layer, uint32_t coarse_depth, i
  * rank i + 1 (n_bounds <= 15); counts[n_bounds + 1] (host) */
 int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed, size_t n, const uint32_t *bounds,
                                     uint32_t n_bounds, uint64_t *counts, const uint64_t **d_out);
+/* bp_layer_scan_shard_pairs_device + bp_layer_partition_pairs_device in one step (the partition pass
+ * reads the scan's block-structured output directly, no dense intermediate): *d_out = *n_raw packed
+ * pairs grouped by owner rank, counts[n_bounds + 1] (host) */
+int bp_layer_scan_shard_partition_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse, const uint32_t *bounds,
+                                         uint32_t n_bounds, uint64_t *counts, const uint64_t **d_out, size_t *n_raw,
+                                         int *unique);
 /* sort + dedup n packed pairs in device memory (d_packed is used as scratch and clobbered);
  * varying_mask: bits that may differ between the pairs (0 = all 64) */
 int bp_layer_sort_unique_packed_device(bp_layer_t *layer, uint64_t *d_packed, size_t n, uint64_t varying_mask,
