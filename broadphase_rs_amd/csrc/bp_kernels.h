@@ -219,9 +219,24 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
 // by first id (segments in arbitrary internal order); every segment is rank-sorted by second id
 // inside an LDS window and written in the ABI layout.  Sets KERR_SEGMENT_TOO_LONG in sc->err when a
 // segment does not fit the window (the caller then falls back to the full-width sort).
+// window geometry (elements per workgroup + halo on each side), pairs / tree; small windows win: the
+// kernels are latency-bound and LDS per workgroup sets the occupancy
+#ifndef SEGP_CHUNK_DEF
+#define SEGP_CHUNK_DEF 2048
+#endif
+#ifndef SEGP_HALO_DEF
+#define SEGP_HALO_DEF 128
+#endif
+#ifndef SEGT_CHUNK_DEF
+#define SEGT_CHUNK_DEF 1024
+#endif
+#ifndef SEGT_HALO_DEF
+#define SEGT_HALO_DEF 128
+#endif
 constexpr int SEG_THREADS = 256;
-constexpr int SEG_CHUNK = 2048;
-constexpr int SEG_HALO = 512;
+constexpr int SEGP_CHUNK = SEGP_CHUNK_DEF, SEGP_HALO = SEGP_HALO_DEF;   // segment_finish
+constexpr int SEGT_CHUNK = SEGT_CHUNK_DEF, SEGT_HALO = SEGT_HALO_DEF;   // tree_segment_finish
+constexpr int SEG_SLOW_MAX = 4096;  // longest group the finish kernels rank straight from HBM before giving up
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
 
 // Finishing step of the tree sort after radix passes on the high key bits only: entries are grouped

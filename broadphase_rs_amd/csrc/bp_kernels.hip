@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(UQ_THREADS) void unique_emit_kernel(const u64* __re
 
 __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* __restrict__ in, size_t n,
                                                                       uint2* __restrict__ out, DevScalars* sc) {
+    constexpr int SEG_CHUNK = SEGP_CHUNK, SEG_HALO = SEGP_HALO;
     constexpr int WIN = SEG_HALO + SEG_CHUNK + SEG_HALO;
     constexpr int GROUPS = WIN / 64;
     __shared__ u64 s_win[WIN];
@@ -1540,9 +1541,23 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* 
             while (gg < ngroups && s_heads[gg] == 0) ++gg;
             end = gg < ngroups ? gg * 64u + (u32)__builtin_ctzll(s_heads[gg]) : wlen;
         }
-        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) too_long = true;  // may leave the window
-        u32 rank = 0;
         const u32 vb = (u32)v;
+        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) {
+            // the segment may leave the window (rare): bounds by bisection on the whole array, rank straight from HBM
+            const u32 fid = (u32)(v >> 32);
+            size_t lo = 0, hi = win_lo + x;  // first element with first id >= fid
+            while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if ((u32)(in[mid] >> 32) < fid) lo = mid + 1; else hi = mid; }
+            const size_t gs = lo;
+            lo = win_lo + x + 1; hi = n;     // first element with first id > fid
+            while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if ((u32)(in[mid] >> 32) <= fid) lo = mid + 1; else hi = mid; }
+            const size_t ge = lo;
+            if (ge - gs > (size_t)SEG_SLOW_MAX) { too_long = true; continue; }
+            u32 rank = 0;
+            for (size_t y = gs; y < ge; ++y) rank += (u32)in[y] < vb ? 1u : 0u;
+            out[gs + rank] = make_uint2(fid, vb);
+            continue;
+        }
+        u32 rank = 0;
         const u32* s_lo = reinterpret_cast<const u32*>(s_win);  // low dword = second id (first ids are equal)
         for (u32 y = start; y < end; ++y) rank += s_lo[2 * y] < vb ? 1u : 0u;  // independent LDS reads
         out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
@@ -1555,6 +1570,7 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
                                                                            const u32* __restrict__ ids_in, size_t n, int seg_shift,
                                                                            u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                            uint8_t* __restrict__ box_out, DevScalars* sc) {
+    constexpr int SEG_CHUNK = SEGT_CHUNK, SEG_HALO = SEGT_HALO;
     constexpr int WIN = SEG_HALO + SEG_CHUNK + SEG_HALO;
     constexpr int GROUPS = WIN / 64;
     __shared__ u64 s_key[WIN];
@@ -1607,7 +1623,30 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
             while (gg < ngroups && s_heads[gg] == 0) ++gg;
             end = gg < ngroups ? gg * 64u + (u32)__builtin_ctzll(s_heads[gg]) : wlen;
         }
-        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) too_long = true;
+        if ((start == 0 && win_lo > 0) || (end == wlen && win_hi < n)) {
+            // the group may leave the window (rare): bounds by bisection on the whole array, rank straight from HBM
+            const u64 gk = kx >> seg_shift;
+            const size_t self = win_lo + x;
+            size_t lo = 0, hi = self;
+            while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if ((keys_in[mid] >> seg_shift) < gk) lo = mid + 1; else hi = mid; }
+            const size_t gs = lo;
+            lo = self + 1; hi = n;
+            while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if ((keys_in[mid] >> seg_shift) <= gk) lo = mid + 1; else hi = mid; }
+            const size_t ge = lo;
+            if (ge - gs > (size_t)SEG_SLOW_MAX) { too_long = true; continue; }
+            u32 rank = 0;
+            for (size_t y = gs; y < ge; ++y) {
+                const u64 ky = keys_in[y];
+                const u32 iy = PACKED ? (ids_in[y] & BOX_ID_MASK) : ids_in[y];
+                const bool less = ky < kx || (ky == kx && (iy < ix || (iy == ix && y < self)));
+                rank += less ? 1u : 0u;
+            }
+            const size_t dst = gs + rank;
+            keys_out[dst] = kx;
+            ids_out[dst] = ix;
+            if (PACKED) box_out[dst] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
+            continue;
+        }
         u32 rank = 0;
         for (u32 y = start; y < end; ++y) {  // order: key, then id, then input position (exact duplicates)
             const u64 ky = s_key[y];
@@ -2055,7 +2094,7 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
 
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const unsigned g = (unsigned)((n + SEG_CHUNK - 1) / SEG_CHUNK);
+    const unsigned g = (unsigned)((n + SEGP_CHUNK - 1) / SEGP_CHUNK);
     segment_finish_kernel<<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
     return hipGetLastError();
 }
@@ -2064,7 +2103,7 @@ hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* i
                                       int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out,
                                       DevScalars* sc, hipStream_t stream) {
     if (m == 0) return hipSuccess;
-    const unsigned g = (unsigned)((m + SEG_CHUNK - 1) / SEG_CHUNK);
+    const unsigned g = (unsigned)((m + SEGT_CHUNK - 1) / SEGT_CHUNK);
     if (payload_packed)
         tree_segment_finish_kernel<true><<<g, SEG_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, m, seg_shift, (u64*)keys_out,
                                                                          ids_out, box_out, sc);

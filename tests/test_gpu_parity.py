@@ -300,11 +300,12 @@ def test_cpp_facade_binary():
     assert "facade ok" in out.stdout
 
 
-def test_segment_finish_falls_back_when_one_id_owns_many_pairs():
-    # one small box inside > 1024 large ones: its id owns more pairs than the LDS window of the
-    # first-id-only sort holds -> the full-width sort must take over, result unchanged
+@pytest.mark.parametrize("n_big", [1500, 5000])
+def test_segment_finish_falls_back_when_one_id_owns_many_pairs(n_big):
+    # one small box inside many large ones: its id owns more pairs than the LDS window of the
+    # first-id-only sort holds.  1500: ranked straight from HBM by the finish kernel (slow path);
+    # 5000 (> SEG_SLOW_MAX): the full-width sort must take over.  Result unchanged either way.
     rng = np.random.default_rng(2)
-    n_big = 1500
     sysb = ([0.0] * 3, [1000.0] * 3)
     lo = rng.uniform(0, 300, size=(n_big, 3)).astype(np.float32)
     hi = (lo + rng.uniform(400, 650, size=(n_big, 3))).astype(np.float32)
@@ -315,7 +316,7 @@ def test_segment_finish_falls_back_when_one_id_owns_many_pairs():
     gpu, ref = both(2)
     gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
     exp = ref.scan()
-    assert (exp[:, 0] == ids[-1]).sum() > 1024                # longer than any LDS window halo
+    assert (exp[:, 0] == ids[-1]).sum() > (1024 if n_big == 1500 else 4096)   # longer than any LDS window halo / the slow-path limit
     assert_pairs_equal(gpu.par_scan(), exp, "scan with a >1024-pair segment")
     assert gpu.stats()["flags"] == 3
 
