@@ -88,6 +88,7 @@ struct bp_layer {
 
     bp_stats stats{};
     bool prof_on = false;
+    uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     int prof_open = -1;
@@ -200,6 +201,7 @@ void prof_mark(void* ctx, int cls) {
     bp_layer* L = (bp_layer*)ctx;
     if (!L->prof_on) return;
     if (cls >= 0) {
+        if (!((L->prof_mask >> cls) & 1u)) return;  // class not selected: no events, no stream bubbles
         L->prof_open = cls;
         L->prof_open_ev = prof_event(L);
         if (L->prof_open_ev) (void)hipEventRecord(L->prof_open_ev, L->stream);
@@ -1571,6 +1573,11 @@ int bp_layer_stats(const bp_layer_t* L, bp_stats* out) {
 }
 
 int bp_layer_profile_enable(bp_layer_t* L, int on) { if (!L) return BP_ERR_INVALID_ARG; L->prof_on = on != 0; return BP_OK; }
+int bp_layer_profile_select(bp_layer_t* L, uint32_t class_mask) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    L->prof_mask = class_mask;
+    return BP_OK;
+}
 int bp_layer_profile_reset(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     for (int i = 0; i < BP_K_COUNT; ++i) { L->prof_ms[i] = 0; L->prof_n[i] = 0; }
