@@ -1188,7 +1188,7 @@ struct ExpandParams {
     u64* out;          // block-structured: block g = slots [g * SX_BLOCK, (g + 1) * SX_BLOCK)
     u64 out_blocks;    // capacity in blocks
     u32* blockfill;    // [out_blocks] zeroed by the host; records present in each block
-    u64* shards;       // [SX_SHARDS] block cursors, then [SX_SHARDS] pair counts (zeroed by the host)
+    u64* shards;       // [SX_SHARDS] block cursors, [SX_SHARDS] pair counts, [SX_SHARDS] candidate counts (zeroed by the host)
     DevScalars* sc;
     u64* big_list;     // j | slice << 32 (slice s covers candidates [s * SX_BIG, (s + 1) * SX_BIG) of j's range)
     u32 big_cap;
@@ -1260,6 +1260,7 @@ struct WaveStage {
     u64 next_k;    // blocks reserved from the shard's cursor and not yet used: [next_k, next_k + k_left)
     u32 k_left;
     u32* hist;     // LDS, workgroup-wide: SX_HIST_MAX x 256 digit counters
+    u64 examined;  // candidates this wave tested (wave-uniform)
     __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
         __builtin_amdgcn_wave_barrier();
         if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
@@ -1302,6 +1303,7 @@ struct WaveStage {
         const u32 rem = wp & (SX_BLOCK - 1u);
         if (rem) write_block(p, (wp / SX_BLOCK) & 1u, rem);
         if (wp && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)wp);
+        if (examined && lane_id() == 0) atomicAdd(&p.shards[2 * SX_SHARDS + shard], examined);
     }
 };
 
@@ -1329,7 +1331,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p)
     const int w = (int)(threadIdx.x >> 6), lane = lane_id();
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
-    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist};
+    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     const u64 le_lane = (2ull << lane) - 1ull;  // bits 0..lane
     for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
         const u32 j = (u32)base + (u32)lane;
@@ -1361,6 +1363,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p)
         // owner a candidate belongs to = how many ranges end at or before it: every owner sets ONE
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
         // popcount and one 16-byte LDS read per lane -- no per-candidate search.
+        st.examined += total;
         if (c > 0) s_rec[w][__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, cbdd, (u32)lane);
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
@@ -1414,7 +1417,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     const u32 n_items = min(p.sc->big_count, p.big_cap);
     if (blockIdx.x >= n_items) return;  // workgroup-uniform: nothing on the list for this workgroup
     sx_hist_clear(s_hist, p);
-    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u, s_hist};
+    WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const u64 item = p.big_list[it];
         const u32 j = (u32)item, slice = (u32)(item >> 32);
@@ -1427,6 +1430,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
         const u32 idj = (u32)(wj >> 32), cb = ((u32)wj >> 22) & 63u, dd = key_depth<KIND>(key);
         const u64 first = (u64)j + 1u + (u64)slice * SX_BIG;
         const u64 last = min(first + SX_BIG, (u64)end);
+        if (w == 0 && last > first) st.examined += last - first;
         for (u64 i0 = first; i0 < last; i0 += SX_THREADS) {  // workgroup-uniform trip count
             const u64 i = i0 + threadIdx.x;
             bool keep = false;

@@ -567,6 +567,7 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
     const size_t n_raw = (size_t)sc.total;
     L->n_raw = n_raw;
     L->stats.raw_pairs = n_raw;
+    L->stats.raw_candidates = p.box ? 0 : n_raw;  // without suppression this IS the reference's raw stream
     if (n_raw == 0) return BP_OK;
     BP_TRY(ensure_dev(L, L->pairs[0], n_raw * sizeof(uint64_t)));
     {
@@ -760,7 +761,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         BP_TRY(sc_reset(L));
         if (expand) {
             const size_t out_blocks = cap / SX_BLOCK;
-            const size_t shard_bytes = 2 * SX_SHARDS * sizeof(uint64_t);
+            const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
             BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->shards, shard_bytes));
             BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
@@ -788,12 +789,17 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 continue;
             }
             const uint64_t* sh = (const uint64_t*)L->h_shards.p;
-            uint64_t kmax = 0, total = 0;
-            for (int i = 0; i < SX_SHARDS; ++i) { kmax = std::max<uint64_t>(kmax, sh[i]); total += sh[SX_SHARDS + i]; }
+            uint64_t kmax = 0, total = 0, examined = 0;
+            for (int i = 0; i < SX_SHARDS; ++i) {
+                kmax = std::max<uint64_t>(kmax, sh[i]);
+                total += sh[SX_SHARDS + i];
+                examined += sh[2 * SX_SHARDS + i];
+            }
             const size_t extent_blocks = (size_t)kmax * SX_SHARDS;
             if (extent_blocks <= out_blocks) {
                 L->n_raw = (size_t)total;
                 L->stats.raw_pairs = L->n_raw;
+                L->stats.raw_candidates = examined;
                 L->raw_holes = true;
                 L->raw_extent = extent_blocks * SX_BLOCK;
                 if (count_digits) { L->pair_hist_plan = *hist_plan; L->pair_hist_valid = true; }
@@ -812,6 +818,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         if ((size_t)sc.total <= cap) {
             L->n_raw = (size_t)sc.total;
             L->stats.raw_pairs = L->n_raw;
+            L->stats.raw_candidates = p.box ? 0 : L->n_raw;
             return BP_OK;
         }
         cap = (size_t)sc.total + (size_t)sc.total / 16;  // the buffer was too small: grow and redo

@@ -54,7 +54,8 @@ FACT_ORDER_OK, FACT_IDS_DISTINCT, FACT_IDS_CARRY_BOX, FACT_BOX_ALL_KNOWN = 1, 2,
 
 class _Stats(C.Structure):
     _fields_ = [("objects_valid", C.c_uint64), ("objects_invalid", C.c_uint64), ("entries", C.c_uint64),
-                ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("tree_sort_passes", C.c_uint32),
+                ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("raw_candidates", C.c_uint64),
+                ("tree_sort_passes", C.c_uint32),
                 ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32)]
 
 

@@ -222,6 +222,8 @@ typedef struct bp_stats {
     uint64_t entries;         /* M: index entries in the tree                           */
     uint64_t raw_pairs;       /* P_raw of the last scan                                 */
     uint64_t pairs;           /* P of the last scan                                     */
+    uint64_t raw_candidates;  /* containment combos the last scan examined = the reference's raw pair count
+                                 before dedup (src/layer.rs:566-570); 0 when the scan path does not count them */
     uint32_t tree_sort_passes;
     uint32_t pair_sort_passes;
     uint32_t depth_mask;      /* bit d set <=> some entry has depth d                   */

@@ -66,6 +66,8 @@ def test_extend_sort_scan_match_oracle(kind, n, min_depth):
     st = gpu.stats()
     # duplicates are suppressed at the source when the layer can prove ids distinct and ordered
     assert st["pairs"] == len(exp) and len(exp) <= st["raw_pairs"] <= len(raw_ref)
+    # the expanding scan examines exactly the reference's raw stream (one candidate per containment combo)
+    assert st["raw_candidates"] in (0, len(raw_ref))
 
 
 def test_cell_explosion_is_reported_not_attempted():
