@@ -190,6 +190,7 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 // KERR_BIGLIST_OVERFLOW in sc->err means the result is incomplete (use scan_fused).
 constexpr uint32_t SX_BLOCK = 256;
 constexpr int SX_SHARDS = 64;
+constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
@@ -199,6 +200,12 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
 // hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
 // hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)
+// Batched Layer::test_box: (query << 32 | id) records for every entry whose cell the reference's recursion
+// reaches, block-structured like the scan's output (blockfill / shards zeroed by the caller); boxes: n_queries
+// rows of 2*dim f32 [min, max] in device memory
+hipError_t launch_test_box(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
+                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
+                           uint32_t* blockfill, uint64_t* shards, hipStream_t stream);
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

@@ -1178,7 +1178,6 @@ constexpr int SX_THREADS = 256;
 constexpr int SX_WAVES = SX_THREADS / 64;
 constexpr u32 SX_STAGE = 2 * SX_BLOCK;  // per-wave LDS ring: two output blocks
 constexpr u32 SX_BIG = 16384;           // ranges at least this long go to the work list, in slices of this size
-constexpr u32 SX_RESERVE = 4;           // output blocks a wave reserves per atomic
 static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
 
 struct ExpandParams {
@@ -2058,6 +2057,115 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     }
 }
 
+// =================================================================================================
+// Batched region queries: Layer::test_box (src/layer.rs:294-313 -> test :252-279 -> test_impl :167-239
+// with BoxTestGeometry, src/geom.rs:353-455), many boxes against one sorted tree.
+//
+// One lane per query walks the reference's recursion depth-first with an explicit per-level stack in
+// scratch memory: a node = (cell, slice of the tree, f32 cell bounds); `should_test` is the inclusive
+// overlap of the cell bounds with the test box; the entries exactly at the cell (the head of the
+// slice, before the first child's key) are reported, then the 2^dim children in key order, each child's
+// slice ending at the lower bound of the next child's key (the reference's binary_search_by split);
+// at max_depth or at the depth limit the whole slice is reported.  Child bounds replay
+// BoxTestGeometry::subdivide: centre = min + (max - min) / 2 (cgmath ^0.17 EuclideanSpace::midpoint),
+// child c takes [min, centre] or [centre, max] per axis by bit `axis` of c -- the same f32 operations
+// in the same order, so the cell bounds are bit-identical to the reference's.
+// Output: (query << 32 | id) records through the scan's block-structured wave stage; the caller's
+// sort + dedup yields each query's sorted duplicate-free id list (results.sort(); results.dedup()).
+// =================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(SX_THREADS) void test_box_kernel(ExpandParams p, const u32* __restrict__ ids, SysBounds sb,
+                                                              const float* __restrict__ boxes, u32 n_queries, int has_max_depth,
+                                                              u32 max_depth) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, NSUB = 1u << DIM;
+    constexpr u32 TOP = DIM * AB + DB;
+    __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
+    const int w = (int)(threadIdx.x >> 6);
+    const u32 gw = blockIdx.x * SX_WAVES + (u32)w;
+    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, nullptr, 0ull};
+    const u32 q = blockIdx.x * SX_THREADS + threadIdx.x;
+    // per-level stack (dynamically indexed -> scratch)
+    u32 lo[AB + 1], hi[AB + 1], cur[AB + 1];
+    u32 child[AB + 1];            // next child to visit; NSUB + 1 marks "node not entered yet"
+    float mn[AB + 1][DIM], mx[AB + 1][DIM];
+    u64 cell[AB + 1];
+    float tmin[DIM], tmax[DIM];
+    int level = -1;
+    if (q < n_queries) {
+#pragma unroll
+        for (u32 a = 0; a < DIM; ++a) {
+            tmin[a] = boxes[(size_t)q * (2 * DIM) + a];
+            tmax[a] = boxes[(size_t)q * (2 * DIM) + DIM + a];
+            mn[0][a] = sb.mn[a];
+            mx[0][a] = sb.mx[a];
+        }
+        lo[0] = 0; hi[0] = (u32)p.m; cell[0] = 0ull; child[0] = NSUB + 1u;
+        level = 0;
+    }
+    u32 ea = 0, eb = 0;  // pending report: entries [ea, eb) of the tree
+    const u64 qhi = (u64)q << 32;
+    auto lower_bound = [&](u32 a, u32 b, u64 key) {  // first index in [a, b) whose key is >= key
+        while (a < b) {
+            const u32 mid = a + ((b - a) >> 1);
+            if (p.keys[mid] < key) a = mid + 1; else b = mid;
+        }
+        return a;
+    };
+    while (__any(level >= 0 || ea < eb)) {  // wave-uniform loop: every lane reports at most one id per turn
+        bool keep = false;
+        u64 rec = 0;
+        if (ea < eb) {
+            keep = true;
+            rec = qhi | (u64)ids[ea];
+            ++ea;
+        } else if (level >= 0) {
+            const int l = level;
+            if (child[l] == NSUB + 1u) {  // entering the node (test_impl :181-197, :232-237)
+                bool ov = lo[l] < hi[l];
+#pragma unroll
+                for (u32 a = 0; a < DIM; ++a) ov = ov && !(mn[l][a] > tmax[a] || mx[l][a] < tmin[a]);  // geom.rs:112-119
+                if (!ov) {
+                    --level;
+                } else if ((has_max_depth && (u32)l >= max_depth) || (u32)l >= AB) {
+                    ea = lo[l]; eb = hi[l];
+                    --level;
+                } else {
+                    const u64 first_child = cell[l] + 1ull;  // child 0: same Morton bits, depth + 1
+                    const u32 s0 = lower_bound(lo[l], hi[l], first_child);
+                    ea = lo[l]; eb = s0;  // the entries exactly at this cell (:216-219)
+                    cur[l] = s0;
+                    child[l] = 0;
+                }
+            } else if (child[l] >= NSUB) {
+                --level;
+            } else {
+                const u32 c = child[l];
+                const u32 shift = TOP - DIM * ((u32)l + 1u);
+                const u64 base_key = (cell[l] & ~(u64)((1u << DB) - 1u)) | (u64)((u32)l + 1u);
+                const u32 a0 = cur[l];
+                const u32 b0 = c + 1u == NSUB ? hi[l] : lower_bound(a0, hi[l], base_key | ((u64)(c + 1u) << shift));
+                cur[l] = b0;
+                child[l] = c + 1u;
+                if (a0 < b0) {
+#pragma unroll
+                    for (u32 a = 0; a < DIM; ++a) {
+                        const float ctr = mn[l][a] + (mx[l][a] - mn[l][a]) / 2.0f;
+                        const bool upper = (c >> a) & 1u;
+                        mn[l + 1][a] = upper ? ctr : mn[l][a];
+                        mx[l + 1][a] = upper ? mx[l][a] : ctr;
+                    }
+                    lo[l + 1] = a0; hi[l + 1] = b0;
+                    cell[l + 1] = base_key | ((u64)c << shift);
+                    child[l + 1] = NSUB + 1u;
+                    level = l + 1;
+                }
+            }
+        }
+        st.push(keep, rec, p);
+    }
+    st.finish(p);
+}
+
 __global__ __launch_bounds__(256) void blockfill_to_u64_kernel(const u32* __restrict__ f, size_t nb, u64* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nb) out[i] = f[i];
@@ -2070,6 +2178,20 @@ __global__ __launch_bounds__(256) void compact_blocks_kernel(const u64* __restri
     const u64 o = offs[g];
     for (u32 k = (u32)lane_id(); k < cnt; k += 64) out[o + k] = in[g * SX_BLOCK + k];
 }
+hipError_t launch_test_box(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
+                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
+                           uint32_t* blockfill, uint64_t* shards, hipStream_t stream) {
+    if (n_queries == 0 || m == 0) return hipSuccess;
+    ExpandParams p;
+    p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
+    p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.hist = nullptr; p.hist_passes = 0;
+    for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
+    const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
+    BP_DISPATCH_KIND(kind, (test_box_kernel<K><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+    return hipGetLastError();
+}
+
 hipError_t launch_blockfill_to_u64(const uint32_t* blockfill, size_t n_blocks, unsigned long long* out, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     blockfill_to_u64_kernel<<<(unsigned)((n_blocks + 255) / 256), 256, 0, stream>>>(blockfill, n_blocks, (u64*)out);

@@ -1218,6 +1218,94 @@ int bp_layer_scan_filtered_aabb(bp_layer_t* L, const float* bounds_by_id, size_t
     return pairs_to_host(L, pairs, n_pairs);
 }
 
+// Batched Layer::test_box; result (query, id) rows in L->out_pairs, L->n_pairs
+static int test_box_batch_impl(bp_layer* L, const float* sys_min, const float* sys_max, const float* boxes, size_t n_queries,
+                               int has_max_depth, uint32_t max_depth) {
+    if (!sys_min || !sys_max || (n_queries && !boxes)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
+    if (n_queries > 0x7FFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "bp_layer_test_box_batch: more than 2^31-1 queries");
+    BP_TRY(sort_tree(L));  // src/layer.rs:260 (Layer::test sorts first)
+    L->n_pairs = 0;
+    L->n_raw = 0;
+    L->raw_holes = false;
+    L->pair_hist_valid = false;
+    if (n_queries == 0 || L->m == 0) return sync_stream(L);
+    if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "test_box: more than 2^32-1 index entries");
+    const KindInfo ki = kind_info(L->kind);
+    SysBounds sb;
+    for (uint32_t a = 0; a < 3; ++a) {
+        sb.mn[a] = a < ki.dim ? sys_min[a] : 0.f;
+        sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
+    }
+    const float* d_boxes = boxes;
+    if (!is_device_ptr(boxes)) {
+        const size_t bytes = n_queries * 2 * ki.dim * sizeof(float);
+        BP_TRY(ensure_dev(L, L->in_bounds, bytes));
+        HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, boxes, bytes, hipMemcpyHostToDevice, L->stream));
+        d_boxes = (const float*)L->in_bounds.p;
+    }
+    const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
+    BP_TRY(ensure_dev(L, L->shards, shard_bytes));
+    BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
+    // every wave ends with one partial block: room for that plus a first guess of 64 ids per query
+    const size_t n_waves = (n_queries + 63) / 64;
+    size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), (n_waves + SX_SHARDS * SX_RESERVE) * SX_BLOCK + 64 * n_queries);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
+        cap = L->pairs[0].cap / sizeof(uint64_t);
+        const size_t out_blocks = cap / SX_BLOCK;
+        BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
+        HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
+        HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+        {
+            ProfScope ps(L, BP_K_SCAN_EMIT);
+            HIP_TRY(L, launch_test_box(L->kind, cur_keys(L), cur_ids(L), L->m, sb, d_boxes, (uint32_t)n_queries, has_max_depth,
+                                       max_depth, (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p,
+                                       (uint64_t*)L->shards.p, L->stream));
+        }
+        HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
+        BP_TRY(sync_stream(L));
+        const uint64_t* sh = (const uint64_t*)L->h_shards.p;
+        uint64_t kmax = 0, total = 0;
+        for (int i = 0; i < SX_SHARDS; ++i) { kmax = std::max<uint64_t>(kmax, sh[i]); total += sh[SX_SHARDS + i]; }
+        const size_t extent_blocks = (size_t)kmax * SX_SHARDS;
+        if (extent_blocks > out_blocks) {  // the buffer was too small: grow and redo
+            cap = extent_blocks * SX_BLOCK + extent_blocks * SX_BLOCK / 16;
+            continue;
+        }
+        L->n_raw = (size_t)total;
+        L->raw_holes = true;
+        L->raw_extent = extent_blocks * SX_BLOCK;
+        // sort by (query, id) + dedup = results.sort(); results.dedup() per query (src/layer.rs:274-275)
+        unsigned long long qv = 0;
+        for (size_t v = n_queries - 1; v; v >>= 1) qv = (qv << 1) | 1ull;
+        const unsigned long long varying = (qv << 32) | (unsigned long long)(L->id_or ^ L->id_and);
+        const bool holes = L->raw_holes;
+        L->raw_holes = false;
+        BP_TRY(sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, L->n_raw, varying, false, holes));
+        if (L->n_raw == 0) BP_TRY(sync_stream(L));
+        return BP_OK;
+    }
+    return fail(L, BP_ERR_KERNEL, "test_box: output size did not converge");
+}
+
+int bp_layer_test_box_batch_device(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* boxes, size_t n_queries,
+                                   int has_max_depth, uint32_t max_depth, const uint32_t** d_rows, size_t* n_rows) {
+    if (!L || !d_rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(test_box_batch_impl(L, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
+    *d_rows = (const uint32_t*)L->out_pairs.p;
+    *n_rows = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_test_box_batch(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* boxes, size_t n_queries,
+                            int has_max_depth, uint32_t max_depth, const uint32_t** rows, size_t* n_rows) {
+    if (!L || !rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(test_box_batch_impl(L, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
+    return pairs_to_host(L, rows, n_rows);
+}
+
 int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in, size_t n, const uint32_t** d_pairs,
                                       size_t* n_pairs) {
     if (!L || !d_pairs || !n_pairs || (n && !d_pairs_in)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_unique_pairs: null argument");

@@ -75,6 +75,7 @@ EXPORTS = [
     "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
+    "bp_layer_test_box_batch", "bp_layer_test_box_batch_device",
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
@@ -187,6 +188,8 @@ def load_library():
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.bp_layer_profile_enable.argtypes = [vp, C.c_int]
     L.bp_layer_profile_reset.argtypes = [vp]
+    for fn in (L.bp_layer_test_box_batch, L.bp_layer_test_box_batch_device):
+        fn.argtypes = [vp, f32p, f32p, vp, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.bp_layer_profile_select.argtypes = [vp, C.c_uint32]
     L.bp_layer_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
     for name in EXPORTS:
@@ -391,6 +394,33 @@ class Layer:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._L.bp_layer_scan_filtered_aabb_device(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    # ---- batched region queries (src/layer.rs:294-313 for many boxes at once) -----------------------
+    def _test_box_args(self, system_bounds, boxes, max_depth):
+        f32p = C.POINTER(C.c_float)
+        smin = np.ascontiguousarray(system_bounds[0], dtype=np.float32)
+        smax = np.ascontiguousarray(system_bounds[1], dtype=np.float32)
+        ptr, rows, keep = self._bounds_arg(boxes)
+        return (smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p), C.c_void_p(ptr), rows,
+                0 if max_depth is None else 1, 0 if max_depth is None else int(max_depth)), (smin, smax, keep)
+
+    def test_box_batch(self, system_bounds, boxes, max_depth=None):
+        """rows (query index, id), sorted, duplicate-free: group q == test_box(system_bounds, boxes[q], max_depth)"""
+        args, _keep = self._test_box_args(system_bounds, boxes, max_depth)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_test_box_batch(self._h, *args, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def test_box_batch_device(self, system_bounds, boxes, max_depth=None):
+        args, _keep = self._test_box_args(system_bounds, boxes, max_depth)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_test_box_batch_device(self._h, *args, C.byref(p), C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    def test_box(self, system_bounds, test_bounds, max_depth=None):  # src/layer.rs:294-313
+        """sorted duplicate-free ids whose cells overlap test_bounds = (min, max)"""
+        box = np.concatenate([np.asarray(test_bounds[0], dtype=np.float32), np.asarray(test_bounds[1], dtype=np.float32)])
+        return np.array(self.test_box_batch(system_bounds, box[None, :], max_depth)[:, 1])
 
     def iter(self):  # src/layer.rs:79-81
         keys, ids = self.tree()

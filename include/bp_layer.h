@@ -231,6 +231,19 @@ typedef struct bp_stats {
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 
+/* ---- batched region queries ----------------------------------------------------
+ * Layer::test_box (src/layer.rs:294-313; test :252-279, test_impl :167-239, BoxTestGeometry
+ * src/geom.rs:353-455) for n_queries boxes at once.  boxes: rows of 2*dim f32 [min..., max...], host or
+ * device memory.  has_max_depth = 0 stands for max_depth = None.  Result: rows (query index, id),
+ * sorted by query then id, duplicate-free -- row group q is exactly what test_box(system_bounds,
+ * boxes[q], max_depth) returns.  Sorts the layer first, like the reference (src/layer.rs:260).
+ * The rows are borrowed until the next call on the handle and share storage with the scan results. */
+int bp_layer_test_box_batch(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *boxes,
+                            size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **rows, size_t *n_rows);
+int bp_layer_test_box_batch_device(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *boxes,
+                                   size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **d_rows,
+                                   size_t *n_rows);
+
 /* Kernel classes timed with HIP events on the layer's own stream when profiling is enabled */
 typedef enum bp_kernel_class {
     BP_K_ENCODE = 0,      /* encode_count + encode_emit                   */

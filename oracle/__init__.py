@@ -114,6 +114,8 @@ def lib():
     L.orc_layer_min_depth.argtypes = [C.c_void_p]
     L.orc_layer_num_invalid.restype = sz
     L.orc_layer_num_invalid.argtypes = [C.c_void_p]
+    L.orc_layer_test_box.restype = C.c_long
+    L.orc_layer_test_box.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_uint32, u32p, sz]
     L.orc_brute_force_overlaps.restype = sz
     L.orc_brute_force_overlaps.argtypes = [C.c_uint32, f32p, sz, u32p, sz]
     L.orc_hw_threads.restype = C.c_int
@@ -250,6 +252,18 @@ class OracleLayer:
         n, ms = C.c_size_t(0), C.c_size_t(0)
         p = self._L.orc_layer_scan_raw(self._h, C.byref(n), C.byref(ms))
         return self._pairs(p, n), ms.value
+
+    def test_box(self, system_bounds, test_bounds, max_depth=None):
+        """Layer::test_box (layer.rs:294-313): sorted unique ids whose cells overlap test_bounds = (min, max)"""
+        sys_min, sys_max = _f32(system_bounds[0]), _f32(system_bounds[1])
+        tmin, tmax = _f32(test_bounds[0]), _f32(test_bounds[1])
+        out = np.zeros(max(len(self), 1), dtype=np.uint32)
+        n = self._L.orc_layer_test_box(self._h, _ptr(sys_min, C.c_float), _ptr(sys_max, C.c_float), _ptr(tmin, C.c_float),
+                                       _ptr(tmax, C.c_float), 0 if max_depth is None else 1,
+                                       0 if max_depth is None else int(max_depth), _ptr(out, C.c_uint32), len(out))
+        if n < 0:
+            raise RuntimeError("orc_layer_test_box failed (%d)" % n)
+        return out[:n].copy()
 
     def __len__(self):
         return self._L.orc_layer_len(self._h)

@@ -663,6 +663,113 @@ static void refresh_views(orc_layer_t *l) {
 const uint64_t *orc_layer_keys(const orc_layer_t *l) { refresh_views((orc_layer_t *)l); return l->view_keys; }
 const uint32_t *orc_layer_ids(const orc_layer_t *l) { refresh_views((orc_layer_t *)l); return l->view_ids; }
 
+/* ------------------------------------------------------------------------------------------ */
+/* region query: Layer::test / test_box with BoxTestGeometry (section 8(f) row 1)               */
+/*                                                                                              */
+/* cgmath ^0.17 (Cargo.toml dependency, absent from the tree, no lockfile) supplies             */
+/* EuclideanSpace::midpoint for Bounds::center (geom.rs:130-132); its published definition is   */
+/* `self + (other - self) / 2`, restated here in f32 in that order.                             */
+
+typedef struct { float mn[3], mx[3]; } fbounds_t;
+
+/* geom.rs:112-119 */
+static int fbounds_overlaps(uint32_t dim, const fbounds_t *a, const float *bmin, const float *bmax) {
+    for (uint32_t i = 0; i < dim; ++i)
+        if (a->mn[i] > bmax[i] || a->mx[i] < bmin[i]) return 0;
+    return 1;
+}
+
+/* index.rs:253-289: the 2^dim children in key order, or 0 at the depth limit */
+static int subdivide_index(int kind, uint64_t cell, uint64_t *out) {
+    orc_kind_t k; orc_kind(kind, &k);
+    uint32_t depth = orc_depth(kind, cell);
+    if (depth >= k.axis_bits) return 0;
+    uint32_t shift = k.dim * k.axis_bits + k.depth_bits - k.dim * (depth + 1);
+    for (uint32_t c = 0; c < (1u << k.dim); ++c)
+        out[c] = orc_set_depth(kind, cell | ((uint64_t)c << shift), depth + 1);
+    return 1;
+}
+
+typedef struct {
+    int kind; uint32_t dim;
+    const float *tmin, *tmax;      /* test bounds */
+    int has_max_depth; uint32_t max_depth;
+    u32vec_t *results; int err;
+} boxtest_t;
+
+static void results_push_all(boxtest_t *t, const rec_t *tree, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        if (t->results->n == t->results->cap) {
+            size_t c = t->results->cap ? t->results->cap * 2 : 64;
+            uint32_t *q = (uint32_t *)realloc(t->results->p, c * sizeof(uint32_t));
+            if (!q) { t->err = -1; return; }
+            t->results->p = q; t->results->cap = c;
+        }
+        t->results->p[t->results->n++] = tree[i].id;
+    }
+}
+
+/* layer.rs:167-239 with TestGeom = BoxTestGeometry (geom.rs:353-455); `nearest` stays INFINITY for
+ * box tests (the callback of Layer::test returns it unchanged, layer.rs:268-271) and is dropped */
+static void test_impl_box(boxtest_t *t, const rec_t *tree, size_t n, uint64_t cell, const fbounds_t *cell_bounds) {
+    if (n == 0 || !fbounds_overlaps(t->dim, cell_bounds, t->tmin, t->tmax)) return;   /* :181-183, should_test :409-412 */
+    if (tree[0].key < cell || !orc_overlaps(t->kind, cell, tree[n - 1].key)) { t->err = -2; return; }   /* :185-187 panic */
+    uint32_t depth = orc_depth(t->kind, cell);
+    if (t->has_max_depth && depth >= t->max_depth) { results_push_all(t, tree, n); return; }   /* :190-197 */
+    uint64_t sub[8];
+    if (!subdivide_index(t->kind, cell, sub)) { results_push_all(t, tree, n); return; }       /* :232-237 */
+    const uint32_t nsub = 1u << t->dim;
+    /* :200-215: split the slice at each child's first key (binary_search_by ... Less/Greater) */
+    size_t start[9];
+    const rec_t *rest = tree; size_t nrest = n, consumed = 0;
+    for (uint32_t c = 0; c < nsub; ++c) {
+        size_t lo = 0, hi = nrest;
+        while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (rest[mid].key < sub[c]) lo = mid + 1; else hi = mid; }
+        start[c] = consumed + lo;        /* children c-1 (or the head, c == 0) ends here */
+        rest += lo; nrest -= lo; consumed += lo;
+    }
+    start[nsub] = n;
+    results_push_all(t, tree, start[0]);                                                       /* head :216-219 */
+    /* BoxTestGeometry::subdivide (geom.rs:383-407 / :418-446): center = min.midpoint(max) */
+    float center[3];
+    for (uint32_t a = 0; a < t->dim; ++a)
+        center[a] = cell_bounds->mn[a] + (cell_bounds->mx[a] - cell_bounds->mn[a]) / 2.0f;
+    for (uint32_t c = 0; c < nsub; ++c) {                                                      /* test_order = 0..n :449 */
+        fbounds_t b = *cell_bounds;
+        for (uint32_t a = 0; a < t->dim; ++a) {
+            if (c & (1u << a)) b.mn[a] = center[a]; else b.mx[a] = center[a];
+        }
+        test_impl_box(t, tree + start[c], start[c + 1] - start[c], sub[c], &b);
+        if (t->err) return;
+    }
+}
+
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* Layer::test_box (layer.rs:294-313) -> Layer::test (:252-279): sort, test_impl from the root cell,
+ * results.sort(); results.dedup().  Returns the number of ids written (<= cap), or < 0 on error. */
+long orc_layer_test_box(orc_layer_t *l, const float *sys_min, const float *sys_max, const float *tmin, const float *tmax,
+                        int has_max_depth, uint32_t max_depth, uint32_t *out, size_t cap) {
+    orc_kind_t k; orc_kind(l->kind, &k);
+    orc_layer_sort(l);                                                                          /* :260 */
+    u32vec_t res = {0, 0, 0};
+    boxtest_t t = { l->kind, k.dim, tmin, tmax, has_max_depth, max_depth, &res, 0 };
+    fbounds_t root;
+    for (uint32_t a = 0; a < 3; ++a) { root.mn[a] = a < k.dim ? sys_min[a] : 0.f; root.mx[a] = a < k.dim ? sys_max[a] : 0.f; }
+    test_impl_box(&t, l->tree.p, l->tree.n, 0, &root);                                          /* Index::default() :265 */
+    if (t.err) { free(res.p); return t.err; }
+    qsort(res.p, res.n, sizeof(uint32_t), cmp_u32);                                             /* :274 */
+    size_t w = 0;
+    for (size_t i = 0; i < res.n; ++i) if (i == 0 || res.p[i] != res.p[i - 1]) res.p[w++] = res.p[i];   /* :275 */
+    long ret = (long)w;
+    if (w > cap) ret = -3; else memcpy(out, res.p, w * sizeof(uint32_t));
+    free(res.p);
+    return ret;
+}
+
 /* geom.rs:112-119 (Bounds::overlaps, inclusive) over all i<j */
 size_t orc_brute_force_overlaps(uint32_t dim, const float *b, size_t n, uint32_t *pairs, size_t cap) {
     size_t cnt = 0;

@@ -97,6 +97,12 @@ size_t          orc_layer_num_invalid(const orc_layer_t *);
 
 /* brute force: all (i<j) whose inclusive AABBs overlap (geom.rs:112-119); returns count,
  * writes up to cap pairs (interleaved i,j of input row indices). */
+/* Layer::test_box (layer.rs:294-313, :252-279; BoxTestGeometry geom.rs:353-455): sorted unique ids whose
+ * cells overlap the test box; has_max_depth = 0 stands for None.  Returns the count, < 0 on error
+ * (-2: the reference would panic, -3: out too small) */
+long orc_layer_test_box(orc_layer_t *, const float *sys_min, const float *sys_max, const float *test_min,
+                        const float *test_max, int has_max_depth, uint32_t max_depth, uint32_t *out, size_t cap);
+
 size_t orc_brute_force_overlaps(uint32_t dim, const float *bounds, size_t n, uint32_t *pairs, size_t cap);
 
 /* number of hardware threads the par_* baseline can use */

@@ -174,3 +174,42 @@ class PyLayer:
     def scan(self, filt=None):
         raw, _ = self.scan_raw(filt)
         return sorted(set(raw))
+
+    def test_box(self, system_bounds, test_bounds, max_depth=None):
+        """Layer::test_box (layer.rs:294-313, test_impl :167-239) in CLOSED FORM, unlike the recursive
+        restatement in bp_oracle.c: the recursion reaches an entry iff the float bounds of every cell on the
+        path from the root down to level min(depth, max_depth) overlap the test box (should_test,
+        geom.rs:409-412); those bounds come from repeated centre splits (geom.rs:383-407 / 418-446) with
+        cgmath's midpoint = min + (max - min) / 2 in f32."""
+        self.sort()
+        dim, _bits, db, ab = KINDS[self.kind]
+        f = np.float32
+        smin = [f(v) for v in system_bounds[0]]
+        smax = [f(v) for v in system_bounds[1]]
+        tmin = [f(v) for v in test_bounds[0]]
+        tmax = [f(v) for v in test_bounds[1]]
+
+        def ov(mn, mx):
+            return not any(mn[a] > tmax[a] or mx[a] < tmin[a] for a in range(dim))
+
+        out = set()
+        for index, id_ in self.tree:
+            d = depth_of(self.kind, index)
+            levels = d if max_depth is None else min(d, max_depth)
+            morton = index >> db
+            mn, mx = list(smin), list(smax)
+            ok = ov(mn, mx)
+            for lvl in range(1, levels + 1):
+                if not ok:
+                    break
+                child = (morton >> (dim * (ab - lvl))) & ((1 << dim) - 1)
+                for a in range(dim):
+                    c = f(mn[a] + f(f(mx[a] - mn[a]) / f(2.0)))
+                    if child & (1 << a):
+                        mn[a] = c
+                    else:
+                        mx[a] = c
+                ok = ov(mn, mx)
+            if ok:
+                out.add(id_)
+        return sorted(out)

@@ -387,3 +387,55 @@ def test_large_ids_cannot_carry_box_codes_and_still_match():
     assert_pairs_equal(gpu.par_scan(), exp, "scan with ids >= 2^27")
     st = gpu.stats()
     assert st["flags"] == 3 and st["raw_pairs"] > st["pairs"] == len(exp)      # raw stream had duplicates: dedup ran
+
+
+# ---- batched region queries: Layer::test_box, src/layer.rs:294-313 ----------------
+@pytest.mark.parametrize("kind,min_depth", [(2, 0), (2, 5), (1, 0), (0, 3)])
+def test_test_box_batch_matches_reference_recursion(kind, min_depth):
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(6000, seed=40 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2])
+        bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    gpu, ref = both(kind, min_depth)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(kind)
+    L = float(sysb[1][0])
+    nq = 300
+    c = rng.uniform(-0.05 * L, 1.05 * L, size=(nq, dim))
+    h = rng.uniform(0.2, L / 5, size=(nq, dim)) * rng.choice([0.02, 0.2, 1.0], size=(nq, 1))
+    boxes = np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+    boxes[0] = np.concatenate([sysb[0], sysb[1]])                    # the whole system
+    boxes[1] = np.concatenate([sysb[1] + 5, sysb[1] + 9])            # entirely outside
+    boxes[2, dim:] = boxes[2, :dim]                                  # a point
+    for max_depth in (None, 0, 4, 9):
+        rows = np.array(gpu.test_box_batch(sysb, boxes, max_depth))
+        assert gpu.sorted                                            # Layer::test sorts first (layer.rs:260)
+        k = rows[:, 0].astype(np.uint64) << np.uint64(32) | rows[:, 1].astype(np.uint64)
+        assert np.all(k[1:] > k[:-1])                                # sorted by (query, id), duplicate-free
+        splits = np.searchsorted(rows[:, 0], np.arange(nq + 1))
+        for q in range(nq):
+            exp = ref.test_box(sysb, (boxes[q, :dim], boxes[q, dim:]), max_depth)
+            got = rows[splits[q]:splits[q + 1], 1]
+            assert np.array_equal(got, exp), "query %d max_depth %s: %d vs %d ids" % (q, max_depth, len(got), len(exp))
+    # single-query form, and the broadphase guarantee: every truly overlapping object is reported
+    q = 7
+    got = gpu.test_box(sysb, (boxes[q, :dim], boxes[q, dim:]))
+    true = np.flatnonzero(~np.any((bounds[:, :dim] > boxes[q, dim:]) | (bounds[:, dim:] < boxes[q, :dim]), axis=1))
+    assert set(true.tolist()) <= set(got.tolist())
+    # the scan still works afterwards (shared buffers)
+    assert_pairs_equal(gpu.par_scan(), ref.scan(), "scan after queries")
+
+
+def test_test_box_batch_empty_and_large_results():
+    gpu, ref = both(2)
+    sysb, bounds, ids = scenes.gen_boxes(20000, seed=3)
+    assert len(gpu.test_box_batch(sysb, np.zeros((4, 6), np.float32))) == 0          # empty layer
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    assert len(gpu.test_box_batch(sysb, np.zeros((0, 6), np.float32))) == 0          # no queries
+    whole = np.concatenate([sysb[0], sysb[1]]).astype(np.float32)
+    boxes = np.repeat(whole[None, :], 70, axis=0)                                    # 70 x every object: output regrowth
+    rows = np.array(gpu.test_box_batch(sysb, boxes))
+    assert len(rows) == 70 * len(ids)
+    assert np.array_equal(rows[:len(ids), 1], np.sort(ids))
+    assert np.array_equal(ref.test_box(sysb, (sysb[0], sysb[1])), np.sort(ids))
