@@ -114,6 +114,20 @@ template <class Index, class ID = uint32_t> class Layer {
     template <class F> PairView scan_filtered(F&& filter) { return filtered(&bp_layer_scan_filtered, std::forward<F>(filter)); }
     template <class F> PairView par_scan_filtered(F&& filter) { return filtered(&bp_layer_par_scan_filtered, std::forward<F>(filter)); }
 
+    // Layer::test_box (layer.rs:294-313): sorted duplicate-free ids whose cells overlap test_bounds;
+    // max_depth < 0 stands for None.  (One query per call here; bp_layer_test_box_batch takes many.)
+    std::vector<ID> test_box(const Bounds<Index::dim>& system_bounds, const Bounds<Index::dim>& test_bounds, int max_depth = -1) {
+        float box[2 * Index::dim];
+        for (int a = 0; a < Index::dim; ++a) { box[a] = test_bounds.min[a]; box[Index::dim + a] = test_bounds.max[a]; }
+        const uint32_t* rows = nullptr;
+        size_t n = 0;
+        check(bp_layer_test_box_batch(h_, system_bounds.min, system_bounds.max, box, 1, max_depth >= 0 ? 1 : 0,
+                                      max_depth >= 0 ? (uint32_t)max_depth : 0u, &rows, &n));
+        std::vector<ID> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = (ID)rows[2 * i + 1];
+        return out;
+    }
+
     // Layer::iter (layer.rs:79-81): entries in current order
     std::vector<std::pair<uint64_t, ID>> iter() {
         const uint64_t* k; const uint32_t* i; size_t m; int s;

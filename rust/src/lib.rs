@@ -34,6 +34,9 @@ extern "C" {
                                   n: *mut usize) -> c_int;
     fn bp_layer_tree(layer: *mut BpLayer, keys: *mut *const u64, ids: *mut *const u32, m: *mut usize,
                      sorted: *mut c_int) -> c_int;
+    fn bp_layer_test_box_batch(layer: *mut BpLayer, sys_min: *const f32, sys_max: *const f32, boxes: *const f32,
+                               n_queries: usize, has_max_depth: c_int, max_depth: u32, rows: *mut *const u32,
+                               n_rows: *mut usize) -> c_int;
 }
 
 /// Index kinds of the reference (`src/index.rs:293-295`); DIM f32 per corner on the wire.
@@ -94,6 +97,22 @@ impl<Index: SpatialIndexKind> Layer<Index, u32> {
         let s = unsafe { std::slice::from_raw_parts(p, 2 * n) };
         self.collisions.extend(s.chunks_exact(2).map(|c| (c[0], c[1])));
         &self.collisions
+    }
+    /// `Layer::test_box` (`src/layer.rs:294-313`): ids whose cells overlap `test_bounds`, sorted, duplicate-free
+    pub fn test_box<const D: usize>(&mut self, system_bounds: Bounds<D>, test_bounds: Bounds<D>, max_depth: Option<u32>) -> Vec<u32> {
+        self.test_box_batch(system_bounds, &[test_bounds], max_depth).into_iter().map(|(_, id)| id).collect()
+    }
+    /// many boxes in one device pass: rows `(query index, id)`, sorted by query then id
+    pub fn test_box_batch<const D: usize>(&mut self, system_bounds: Bounds<D>, boxes: &[Bounds<D>], max_depth: Option<u32>) -> Vec<(u32, u32)> {
+        assert_eq!(D, Index::DIM);
+        let mut flat: Vec<f32> = Vec::with_capacity(boxes.len() * 2 * D);
+        for b in boxes { flat.extend_from_slice(&b.min); flat.extend_from_slice(&b.max); }
+        let (mut p, mut n) = (std::ptr::null(), 0usize);
+        check(unsafe { bp_layer_test_box_batch(self.handle, system_bounds.min.as_ptr(), system_bounds.max.as_ptr(), flat.as_ptr(),
+                                               boxes.len(), max_depth.is_some() as c_int, max_depth.unwrap_or(0), &mut p, &mut n) },
+              self.handle);
+        let s = unsafe { std::slice::from_raw_parts(p, 2 * n) };
+        s.chunks_exact(2).map(|c| (c[0], c[1])).collect()
     }
     /// `Layer::scan` (`src/layer.rs:449-453`)
     pub fn scan<'a>(&'a mut self) -> &'a Vec<(u32, u32)> {

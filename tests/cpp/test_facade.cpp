@@ -48,6 +48,13 @@ int main() {
     CHECK(calls == 32);  // the filter sees every raw pair before dedup (layer.rs:455-459)
     CHECK(filtered.size() == 2 && filtered[0].first == 0 && filtered[1].first == 1);
 
+    // test_box (layer.rs:294-313): expected ids from the oracle's restatement of test_impl
+    auto near_origin = layer.test_box(system_bounds, B3{{1.f, 1.f, 1.f}, {2.f, 2.f, 2.f}});
+    CHECK(near_origin.size() == 3 && near_origin[0] == 0 && near_origin[1] == 1 && near_origin[2] == 2);
+    auto far_corner = layer.test_box(system_bounds, B3{{10.f, 10.f, 10.f}, {12.f, 12.f, 12.f}}, 2);
+    CHECK(far_corner.size() == 2 && far_corner[0] == 2 && far_corner[1] == 3);
+    CHECK(layer.par_scan().size() == 4);  // the scan is unaffected by the shared result buffers
+
     // merge: static layer into a dynamic one (layer.rs:123-138)
     auto dynamic = LayerBuilder::create().with_min_depth(2).build<Index64_3D>();
     dynamic.extend(system_bounds, {{B3{{2.5f, 2.5f, 2.5f}, {2.75f, 2.75f, 2.75f}}, 9}});
