@@ -200,12 +200,13 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
 // hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
 // hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)
-// Batched Layer::test_box: (query << 32 | id) records for every entry whose cell the reference's recursion
-// reaches, block-structured like the scan's output (blockfill / shards zeroed by the caller); boxes: n_queries
-// rows of 2*dim f32 [min, max] in device memory
-hipError_t launch_test_box(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
-                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
-                           uint32_t* blockfill, uint64_t* shards, hipStream_t stream);
+// Batched Layer::test_box / test_ray: (query << 32 | id) records for every entry whose cell the reference's
+// recursion reaches, block-structured like the scan's output (blockfill / shards zeroed by the caller).
+// queries (device memory): n_queries rows of 2*dim f32 [min, max] (ray = 0) or 2*dim + 2 f32
+// [origin, direction, range_min, range_max] (ray = 1)
+hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb,
+                               const float* queries, uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out,
+                               size_t out_blocks, uint32_t* blockfill, uint64_t* shards, hipStream_t stream);
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

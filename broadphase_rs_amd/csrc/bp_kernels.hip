@@ -2073,12 +2073,19 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
 // Output: (query << 32 | id) records through the scan's block-structured wave stage; the caller's
 // sort + dedup yields each query's sorted duplicate-free id list (results.sort(); results.dedup()).
 // =================================================================================================
-template <int KIND>
-__global__ __launch_bounds__(SX_THREADS) void test_box_kernel(ExpandParams p, const u32* __restrict__ ids, SysBounds sb,
-                                                              const float* __restrict__ boxes, u32 n_queries, int has_max_depth,
-                                                              u32 max_depth) {
+// RAY = false: Layer::test_box, query row = [min(dim), max(dim)].
+// RAY = true:  Layer::test_ray (src/layer.rs:327-351) with RayTestGeometry (src/geom.rs:460-689), query row =
+// [origin(dim), direction(dim), range_min, range_max]: with_system_bounds clamps the range to the system
+// bounds (:511-537), subdivide narrows it by the distances to the centre planes (:617-661, the non-finite
+// distance case included), should_test = range_min < range_max (:686-688).  test_order only matters for the
+// nearest-hit early-out of `pick`, not for the result set of `test`.
+template <int KIND, bool RAY>
+__global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p, const u32* __restrict__ ids, SysBounds sb,
+                                                                  const float* __restrict__ queries, u32 n_queries,
+                                                                  int has_max_depth, u32 max_depth) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, NSUB = 1u << DIM;
     constexpr u32 TOP = DIM * AB + DB;
+    constexpr u32 ROW = RAY ? 2 * DIM + 2 : 2 * DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     const int w = (int)(threadIdx.x >> 6);
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;
@@ -2088,16 +2095,31 @@ __global__ __launch_bounds__(SX_THREADS) void test_box_kernel(ExpandParams p, co
     u32 lo[AB + 1], hi[AB + 1], cur[AB + 1];
     u32 child[AB + 1];            // next child to visit; NSUB + 1 marks "node not entered yet"
     float mn[AB + 1][DIM], mx[AB + 1][DIM];
+    float rmin[RAY ? AB + 1 : 1], rmax[RAY ? AB + 1 : 1];
     u64 cell[AB + 1];
-    float tmin[DIM], tmax[DIM];
+    float qa[DIM], qb[DIM];       // box: test min / max; ray: origin / direction
     int level = -1;
     if (q < n_queries) {
+        const float* row = queries + (size_t)q * ROW;
 #pragma unroll
         for (u32 a = 0; a < DIM; ++a) {
-            tmin[a] = boxes[(size_t)q * (2 * DIM) + a];
-            tmax[a] = boxes[(size_t)q * (2 * DIM) + DIM + a];
+            qa[a] = row[a];
+            qb[a] = row[DIM + a];
             mn[0][a] = sb.mn[a];
             mx[0][a] = sb.mx[a];
+        }
+        if (RAY) {  // RayTestGeometry::with_system_bounds (geom.rs:511-537)
+            float r0 = row[2 * DIM], r1 = row[2 * DIM + 1];
+#pragma unroll
+            for (u32 a = 0; a < DIM; ++a) {
+                const float distance_0 = (sb.mn[a] - qa[a]) / qb[a];
+                const float distance_1 = (sb.mx[a] - qa[a]) / qb[a];
+                const bool is_forward = qb[a] > 0.0f;
+                const float d0 = is_forward ? distance_0 : distance_1, d1 = is_forward ? distance_1 : distance_0;
+                if (isfinite(d0)) r0 = fmaxf(r0, d0);  // f32::max / min: a NaN operand loses, like fmaxf / fminf
+                if (isfinite(d1)) r1 = fminf(r1, d1);
+            }
+            rmin[0] = r0; rmax[0] = r1;
         }
         lo[0] = 0; hi[0] = (u32)p.m; cell[0] = 0ull; child[0] = NSUB + 1u;
         level = 0;
@@ -2122,8 +2144,12 @@ __global__ __launch_bounds__(SX_THREADS) void test_box_kernel(ExpandParams p, co
             const int l = level;
             if (child[l] == NSUB + 1u) {  // entering the node (test_impl :181-197, :232-237)
                 bool ov = lo[l] < hi[l];
+                if (RAY) {
+                    ov = ov && rmin[RAY ? l : 0] < rmax[RAY ? l : 0] && rmin[RAY ? l : 0] < INFINITY;
+                } else {
 #pragma unroll
-                for (u32 a = 0; a < DIM; ++a) ov = ov && !(mn[l][a] > tmax[a] || mx[l][a] < tmin[a]);  // geom.rs:112-119
+                    for (u32 a = 0; a < DIM; ++a) ov = ov && !(mn[l][a] > qb[a] || mx[l][a] < qa[a]);  // geom.rs:112-119
+                }
                 if (!ov) {
                     --level;
                 } else if ((has_max_depth && (u32)l >= max_depth) || (u32)l >= AB) {
@@ -2147,13 +2173,24 @@ __global__ __launch_bounds__(SX_THREADS) void test_box_kernel(ExpandParams p, co
                 cur[l] = b0;
                 child[l] = c + 1u;
                 if (a0 < b0) {
+                    float r0 = RAY ? rmin[RAY ? l : 0] : 0.f, r1 = RAY ? rmax[RAY ? l : 0] : 0.f;
 #pragma unroll
                     for (u32 a = 0; a < DIM; ++a) {
                         const float ctr = mn[l][a] + (mx[l][a] - mn[l][a]) / 2.0f;
                         const bool upper = (c >> a) & 1u;
+                        if (RAY) {
+                            const float distance = (ctr - qa[a]) / qb[a];
+                            if (isfinite(distance)) {
+                                const bool is_towards = (qb[a] > 0.0f) != upper;
+                                if (is_towards) r1 = fminf(r1, distance); else r0 = fmaxf(r0, distance);
+                            } else if ((qa[a] > ctr) != upper) {
+                                r0 = INFINITY; r1 = -INFINITY;
+                            }
+                        }
                         mn[l + 1][a] = upper ? ctr : mn[l][a];
                         mx[l + 1][a] = upper ? mx[l][a] : ctr;
                     }
+                    if (RAY) { rmin[RAY ? l + 1 : 0] = r0; rmax[RAY ? l + 1 : 0] = r1; }
                     lo[l + 1] = a0; hi[l + 1] = b0;
                     cell[l + 1] = base_key | ((u64)c << shift);
                     child[l + 1] = NSUB + 1u;
@@ -2178,9 +2215,9 @@ __global__ __launch_bounds__(256) void compact_blocks_kernel(const u64* __restri
     const u64 o = offs[g];
     for (u32 k = (u32)lane_id(); k < cnt; k += 64) out[o + k] = in[g * SX_BLOCK + k];
 }
-hipError_t launch_test_box(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
-                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
-                           uint32_t* blockfill, uint64_t* shards, hipStream_t stream) {
+hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
+                               uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
+                               uint32_t* blockfill, uint64_t* shards, hipStream_t stream) {
     if (n_queries == 0 || m == 0) return hipSuccess;
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
@@ -2188,7 +2225,11 @@ hipError_t launch_test_box(int kind, const uint64_t* keys, const uint32_t* ids, 
     p.n_waves = 0; p.filt_bounds = nullptr; p.hist = nullptr; p.hist_passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
-    BP_DISPATCH_KIND(kind, (test_box_kernel<K><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+    if (ray) {
+        BP_DISPATCH_KIND(kind, (region_query_kernel<K, true><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+    } else {
+        BP_DISPATCH_KIND(kind, (region_query_kernel<K, false><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+    }
     return hipGetLastError();
 }
 

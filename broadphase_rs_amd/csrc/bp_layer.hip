@@ -1218,10 +1218,10 @@ int bp_layer_scan_filtered_aabb(bp_layer_t* L, const float* bounds_by_id, size_t
     return pairs_to_host(L, pairs, n_pairs);
 }
 
-// Batched Layer::test_box; result (query, id) rows in L->out_pairs, L->n_pairs
-static int test_box_batch_impl(bp_layer* L, const float* sys_min, const float* sys_max, const float* boxes, size_t n_queries,
-                               int has_max_depth, uint32_t max_depth) {
-    if (!sys_min || !sys_max || (n_queries && !boxes)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
+// Batched Layer::test_box / test_ray; result (query, id) rows in L->out_pairs, L->n_pairs
+static int region_query_batch_impl(bp_layer* L, int ray, const float* sys_min, const float* sys_max, const float* boxes,
+                                   size_t n_queries, int has_max_depth, uint32_t max_depth) {
+    if (!sys_min || !sys_max || (n_queries && !boxes)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_*_batch: null argument");
     if (n_queries > 0x7FFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "bp_layer_test_box_batch: more than 2^31-1 queries");
     BP_TRY(sort_tree(L));  // src/layer.rs:260 (Layer::test sorts first)
     L->n_pairs = 0;
@@ -1238,7 +1238,7 @@ static int test_box_batch_impl(bp_layer* L, const float* sys_min, const float* s
     }
     const float* d_boxes = boxes;
     if (!is_device_ptr(boxes)) {
-        const size_t bytes = n_queries * 2 * ki.dim * sizeof(float);
+        const size_t bytes = n_queries * (2 * ki.dim + (ray ? 2 : 0)) * sizeof(float);
         BP_TRY(ensure_dev(L, L->in_bounds, bytes));
         HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, boxes, bytes, hipMemcpyHostToDevice, L->stream));
         d_boxes = (const float*)L->in_bounds.p;
@@ -1258,9 +1258,9 @@ static int test_box_batch_impl(bp_layer* L, const float* sys_min, const float* s
         HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
-            HIP_TRY(L, launch_test_box(L->kind, cur_keys(L), cur_ids(L), L->m, sb, d_boxes, (uint32_t)n_queries, has_max_depth,
-                                       max_depth, (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p,
-                                       (uint64_t*)L->shards.p, L->stream));
+            HIP_TRY(L, launch_region_query(L->kind, ray, cur_keys(L), cur_ids(L), L->m, sb, d_boxes, (uint32_t)n_queries,
+                                           has_max_depth, max_depth, (uint64_t*)L->pairs[0].p, out_blocks,
+                                           (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, L->stream));
         }
         HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
         BP_TRY(sync_stream(L));
@@ -1292,7 +1292,7 @@ int bp_layer_test_box_batch_device(bp_layer_t* L, const float* sys_min, const fl
                                    int has_max_depth, uint32_t max_depth, const uint32_t** d_rows, size_t* n_rows) {
     if (!L || !d_rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
     DeviceGuard g(L->device);
-    BP_TRY(test_box_batch_impl(L, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
+    BP_TRY(region_query_batch_impl(L, 0, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
     *d_rows = (const uint32_t*)L->out_pairs.p;
     *n_rows = L->n_pairs;
     return BP_OK;
@@ -1302,7 +1302,25 @@ int bp_layer_test_box_batch(bp_layer_t* L, const float* sys_min, const float* sy
                             int has_max_depth, uint32_t max_depth, const uint32_t** rows, size_t* n_rows) {
     if (!L || !rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_box_batch: null argument");
     DeviceGuard g(L->device);
-    BP_TRY(test_box_batch_impl(L, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
+    BP_TRY(region_query_batch_impl(L, 0, sys_min, sys_max, boxes, n_queries, has_max_depth, max_depth));
+    return pairs_to_host(L, rows, n_rows);
+}
+
+int bp_layer_test_ray_batch_device(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* rays, size_t n_queries,
+                                   int has_max_depth, uint32_t max_depth, const uint32_t** d_rows, size_t* n_rows) {
+    if (!L || !d_rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_ray_batch: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(region_query_batch_impl(L, 1, sys_min, sys_max, rays, n_queries, has_max_depth, max_depth));
+    *d_rows = (const uint32_t*)L->out_pairs.p;
+    *n_rows = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_test_ray_batch(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* rays, size_t n_queries,
+                            int has_max_depth, uint32_t max_depth, const uint32_t** rows, size_t* n_rows) {
+    if (!L || !rows || !n_rows) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_test_ray_batch: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(region_query_batch_impl(L, 1, sys_min, sys_max, rays, n_queries, has_max_depth, max_depth));
     return pairs_to_host(L, rows, n_rows);
 }
 

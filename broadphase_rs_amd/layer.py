@@ -75,7 +75,7 @@ EXPORTS = [
     "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
-    "bp_layer_test_box_batch", "bp_layer_test_box_batch_device",
+    "bp_layer_test_box_batch", "bp_layer_test_box_batch_device", "bp_layer_test_ray_batch", "bp_layer_test_ray_batch_device",
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
@@ -188,7 +188,8 @@ def load_library():
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.bp_layer_profile_enable.argtypes = [vp, C.c_int]
     L.bp_layer_profile_reset.argtypes = [vp]
-    for fn in (L.bp_layer_test_box_batch, L.bp_layer_test_box_batch_device):
+    for fn in (L.bp_layer_test_box_batch, L.bp_layer_test_box_batch_device, L.bp_layer_test_ray_batch,
+               L.bp_layer_test_ray_batch_device):
         fn.argtypes = [vp, f32p, f32p, vp, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.bp_layer_profile_select.argtypes = [vp, C.c_uint32]
     L.bp_layer_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
@@ -416,6 +417,31 @@ class Layer:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._L.bp_layer_test_box_batch_device(self._h, *args, C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    def _query_rows(self, rows, width):
+        if _is_device_tensor(rows):
+            if rows.element_size() != 4 or not rows.is_contiguous():
+                raise ValueError("query rows must be contiguous f32")
+            return rows.data_ptr(), int(rows.numel()) // width, rows
+        b = np.ascontiguousarray(np.asarray(rows, dtype=np.float32).reshape(-1, width))
+        return b.ctypes.data, len(b), b
+
+    def test_ray_batch(self, system_bounds, rays, max_depth=None, device=False):
+        """rays: rows [origin(dim), direction(dim), range_min, range_max]; rows (query index, id) like test_box_batch"""
+        f32p = C.POINTER(C.c_float)
+        smin = np.ascontiguousarray(system_bounds[0], dtype=np.float32)
+        smax = np.ascontiguousarray(system_bounds[1], dtype=np.float32)
+        ptr, n_rays, _keep = self._query_rows(rays, 2 * self.index.dim + 2)
+        p, n = C.c_void_p(), C.c_size_t()
+        fn = self._L.bp_layer_test_ray_batch_device if device else self._L.bp_layer_test_ray_batch
+        self._check(fn(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p), C.c_void_p(ptr), n_rays,
+                       0 if max_depth is None else 1, 0 if max_depth is None else int(max_depth), C.byref(p), C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self) if device else self._host_pairs(p, n)
+
+    def test_ray(self, system_bounds, origin, direction, range_min=-np.inf, range_max=np.inf, max_depth=None):  # src/layer.rs:327-351
+        row = np.concatenate([np.asarray(origin, np.float32), np.asarray(direction, np.float32),
+                              np.array([range_min, range_max], np.float32)])
+        return np.array(self.test_ray_batch(system_bounds, row[None, :], max_depth)[:, 1])
 
     def test_box(self, system_bounds, test_bounds, max_depth=None):  # src/layer.rs:294-313
         """sorted duplicate-free ids whose cells overlap test_bounds = (min, max)"""

@@ -243,6 +243,14 @@ int bp_layer_test_box_batch(bp_layer_t *layer, const float *sys_min, const float
 int bp_layer_test_box_batch_device(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *boxes,
                                    size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **d_rows,
                                    size_t *n_rows);
+/* Layer::test_ray (src/layer.rs:327-351, RayTestGeometry src/geom.rs:460-689) for n_queries rays at once.
+ * rays: rows of 2*dim + 2 f32 [origin..., direction..., range_min, range_max] (the range may be -inf / +inf:
+ * it is clamped to the system bounds).  Same result layout as bp_layer_test_box_batch. */
+int bp_layer_test_ray_batch(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *rays,
+                            size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **rows, size_t *n_rows);
+int bp_layer_test_ray_batch_device(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *rays,
+                                   size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **d_rows,
+                                   size_t *n_rows);
 
 /* Kernel classes timed with HIP events on the layer's own stream when profiling is enabled */
 typedef enum bp_kernel_class {

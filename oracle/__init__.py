@@ -116,6 +116,8 @@ def lib():
     L.orc_layer_num_invalid.argtypes = [C.c_void_p]
     L.orc_layer_test_box.restype = C.c_long
     L.orc_layer_test_box.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_uint32, u32p, sz]
+    L.orc_layer_test_ray.restype = C.c_long
+    L.orc_layer_test_ray.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_uint32, u32p, sz]
     L.orc_brute_force_overlaps.restype = sz
     L.orc_brute_force_overlaps.argtypes = [C.c_uint32, f32p, sz, u32p, sz]
     L.orc_hw_threads.restype = C.c_int
@@ -263,6 +265,18 @@ class OracleLayer:
                                        0 if max_depth is None else int(max_depth), _ptr(out, C.c_uint32), len(out))
         if n < 0:
             raise RuntimeError("orc_layer_test_box failed (%d)" % n)
+        return out[:n].copy()
+
+    def test_ray(self, system_bounds, origin, direction, range_min=-np.inf, range_max=np.inf, max_depth=None):
+        """Layer::test_ray (layer.rs:327-351): sorted unique ids of the cells the ray passes through"""
+        sys_min, sys_max = _f32(system_bounds[0]), _f32(system_bounds[1])
+        o, d = _f32(origin), _f32(direction)
+        out = np.zeros(max(len(self), 1), dtype=np.uint32)
+        n = self._L.orc_layer_test_ray(self._h, _ptr(sys_min, C.c_float), _ptr(sys_max, C.c_float), _ptr(o, C.c_float),
+                                       _ptr(d, C.c_float), float(range_min), float(range_max), 0 if max_depth is None else 1,
+                                       0 if max_depth is None else int(max_depth), _ptr(out, C.c_uint32), len(out))
+        if n < 0:
+            raise RuntimeError("orc_layer_test_ray failed (%d)" % n)
         return out[:n].copy()
 
     def __len__(self):

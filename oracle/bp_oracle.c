@@ -13,6 +13,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -690,14 +691,22 @@ static int subdivide_index(int kind, uint64_t cell, uint64_t *out) {
     return 1;
 }
 
+/* Test geometry of one cell: BoxTestGeometry (geom.rs:353-363) or RayTestGeometry (geom.rs:460-470) */
+typedef struct {
+    fbounds_t cell_bounds;
+    float range_min, range_max;    /* ray only */
+} tgeom_t;
+
 typedef struct {
     int kind; uint32_t dim;
-    const float *tmin, *tmax;      /* test bounds */
+    int is_ray;
+    const float *tmin, *tmax;      /* box: test bounds */
+    const float *origin, *direction; /* ray */
     int has_max_depth; uint32_t max_depth;
     u32vec_t *results; int err;
-} boxtest_t;
+} regiontest_t;
 
-static void results_push_all(boxtest_t *t, const rec_t *tree, size_t n) {
+static void results_push_all(regiontest_t *t, const rec_t *tree, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         if (t->results->n == t->results->cap) {
             size_t c = t->results->cap ? t->results->cap * 2 : 64;
@@ -709,10 +718,41 @@ static void results_push_all(boxtest_t *t, const rec_t *tree, size_t n) {
     }
 }
 
-/* layer.rs:167-239 with TestGeom = BoxTestGeometry (geom.rs:353-455); `nearest` stays INFINITY for
- * box tests (the callback of Layer::test returns it unchanged, layer.rs:268-271) and is dropped */
-static void test_impl_box(boxtest_t *t, const rec_t *tree, size_t n, uint64_t cell, const fbounds_t *cell_bounds) {
-    if (n == 0 || !fbounds_overlaps(t->dim, cell_bounds, t->tmin, t->tmax)) return;   /* :181-183, should_test :409-412 */
+/* should_test with nearest = INFINITY: box geom.rs:409-412 / :449-452, ray :609-611 / :686-688 */
+static int geom_should_test(const regiontest_t *t, const tgeom_t *g) {
+    if (t->is_ray) return g->range_min < g->range_max && g->range_min < INFINITY;
+    return fbounds_overlaps(t->dim, &g->cell_bounds, t->tmin, t->tmax);
+}
+
+/* TestGeometry::subdivide for child `c`: box geom.rs:383-407 / :418-446, ray :543-588 / :617-661 */
+static void geom_child(const regiontest_t *t, const tgeom_t *g, uint32_t c, tgeom_t *out) {
+    float center[3];
+    for (uint32_t a = 0; a < t->dim; ++a)   /* Bounds::center = min.midpoint(max), geom.rs:130-132 */
+        center[a] = g->cell_bounds.mn[a] + (g->cell_bounds.mx[a] - g->cell_bounds.mn[a]) / 2.0f;
+    *out = *g;
+    if (t->is_ray) {
+        for (uint32_t a = 0; a < t->dim; ++a) {
+            const float distance = (center[a] - t->origin[a]) / t->direction[a];
+            const int side = (c >> a) & 1u;
+            if (isfinite(distance)) {
+                const int is_towards = (t->direction[a] > 0.0f) != side;
+                if (is_towards) out->range_max = fminf(out->range_max, distance);   /* f32::min: NaN -> the other */
+                else out->range_min = fmaxf(out->range_min, distance);
+            } else if ((t->origin[a] > center[a]) != side) {
+                out->range_min = INFINITY;
+                out->range_max = -INFINITY;
+            }
+        }
+    }
+    for (uint32_t a = 0; a < t->dim; ++a) {
+        if (c & (1u << a)) out->cell_bounds.mn[a] = center[a]; else out->cell_bounds.mx[a] = center[a];
+    }
+}
+
+/* layer.rs:167-239; `nearest` stays INFINITY for Layer::test (its callback returns it unchanged,
+ * layer.rs:268-271), so the visiting order (test_order) cannot change the result set and is dropped */
+static void test_impl(regiontest_t *t, const rec_t *tree, size_t n, uint64_t cell, const tgeom_t *g) {
+    if (n == 0 || !geom_should_test(t, g)) return;                                             /* :181-183 */
     if (tree[0].key < cell || !orc_overlaps(t->kind, cell, tree[n - 1].key)) { t->err = -2; return; }   /* :185-187 panic */
     uint32_t depth = orc_depth(t->kind, cell);
     if (t->has_max_depth && depth >= t->max_depth) { results_push_all(t, tree, n); return; }   /* :190-197 */
@@ -725,21 +765,15 @@ static void test_impl_box(boxtest_t *t, const rec_t *tree, size_t n, uint64_t ce
     for (uint32_t c = 0; c < nsub; ++c) {
         size_t lo = 0, hi = nrest;
         while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (rest[mid].key < sub[c]) lo = mid + 1; else hi = mid; }
-        start[c] = consumed + lo;        /* children c-1 (or the head, c == 0) ends here */
+        start[c] = consumed + lo;
         rest += lo; nrest -= lo; consumed += lo;
     }
     start[nsub] = n;
     results_push_all(t, tree, start[0]);                                                       /* head :216-219 */
-    /* BoxTestGeometry::subdivide (geom.rs:383-407 / :418-446): center = min.midpoint(max) */
-    float center[3];
-    for (uint32_t a = 0; a < t->dim; ++a)
-        center[a] = cell_bounds->mn[a] + (cell_bounds->mx[a] - cell_bounds->mn[a]) / 2.0f;
-    for (uint32_t c = 0; c < nsub; ++c) {                                                      /* test_order = 0..n :449 */
-        fbounds_t b = *cell_bounds;
-        for (uint32_t a = 0; a < t->dim; ++a) {
-            if (c & (1u << a)) b.mn[a] = center[a]; else b.mx[a] = center[a];
-        }
-        test_impl_box(t, tree + start[c], start[c + 1] - start[c], sub[c], &b);
+    for (uint32_t c = 0; c < nsub; ++c) {
+        tgeom_t child;
+        geom_child(t, g, c, &child);
+        test_impl(t, tree + start[c], start[c + 1] - start[c], sub[c], &child);
         if (t->err) return;
     }
 }
@@ -749,18 +783,13 @@ static int cmp_u32(const void *a, const void *b) {
     return x < y ? -1 : x > y;
 }
 
-/* Layer::test_box (layer.rs:294-313) -> Layer::test (:252-279): sort, test_impl from the root cell,
- * results.sort(); results.dedup().  Returns the number of ids written (<= cap), or < 0 on error. */
-long orc_layer_test_box(orc_layer_t *l, const float *sys_min, const float *sys_max, const float *tmin, const float *tmax,
-                        int has_max_depth, uint32_t max_depth, uint32_t *out, size_t cap) {
-    orc_kind_t k; orc_kind(l->kind, &k);
+/* Layer::test (layer.rs:252-279): sort, test_impl from the root cell, results.sort(); results.dedup() */
+static long run_region_test(orc_layer_t *l, regiontest_t *t, const tgeom_t *root, uint32_t *out, size_t cap) {
     orc_layer_sort(l);                                                                          /* :260 */
     u32vec_t res = {0, 0, 0};
-    boxtest_t t = { l->kind, k.dim, tmin, tmax, has_max_depth, max_depth, &res, 0 };
-    fbounds_t root;
-    for (uint32_t a = 0; a < 3; ++a) { root.mn[a] = a < k.dim ? sys_min[a] : 0.f; root.mx[a] = a < k.dim ? sys_max[a] : 0.f; }
-    test_impl_box(&t, l->tree.p, l->tree.n, 0, &root);                                          /* Index::default() :265 */
-    if (t.err) { free(res.p); return t.err; }
+    t->results = &res; t->err = 0;
+    test_impl(t, l->tree.p, l->tree.n, 0, root);                                                /* Index::default() :265 */
+    if (t->err) { free(res.p); return t->err; }
     qsort(res.p, res.n, sizeof(uint32_t), cmp_u32);                                             /* :274 */
     size_t w = 0;
     for (size_t i = 0; i < res.n; ++i) if (i == 0 || res.p[i] != res.p[i - 1]) res.p[w++] = res.p[i];   /* :275 */
@@ -768,6 +797,40 @@ long orc_layer_test_box(orc_layer_t *l, const float *sys_min, const float *sys_m
     if (w > cap) ret = -3; else memcpy(out, res.p, w * sizeof(uint32_t));
     free(res.p);
     return ret;
+}
+
+/* Layer::test_box (layer.rs:294-313) */
+long orc_layer_test_box(orc_layer_t *l, const float *sys_min, const float *sys_max, const float *tmin, const float *tmax,
+                        int has_max_depth, uint32_t max_depth, uint32_t *out, size_t cap) {
+    orc_kind_t k; orc_kind(l->kind, &k);
+    regiontest_t t; memset(&t, 0, sizeof t);
+    t.kind = l->kind; t.dim = k.dim; t.is_ray = 0; t.tmin = tmin; t.tmax = tmax;
+    t.has_max_depth = has_max_depth; t.max_depth = max_depth;
+    tgeom_t root; memset(&root, 0, sizeof root);
+    for (uint32_t a = 0; a < k.dim; ++a) { root.cell_bounds.mn[a] = sys_min[a]; root.cell_bounds.mx[a] = sys_max[a]; }
+    return run_region_test(l, &t, &root, out, cap);
+}
+
+/* Layer::test_ray (layer.rs:327-351) with RayTestGeometry::with_system_bounds (geom.rs:511-537) */
+long orc_layer_test_ray(orc_layer_t *l, const float *sys_min, const float *sys_max, const float *origin,
+                        const float *direction, float range_min, float range_max, int has_max_depth, uint32_t max_depth,
+                        uint32_t *out, size_t cap) {
+    orc_kind_t k; orc_kind(l->kind, &k);
+    regiontest_t t; memset(&t, 0, sizeof t);
+    t.kind = l->kind; t.dim = k.dim; t.is_ray = 1; t.origin = origin; t.direction = direction;
+    t.has_max_depth = has_max_depth; t.max_depth = max_depth;
+    tgeom_t root; memset(&root, 0, sizeof root);
+    for (uint32_t a = 0; a < k.dim; ++a) {
+        root.cell_bounds.mn[a] = sys_min[a]; root.cell_bounds.mx[a] = sys_max[a];
+        const float distance_0 = (sys_min[a] - origin[a]) / direction[a];
+        const float distance_1 = (sys_max[a] - origin[a]) / direction[a];
+        const int is_forward = direction[a] > 0.0f;
+        const float d0 = is_forward ? distance_0 : distance_1, d1 = is_forward ? distance_1 : distance_0;
+        if (isfinite(d0)) range_min = fmaxf(range_min, d0);
+        if (isfinite(d1)) range_max = fminf(range_max, d1);
+    }
+    root.range_min = range_min; root.range_max = range_max;
+    return run_region_test(l, &t, &root, out, cap);
 }
 
 /* geom.rs:112-119 (Bounds::overlaps, inclusive) over all i<j */

@@ -103,6 +103,12 @@ size_t          orc_layer_num_invalid(const orc_layer_t *);
 long orc_layer_test_box(orc_layer_t *, const float *sys_min, const float *sys_max, const float *test_min,
                         const float *test_max, int has_max_depth, uint32_t max_depth, uint32_t *out, size_t cap);
 
+/* Layer::test_ray (layer.rs:327-351; RayTestGeometry geom.rs:460-689): ids whose cells the ray
+ * origin + t * direction, t in [range_min, range_max] (clamped to the system bounds), passes through */
+long orc_layer_test_ray(orc_layer_t *, const float *sys_min, const float *sys_max, const float *origin,
+                        const float *direction, float range_min, float range_max, int has_max_depth, uint32_t max_depth,
+                        uint32_t *out, size_t cap);
+
 size_t orc_brute_force_overlaps(uint32_t dim, const float *bounds, size_t n, uint32_t *pairs, size_t cap);
 
 /* number of hardware threads the par_* baseline can use */

@@ -213,3 +213,64 @@ class PyLayer:
             if ok:
                 out.add(id_)
         return sorted(out)
+
+    def test_ray(self, system_bounds, origin, direction, range_min=-np.inf, range_max=np.inf, max_depth=None):
+        """Layer::test_ray (layer.rs:327-351) in closed form: replay the path of every entry with
+        RayTestGeometry::with_system_bounds / subdivide / should_test (geom.rs:511-537, 617-661, 686-688)."""
+        self.sort()
+        dim, _bits, db, ab = KINDS[self.kind]
+        f = np.float32
+        smin = [f(v) for v in system_bounds[0]]
+        smax = [f(v) for v in system_bounds[1]]
+        o = [f(v) for v in origin]
+        dr = [f(v) for v in direction]
+        inf = f(np.inf)
+
+        def fmax(a, b):  # f32::max: a NaN operand loses
+            return b if np.isnan(a) else (a if np.isnan(b) else max(a, b))
+
+        def fmin(a, b):
+            return b if np.isnan(a) else (a if np.isnan(b) else min(a, b))
+
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            r0, r1 = f(range_min), f(range_max)
+            for a in range(dim):
+                d0 = f(f(smin[a] - o[a]) / dr[a])
+                d1 = f(f(smax[a] - o[a]) / dr[a])
+                if not dr[a] > 0:
+                    d0, d1 = d1, d0
+                if np.isfinite(d0):
+                    r0 = fmax(r0, d0)
+                if np.isfinite(d1):
+                    r1 = fmin(r1, d1)
+            out = set()
+            for index, id_ in self.tree:
+                d = depth_of(self.kind, index)
+                levels = d if max_depth is None else min(d, max_depth)
+                morton = index >> db
+                mn, mx, lo, hi = list(smin), list(smax), r0, r1
+                ok = bool(lo < hi and lo < inf)
+                for lvl in range(1, levels + 1):
+                    if not ok:
+                        break
+                    child = (morton >> (dim * (ab - lvl))) & ((1 << dim) - 1)
+                    ctr = [f(mn[a] + f(f(mx[a] - mn[a]) / f(2.0))) for a in range(dim)]
+                    for a in range(dim):
+                        side = bool(child & (1 << a))
+                        dist = f(f(ctr[a] - o[a]) / dr[a])
+                        if np.isfinite(dist):
+                            if bool(dr[a] > 0) != side:
+                                hi = fmin(hi, dist)
+                            else:
+                                lo = fmax(lo, dist)
+                        elif bool(o[a] > ctr[a]) != side:
+                            lo, hi = inf, -inf
+                    for a in range(dim):
+                        if child & (1 << a):
+                            mn[a] = ctr[a]
+                        else:
+                            mx[a] = ctr[a]
+                    ok = bool(lo < hi and lo < inf)
+                if ok:
+                    out.add(id_)
+        return sorted(out)

@@ -439,3 +439,40 @@ def test_test_box_batch_empty_and_large_results():
     assert len(rows) == 70 * len(ids)
     assert np.array_equal(rows[:len(ids), 1], np.sort(ids))
     assert np.array_equal(ref.test_box(sysb, (sysb[0], sysb[1])), np.sort(ids))
+
+
+@pytest.mark.parametrize("kind,min_depth", [(2, 0), (1, 0), (0, 3)])
+def test_test_ray_batch_matches_reference_recursion(kind, min_depth):
+    # Layer::test_ray, src/layer.rs:327-351 with RayTestGeometry, src/geom.rs:460-689
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(5000, seed=50 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2])
+        bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    gpu, ref = both(kind, min_depth)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(100 + kind)
+    L = float(sysb[1][0])
+    nq = 240
+    org = rng.uniform(-0.2 * L, 1.2 * L, size=(nq, dim)).astype(np.float32)
+    dirs = rng.normal(size=(nq, dim)).astype(np.float32)
+    dirs[::7, 0] = 0.0                                   # axis-parallel rays: infinite / NaN plane distances
+    dirs[5] = 0.0                                        # degenerate: no direction at all
+    org[::11] = bounds[: len(org[::11]), :dim]           # origins exactly on object corners
+    rng_lo = np.where(np.arange(nq) % 3 == 0, -np.inf, 0.0).astype(np.float32)
+    rng_hi = np.where(np.arange(nq) % 3 == 2, L / 3, np.inf).astype(np.float32)
+    rays = np.concatenate([org, dirs, rng_lo[:, None], rng_hi[:, None]], axis=1).astype(np.float32)
+    for max_depth in (None, 3, 8):
+        rows = np.array(gpu.test_ray_batch(sysb, rays, max_depth))
+        k = rows[:, 0].astype(np.uint64) << np.uint64(32) | rows[:, 1].astype(np.uint64)
+        assert np.all(k[1:] > k[:-1])
+        splits = np.searchsorted(rows[:, 0], np.arange(nq + 1))
+        total = 0
+        for q in range(nq):
+            exp = ref.test_ray(sysb, org[q], dirs[q], rng_lo[q], rng_hi[q], max_depth)
+            got = rows[splits[q]:splits[q + 1], 1]
+            assert np.array_equal(got, exp), "ray %d max_depth %s: %d vs %d ids" % (q, max_depth, len(got), len(exp))
+            total += len(exp)
+        assert total > nq                                # the rays do hit things
+    got = gpu.test_ray(sysb, org[1], dirs[1])
+    assert np.array_equal(got, ref.test_ray(sysb, org[1], dirs[1]))

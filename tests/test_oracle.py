@@ -200,3 +200,47 @@ def test_duplicate_ids_skip_rule_and_edge_boxes():
     assert pairs == p.scan()
     assert all(a != b for a, b in pairs)
     assert (9, 7) in pairs and (3, 7) in pairs
+
+
+# ---- region queries: the two restatements of test_impl must agree -----------------
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_region_queries_recursive_c_vs_closed_form_python(kind):
+    from broadphase_rs_amd import scenes
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(300, seed=kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2]); bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    c, p = oracle.OracleLayer(kind, 0), P.PyLayer(kind, 0)
+    c.extend(sysb, bounds, ids); p.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(kind)
+    L = float(sysb[1][0])
+    hits = 0
+    for q in range(25):
+        ctr = rng.uniform(0, L, dim); h = rng.uniform(0.5, L / 6, dim)
+        tb = ((ctr - h).astype(np.float32), (ctr + h).astype(np.float32))
+        for md in (None, 0, 3, 6):
+            got = c.test_box(sysb, tb, md)                       # layer.rs:294-313
+            assert got.tolist() == p.test_box(sysb, tb, md)
+            assert np.all(got[1:] > got[:-1])                    # results.sort(); results.dedup() (layer.rs:274-275)
+        # broadphase guarantee (geom.rs:112-119 inclusive overlap): nothing that truly overlaps is missing
+        true = [i for i in range(len(bounds))
+                if not any(bounds[i][a] > tb[1][a] or bounds[i][dim + a] < tb[0][a] for a in range(dim))]
+        assert set(true) <= set(c.test_box(sysb, tb).tolist())
+        org = rng.uniform(-0.2 * L, 1.2 * L, dim).astype(np.float32)
+        d = rng.normal(size=dim).astype(np.float32)
+        if q % 5 == 0:
+            d[0] = 0.0                                           # infinite / NaN plane distances (geom.rs:640-643)
+        lo, hi = [(-np.inf, np.inf), (0.0, np.inf), (0.0, L / 3)][q % 3]
+        for md in (None, 4):
+            got = c.test_ray(sysb, org, d, lo, hi, md)           # layer.rs:327-351
+            assert got.tolist() == p.test_ray(sysb, org, d, lo, hi, md)
+            hits += len(got)
+    assert hits > 0
+    # the worked example of SURVEY 8(c): objects 0..3 in [0,16]^3
+    if kind == 2:
+        w = oracle.OracleLayer(2, 0)
+        sb = ([0.0] * 3, [16.0] * 3)
+        w.extend(sb, [[1, 1, 1, 2, 2, 2], [1.5, 1.5, 1.5, 3, 3, 3], [0, 0, 0, 16, 16, 16], [7, 7, 7, 9, 9, 9]], [0, 1, 2, 3])
+        assert w.test_box(sb, ([1.0] * 3, [2.0] * 3)).tolist() == [0, 1, 2]
+        assert w.test_box(sb, ([10.0] * 3, [12.0] * 3), 2).tolist() == [2, 3]
+        assert w.test_ray(sb, [0.5, 8.0, 8.0], [1.0, 0.0, 0.0]).tolist() == [2, 3]
