@@ -67,9 +67,10 @@ struct SysBounds {
 
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
-constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_emit
+constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
-inline size_t enc_blocks(size_t n) { return (n + ENC_THREADS - 1) / ENC_THREADS; }
+// workgroups (= block sums / BlockAux partials) for n objects
+inline size_t enc_blocks(size_t n) { return (n + (size_t)ENC_THREADS * ENC_ROUNDS - 1) / ((size_t)ENC_THREADS * ENC_ROUNDS); }
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                                uint32_t min_depth, int have_prev_id, uint32_t prev_id, uint32_t* counts,
@@ -188,7 +189,10 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 // caller derives  pairs = sum(counts),  extent = max(cursor) * SX_SHARDS * SX_BLOCK  and re-runs with
 // more blocks when extent exceeds the capacity.  big_list: scratch for big_cap u64 work items;
 // KERR_BIGLIST_OVERFLOW in sc->err means the result is incomplete (use scan_fused).
-constexpr uint32_t SX_BLOCK = 256;
+#ifndef SX_BLOCK_DEF
+#define SX_BLOCK_DEF 256
+#endif
+constexpr uint32_t SX_BLOCK = SX_BLOCK_DEF;
 constexpr int SX_SHARDS = 64;
 constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel

@@ -134,10 +134,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
         s_inv[ENC_THREADS / 64], s_ior[ENC_THREADS / 64], s_iand[ENC_THREADS / 64], s_imax[ENC_THREADS / 64],
         s_imin[ENC_THREADS / 64];
     __shared__ u64 s_kor[ENC_THREADS / 64], s_kand[ENC_THREADS / 64];
-    const size_t i = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x;
+    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup: a quarter of the partials for scan_block_sums to fold
     u32 cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
     u64 kor = 0, kand = ~0ull;
-    if (i < n) {
+    for (int round = 0; round < ENC_ROUNDS; ++round) {
+        const size_t i = ((size_t)blockIdx.x * ENC_ROUNDS + round) * ENC_THREADS + threadIdx.x;
+        if (i >= n) break;
         const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
         const u32 id = ids[i];
         u32 prev = prev_id;
@@ -150,15 +152,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
             if (id < prev) flags |= EXT_IDS_DECREASE | EXT_IDS_REPEAT;
             else if (id == prev) flags |= EXT_IDS_REPEAT;
         }
-        imax = id;
-        imin = id;
+        imax = id > imax ? id : imax;
+        imin = id < imin ? id : imin;
         if (c.overflow && c.valid) err |= KERR_COUNT_OVERFLOW;
-        if (!c.valid) inv = 1;
-        cnt = c.count;
-        if (cnt > 0) {
+        if (!c.valid) inv += 1;
+        const u32 c_cnt = c.count;
+        cnt += c_cnt;
+        if (c_cnt > 0) {
             if (c.n[0] > 2 || c.n[1] > 2 || c.n[2] > 2) flags |= EXT_BOX_UNKNOWN;
-            dmask = 1u << c.depth;
-            ior = iand = id;
+            dmask |= 1u << c.depth;
+            ior |= id;
+            iand &= id;
             // OR / AND over this object's index values without enumerating its cells
             u32 o[3] = {0, 0, 0}, a[3] = {0, 0, 0};
 #pragma unroll
@@ -170,10 +174,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
                 mo |= spread_bits<DIM>((u64)o[2] << up) << 2;
                 ma |= spread_bits<DIM>((u64)a[2] << up) << 2;
             }
-            kor = (mo << DB) | c.depth;
-            kand = (ma << DB) | c.depth;
+            kor |= (mo << DB) | c.depth;
+            kand &= (ma << DB) | c.depth;
         }
-        counts[i] = cnt;
+        counts[i] = c_cnt;
     }
     // workgroup reduction -> one BlockAux + one block sum per workgroup (no atomics)
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup (block_offs is per block of ENC_THREADS objects)
+    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup; block_offs[blockIdx.x] = first entry of the workgroup
+    size_t round_base = (size_t)block_offs[blockIdx.x];
     for (int round = 0; round < ENC_ROUNDS; ++round) {
         const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
         if (blk * ENC_THREADS >= n) break;  // workgroup-uniform
@@ -237,10 +242,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         const u32 cnt = i < n ? counts[i] : 0u;
         u32 total;
         const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
+        const size_t this_base = round_base;
+        round_base += total;
         if (cnt == 0) continue;
         const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
         const u32 id = ids[i];
-        size_t pos = (size_t)block_offs[blk] + excl;
+        size_t pos = this_base + excl;
         if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
             keys_out[pos] = 0ull;
             ids_out[pos] = id;
@@ -391,7 +398,7 @@ constexpr u64 ST_FLAG_AGG = 1ull << 62;   // tile-local digit count published
 constexpr u64 ST_FLAG_PRE = 2ull << 62;   // inclusive prefix over tiles 0..t published
 constexpr u64 ST_VALUE = (1ull << 62) - 1ull;
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
-constexpr u32 HOLE_BLOCK = 256;  // records per block of a block-structured input (expanding scan output)
+constexpr u32 HOLE_BLOCK = SX_BLOCK;  // records per block of a block-structured input (expanding scan output)
 
 __device__ __forceinline__ void st_store(u64* p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1318,8 +1325,16 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
     }
 }
 
+#ifndef SX_WAVES_PER_EU
+#define SX_WAVES_PER_EU 0
+#endif
+#if SX_WAVES_PER_EU
+#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SX_WAVES_PER_EU, SX_WAVES_PER_EU)))
+#else
+#define SX_OCC_ATTR
+#endif
 template <int KIND, bool FILT>
-__global__ __launch_bounds__(SX_THREADS) void scan_expand_kernel(ExpandParams p) {
+__global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
     __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
@@ -1738,7 +1753,7 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist) {
     if (n == 0) return hipSuccess;
-    const unsigned g = (unsigned)((enc_blocks(n) + ENC_ROUNDS - 1) / ENC_ROUNDS);
+    const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
     dc.hist = (u64*)hist; dc.passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) dc.shift[q] = 0;
