@@ -78,7 +78,8 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
-                              const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
+                              const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0);
+// pack_box: write id | box_to_packed(code) << BOX_ID_BITS into ids_out (box_out may then be nullptr)
 // hist_plan / hist: also count the key digits of every emitted entry for the passes of hist_plan
 // (<= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller)
 

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                                                                  const u32* __restrict__ counts,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
-                                                                 uint8_t* __restrict__ box_out, DigitCount dc) {
+                                                                 uint8_t* __restrict__ box_out, DigitCount dc, int pack_box) {
+    // pack_box: the box code rides in bits 27..31 of the id from the start (ids < 2^27, see BOX_ID_BITS) and
+    // no box byte is written: the first pass of the tree sort then has no byte stream to gather
     constexpr u32 DIM = KT<KIND>::DIM;
     __shared__ u32 s_ws[ENC_THREADS / 64];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         size_t pos = this_base + excl;
         if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
             keys_out[pos] = 0ull;
-            ids_out[pos] = id;
+            ids_out[pos] = id;  // box code 0 packs to 0
             if (box_out) box_out[pos] = 0;
             count_digits(0ull);
             continue;
@@ -262,11 +264,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 for (u32 x = 0; x < c.n[0]; ++x) {
                     const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
                     keys_out[pos] = key;
-                    ids_out[pos] = id;
-                    if (box_out) {
-                        const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
-                        box_out[pos] = boxy ? (uint8_t)(tx | (ty << 2) | (tz << 4)) : (uint8_t)BOX_UNKNOWN;
-                    }
+                    const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
+                    const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
+                    ids_out[pos] = pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id;
+                    if (box_out) box_out[pos] = (uint8_t)code;
                     count_digits(key);
                     ++pos;
                 }
@@ -1751,7 +1752,7 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
-                              const RadixPlan* hist_plan, unsigned long long* hist) {
+                              const RadixPlan* hist_plan, unsigned long long* hist, int pack_box) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
@@ -1766,7 +1767,7 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
         }
     }
     BP_DISPATCH_KIND(kind, (encode_emit_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                 block_offs, (u64*)keys_out, ids_out, box_out, dc)));
+                                                                                 block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
     return hipGetLastError();
 }
 

@@ -320,6 +320,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         sb.mn[a] = a < ki.dim ? sys_min[a] : 0.f;
         sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
     }
+    if (L->m) BP_TRY(ensure_unpacked(L));  // appending to a tree whose ids still carry their box codes
     const size_t nb = enc_blocks(n);
     BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
@@ -357,6 +358,10 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     const bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
                               hist_plan.n_passes <= SX_HIST_MAX;
     L->tree_hist_valid = false;
+    // same situation: the codes can ride in the ids from the start (ids distinct and < 2^27), so the tree
+    // sort's first pass has no box bytes to gather and none are written here
+    static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;  // A/B switch for measurements
+    const bool pack = !no_emit_pack && L->m == 0 && L->box_valid && L->ids_distinct && (sc.id_or >> BOX_ID_BITS) == 0;
     if (count_digits) {
         BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
         HIP_TRY(L, hipMemsetAsync(L->tree_hist.p, 0, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
@@ -365,9 +370,11 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
-                                      (uint8_t*)L->box[L->cur].p + L->m, L->stream, count_digits ? &hist_plan : nullptr,
-                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr));
+                                      pack ? nullptr : (uint8_t*)L->box[L->cur].p + L->m, L->stream,
+                                      count_digits ? &hist_plan : nullptr,
+                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0));
     }
+    if (pack) { L->ids_packed = true; L->box_valid = false; }  // until the sort (or ensure_unpacked) splits them off
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
     BP_TRY(sync_stream(L));
     L->m += add;
@@ -403,7 +410,7 @@ int absorb_raw_entries(bp_layer* L, const uint64_t* d_keys, const uint32_t* d_id
 
 // ---- sort -----------------------------------------------------------------------------------------------
 bool box_can_ride(const bp_layer* L) {  // the box codes travel in the id payload's bits 27..31
-    return L->box_valid && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
+    return (L->box_valid || L->ids_packed) && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
 }
 
 // full-width LSD sort (every varying key bit, ids first when the order fact is missing)
@@ -1456,7 +1463,8 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: bad split_depth / n_cells / n_dest");
     if (pack_box && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
     DeviceGuard g(L->device);
-    BP_TRY(ensure_unpacked(L));
+    const bool already_packed = pack_box && L->ids_packed;  // extend wrote the codes into the ids: nothing to do
+    if (!already_packed) BP_TRY(ensure_unpacked(L));
     const int other = L->cur ^ 1;
     for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = 0;
     BP_TRY(ensure_dev(L, L->keys[other], std::max<size_t>(L->m, 1) * sizeof(uint64_t)));
@@ -1476,7 +1484,7 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
         HIP_TRY(L, partition_entries(cur_keys(L), (uint64_t*)L->keys[other].p, cur_ids(L), (uint32_t*)L->ids[other].p, L->m,
                                      (const unsigned char*)L->skip.p, cell_shift, (1u << ki.depth_bits) - 1u, split_depth, n_dest,
                                      L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream,
-                                     pack_box ? (const uint8_t*)L->box[L->cur].p : nullptr));
+                                     (pack_box && !already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr));
     }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
