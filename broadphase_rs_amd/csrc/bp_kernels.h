@@ -68,6 +68,7 @@ struct SysBounds {
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
+constexpr int ENC_STAGE = 2048;   // entries of one round staged in LDS by encode_emit (8 per object)
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
 // workgroups (= block sums / BlockAux partials) for n objects
 inline size_t enc_blocks(size_t n) { return (n + (size_t)ENC_THREADS * ENC_ROUNDS - 1) / ((size_t)ENC_THREADS * ENC_ROUNDS); }

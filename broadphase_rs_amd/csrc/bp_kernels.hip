@@ -235,7 +235,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup; block_offs[blockIdx.x] = first entry of the workgroup
+    // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup; block_offs[blockIdx.x] = first entry of the workgroup.
+    // A round's entries (<= 8 per object unless min_depth forces more) are staged in LDS in output order and
+    // stored with consecutive threads on consecutive entries; a round that does not fit stores directly.
+    __shared__ u64 s_key[ENC_STAGE];
+    __shared__ u32 s_id[ENC_STAGE];
+    __shared__ uint8_t s_box[ENC_STAGE];
     size_t round_base = (size_t)block_offs[blockIdx.x];
     for (int round = 0; round < ENC_ROUNDS; ++round) {
         const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
@@ -246,31 +251,49 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
         const size_t this_base = round_base;
         round_base += total;
-        if (cnt == 0) continue;
-        const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
-        const u32 id = ids[i];
-        size_t pos = this_base + excl;
-        if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
-            keys_out[pos] = 0ull;
-            ids_out[pos] = id;  // box code 0 packs to 0
-            if (box_out) box_out[pos] = 0;
-            count_digits(0ull);
-            continue;
+        const bool staged = total <= (u32)ENC_STAGE;  // workgroup-uniform
+        auto put = [&](u32 local, u64 key, u32 idv, u32 code) {
+            if (staged) {
+                s_key[local] = key;
+                s_id[local] = idv;
+                s_box[local] = (uint8_t)code;
+            } else {
+                keys_out[this_base + local] = key;
+                ids_out[this_base + local] = idv;
+                if (box_out) box_out[this_base + local] = (uint8_t)code;
+            }
+        };
+        if (cnt != 0) {
+            const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
+            const u32 id = ids[i];
+            u32 local = excl;
+            if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
+                put(local, 0ull, id, 0u);  // box code 0 packs to 0
+                count_digits(0ull);
+            } else {
+                const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
+                // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
+                for (u32 z = 0; z < c.n[2]; ++z)
+                    for (u32 y = 0; y < c.n[1]; ++y)
+                        for (u32 x = 0; x < c.n[0]; ++x) {
+                            const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
+                            const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
+                            const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
+                            put(local, key, pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id, code);
+                            count_digits(key);
+                            ++local;
+                        }
+            }
         }
-        const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
-        // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
-        for (u32 z = 0; z < c.n[2]; ++z)
-            for (u32 y = 0; y < c.n[1]; ++y)
-                for (u32 x = 0; x < c.n[0]; ++x) {
-                    const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
-                    keys_out[pos] = key;
-                    const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
-                    const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
-                    ids_out[pos] = pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id;
-                    if (box_out) box_out[pos] = (uint8_t)code;
-                    count_digits(key);
-                    ++pos;
-                }
+        if (staged) {
+            __syncthreads();
+            for (u32 k = threadIdx.x; k < total; k += ENC_THREADS) {
+                keys_out[this_base + k] = s_key[k];
+                ids_out[this_base + k] = s_id[k];
+                if (box_out) box_out[this_base + k] = s_box[k];
+            }
+            __syncthreads();  // the stage is reused by the next round
+        }
     }
     if (dc.passes) {  // workgroup-uniform.  One device atomic per bin per workgroup would serialise on the bin's
         __syncthreads();  // address (~11 ns each): the workgroups spread over HIST_COPIES copies, summed by the sort
