@@ -70,6 +70,7 @@ struct bp_layer {
     size_t n_raw = 0, n_pairs = 0;
     bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
     DevBuf idctx, big_list;             // expanding scan: per-entry id << 32 | suppression context; long-range work list
+    size_t big_cap = 0;                 // work-list capacity in use
     DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
     HostBuf h_shards;
     bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
@@ -759,7 +760,10 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), p.box, L->m, thr, (uint64_t*)L->idctx.p, L->stream));
             L->ctx_epoch = L->epoch; L->ctx_thr = thr; L->ctx_box = with_box;
         }
-        BP_TRY(ensure_dev(L, L->big_list, std::max<size_t>(65536, L->m / 16) * sizeof(uint64_t)));
+        size_t big_cap = std::max<size_t>(65536, L->m / 16);
+        if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));  // test hook: force the overflow fallback
+        L->big_cap = big_cap;
+        BP_TRY(ensure_dev(L, L->big_list, big_cap * sizeof(uint64_t)));
     }
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -784,7 +788,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds,
                                               (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p,
                                               (uint64_t*)L->big_list.p,
-                                              (uint32_t)std::min<size_t>(L->big_list.cap / sizeof(uint64_t), 0xFFFFFFFFu),
+                                              (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
                                               (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
                                               count_digits ? (unsigned long long*)L->pair_hist.p : nullptr));
             }

@@ -476,3 +476,28 @@ def test_test_ray_batch_matches_reference_recursion(kind, min_depth):
         assert total > nq                                # the rays do hit things
     got = gpu.test_ray(sysb, org[1], dirs[1])
     assert np.array_equal(got, ref.test_ray(sysb, org[1], dirs[1]))
+
+
+def test_long_ranges_go_through_the_work_list_and_its_overflow_falls_back(monkeypatch):
+    # two whole-system boxes + many small ones: the root entries own ranges of ~10^5 candidates (>= SX_BIG),
+    # which the expanding scan cuts into work-list slices; with the list capacity forced to 1 the scan must
+    # notice the overflow and fall back to the per-entry walk -- same result both ways
+    sysb, bounds, ids = scenes.gen_boxes(40000, seed=11)
+    big = np.concatenate([sysb[0], sysb[1]]).astype(np.float32)
+    bounds = np.concatenate([bounds, big[None, :], big[None, :]]).astype(np.float32)
+    ids = np.arange(len(bounds), dtype=np.uint32)
+    ref = oracle.OracleLayer(2, 0)
+    ref.extend(sysb, bounds, ids)
+    exp = ref.scan()
+    assert (exp[:, 1] >= 40000).sum() >= 2 * 40000 - 2           # everything pairs with both big boxes
+    for cap in (None, "1"):
+        if cap is None:
+            monkeypatch.delenv("BP_BIGLIST_CAP", raising=False)
+        else:
+            monkeypatch.setenv("BP_BIGLIST_CAP", cap)
+        gpu = bp.Layer(bp.Index64_3D, 0)
+        gpu.extend(sysb, bounds, ids)
+        assert_pairs_equal(gpu.par_scan(), exp, "long ranges, work-list capacity %s" % cap)
+        st = gpu.stats()
+        assert st["raw_pairs"] == len(exp)
+        assert (st["raw_candidates"] > 0) == (cap is None)       # the fallback kernel does not count candidates
