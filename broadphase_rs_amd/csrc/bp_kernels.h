@@ -210,9 +210,14 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
 // recursion reaches, block-structured like the scan's output (blockfill / shards zeroed by the caller).
 // queries (device memory): n_queries rows of 2*dim f32 [min, max] (ray = 0) or 2*dim + 2 f32
 // [origin, direction, range_min, range_max] (ray = 1)
+// qtab / qtab_levels (optional): slice bounds of the cells of depths 1..qtab_levels (launch_query_table), read by
+// the walk instead of bisecting the top of the tree for every query
 hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb,
                                const float* queries, uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out,
-                               size_t out_blocks, uint32_t* blockfill, uint64_t* shards, hipStream_t stream);
+                               size_t out_blocks, uint32_t* blockfill, uint64_t* shards, hipStream_t stream,
+                               const uint32_t* qtab = nullptr, uint32_t qtab_levels = 0);
+uint32_t query_table_entries(int kind, uint32_t levels);
+hipError_t launch_query_table(int kind, const uint64_t* keys, size_t m, uint32_t levels, uint32_t* qtab, hipStream_t stream);
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

@@ -2118,10 +2118,35 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
 // bounds (:511-537), subdivide narrows it by the distances to the centre planes (:617-661, the non-finite
 // distance case included), should_test = range_min < range_max (:686-688).  test_order only matters for the
 // nearest-hit early-out of `pick`, not for the result set of `test`.
+// Slice bounds of the top levels, shared by every query: qtab[qtab_offset(l) + c] = first index whose key is >=
+// the key of cell c (Morton prefix, in key order) at depth l, for l = 1..levels.  The walk below reads these
+// instead of bisecting the largest slices (the values are the same lower bounds).
+template <int KIND> __host__ __device__ constexpr u32 qtab_offset(u32 l) {  // entries of the levels 1..l-1
+    u32 off = 0, n = 1u << KT<KIND>::DIM;
+    for (u32 k = 1; k < l; ++k) { off += n; n <<= KT<KIND>::DIM; }
+    return off;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void query_table_kernel(const u64* __restrict__ keys, u32 m, u32 levels, u32* __restrict__ qtab) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, TOP = DIM * AB + DB;
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    u32 l = 1, base = 0, n = 1u << DIM;
+    while (l <= levels && t >= base + n) { base += n; n <<= DIM; ++l; }
+    if (l > levels) return;
+    const u64 key = ((u64)(t - base) << (TOP - DIM * l)) | (u64)l;
+    u32 a = 0, b = m;
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        if (keys[mid] < key) a = mid + 1; else b = mid;
+    }
+    qtab[t] = a;
+}
+
 template <int KIND, bool RAY>
 __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p, const u32* __restrict__ ids, SysBounds sb,
                                                                   const float* __restrict__ queries, u32 n_queries,
-                                                                  int has_max_depth, u32 max_depth) {
+                                                                  int has_max_depth, u32 max_depth,
+                                                                  const u32* __restrict__ qtab, u32 qtab_levels) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, NSUB = 1u << DIM;
     constexpr u32 TOP = DIM * AB + DB;
     constexpr u32 ROW = RAY ? 2 * DIM + 2 : 2 * DIM;
@@ -2196,7 +2221,9 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
                     --level;
                 } else {
                     const u64 first_child = cell[l] + 1ull;  // child 0: same Morton bits, depth + 1
-                    const u32 s0 = lower_bound(lo[l], hi[l], first_child);
+                    const u32 s0 = (u32)l + 1u <= qtab_levels
+                                       ? qtab[qtab_offset<KIND>((u32)l + 1u) + (u32)(first_child >> (TOP - DIM * ((u32)l + 1u)))]
+                                       : lower_bound(lo[l], hi[l], first_child);
                     ea = lo[l]; eb = s0;  // the entries exactly at this cell (:216-219)
                     cur[l] = s0;
                     child[l] = 0;
@@ -2208,7 +2235,10 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
                 const u32 shift = TOP - DIM * ((u32)l + 1u);
                 const u64 base_key = (cell[l] & ~(u64)((1u << DB) - 1u)) | (u64)((u32)l + 1u);
                 const u32 a0 = cur[l];
-                const u32 b0 = c + 1u == NSUB ? hi[l] : lower_bound(a0, hi[l], base_key | ((u64)(c + 1u) << shift));
+                const u64 next_key = base_key | ((u64)(c + 1u) << shift);
+                const u32 b0 = c + 1u == NSUB ? hi[l]
+                               : ((u32)l + 1u <= qtab_levels ? qtab[qtab_offset<KIND>((u32)l + 1u) + (u32)(next_key >> shift)]
+                                                              : lower_bound(a0, hi[l], next_key));
                 cur[l] = b0;
                 child[l] = c + 1u;
                 if (a0 < b0) {
@@ -2254,9 +2284,22 @@ __global__ __launch_bounds__(256) void compact_blocks_kernel(const u64* __restri
     const u64 o = offs[g];
     for (u32 k = (u32)lane_id(); k < cnt; k += 64) out[o + k] = in[g * SX_BLOCK + k];
 }
+uint32_t query_table_entries(int kind, uint32_t levels) {
+    const KindInfo ki = kind_info(kind);
+    uint32_t tot = 0, n = 1u << ki.dim;
+    for (uint32_t l = 1; l <= levels; ++l) { tot += n; n <<= ki.dim; }
+    return tot;
+}
+hipError_t launch_query_table(int kind, const uint64_t* keys, size_t m, uint32_t levels, uint32_t* qtab, hipStream_t stream) {
+    const uint32_t n = query_table_entries(kind, levels);
+    if (n == 0) return hipSuccess;
+    const unsigned g = (n + 255) / 256;
+    BP_DISPATCH_KIND(kind, (query_table_kernel<K><<<g, 256, 0, stream>>>((const u64*)keys, (u32)m, levels, qtab)));
+    return hipGetLastError();
+}
 hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* boxes,
                                uint32_t n_queries, int has_max_depth, uint32_t max_depth, uint64_t* out, size_t out_blocks,
-                               uint32_t* blockfill, uint64_t* shards, hipStream_t stream) {
+                               uint32_t* blockfill, uint64_t* shards, hipStream_t stream, const uint32_t* qtab, uint32_t qtab_levels) {
     if (n_queries == 0 || m == 0) return hipSuccess;
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
@@ -2265,9 +2308,9 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {
-        BP_DISPATCH_KIND(kind, (region_query_kernel<K, true><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+        BP_DISPATCH_KIND(kind, (region_query_kernel<K, true><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth, qtab, qtab_levels)));
     } else {
-        BP_DISPATCH_KIND(kind, (region_query_kernel<K, false><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth)));
+        BP_DISPATCH_KIND(kind, (region_query_kernel<K, false><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth, qtab, qtab_levels)));
     }
     return hipGetLastError();
 }

@@ -71,6 +71,9 @@ struct bp_layer {
     bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
     DevBuf idctx, big_list;             // expanding scan: per-entry id << 32 | suppression context; long-range work list
     size_t big_cap = 0;                 // work-list capacity in use
+    DevBuf qtab;                        // region queries: slice bounds of the top levels of the sorted tree ...
+    uint64_t qtab_epoch = 0;            // ... computed for this epoch (0: never)
+    uint32_t qtab_levels = 0;
     DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
     HostBuf h_shards;
     bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
@@ -1254,6 +1257,14 @@ static int region_query_batch_impl(bp_layer* L, int ray, const float* sys_min, c
         HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, boxes, bytes, hipMemcpyHostToDevice, L->stream));
         d_boxes = (const float*)L->in_bounds.p;
     }
+    // slice bounds of the top levels (<= 2^18 cells), once per sorted tree; only worth it for a batch
+    const uint32_t want_levels = n_queries >= 4096 ? std::min<uint32_t>(18u / ki.dim, ki.axis_bits) : 0u;
+    if (want_levels && (L->qtab_epoch != L->epoch || L->qtab_levels != want_levels)) {
+        BP_TRY(ensure_dev(L, L->qtab, (size_t)query_table_entries(L->kind, want_levels) * sizeof(uint32_t)));
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_query_table(L->kind, cur_keys(L), L->m, want_levels, (uint32_t*)L->qtab.p, L->stream));
+        L->qtab_epoch = L->epoch; L->qtab_levels = want_levels;
+    }
     const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
     BP_TRY(ensure_dev(L, L->shards, shard_bytes));
     BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
@@ -1271,7 +1282,8 @@ static int region_query_batch_impl(bp_layer* L, int ray, const float* sys_min, c
             ProfScope ps(L, BP_K_SCAN_EMIT);
             HIP_TRY(L, launch_region_query(L->kind, ray, cur_keys(L), cur_ids(L), L->m, sb, d_boxes, (uint32_t)n_queries,
                                            has_max_depth, max_depth, (uint64_t*)L->pairs[0].p, out_blocks,
-                                           (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, L->stream));
+                                           (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, L->stream,
+                                           want_levels ? (const uint32_t*)L->qtab.p : nullptr, want_levels));
         }
         HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
         BP_TRY(sync_stream(L));

@@ -501,3 +501,43 @@ def test_long_ranges_go_through_the_work_list_and_its_overflow_falls_back(monkey
         st = gpu.stats()
         assert st["raw_pairs"] == len(exp)
         assert (st["raw_candidates"] > 0) == (cap is None)       # the fallback kernel does not count candidates
+
+
+@pytest.mark.parametrize("kind", [2, 0])
+def test_region_queries_large_batch_uses_the_slice_table(kind):
+    # >= 4096 queries switch on the table of top-level slice bounds: same rows as small batches (which bisect)
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(30000, seed=60 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2]); bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    gpu, ref = both(kind, 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(kind)
+    L = float(sysb[1][0])
+    nq = 6000
+    c = rng.uniform(0, L, size=(nq, dim)); h = rng.uniform(0.5, L / 30, size=(nq, dim))
+    boxes = np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+    for md in (None, 5):
+        big = np.array(gpu.test_box_batch(sysb, boxes, md))
+        parts = []
+        for a in range(0, nq, 3000):                                  # < 4096 per call: no table
+            r = np.array(gpu.test_box_batch(sysb, boxes[a:a + 3000], md))
+            r[:, 0] += a
+            parts.append(r)
+        assert np.array_equal(big, np.concatenate(parts))
+        splits = np.searchsorted(big[:, 0], np.arange(nq + 1))
+        for q in range(0, nq, 97):
+            assert np.array_equal(big[splits[q]:splits[q + 1], 1], ref.test_box(sysb, (boxes[q, :dim], boxes[q, dim:]), md))
+    org = rng.uniform(0, L, size=(nq, dim)).astype(np.float32)
+    d = rng.normal(size=(nq, dim)).astype(np.float32)
+    rays = np.concatenate([org, d, np.zeros((nq, 1), np.float32), np.full((nq, 1), L / 10, np.float32)], axis=1)
+    big = np.array(gpu.test_ray_batch(sysb, rays))
+    small = np.array(gpu.test_ray_batch(sysb, rays[:2000]))
+    assert np.array_equal(big[: len(small)], small)
+    # a re-sorted tree must rebuild the table
+    gpu.extend(sysb, bounds[:100] + np.float32(0.25), np.arange(len(ids), len(ids) + 100, dtype=np.uint32))
+    ref.extend(sysb, bounds[:100] + np.float32(0.25), np.arange(len(ids), len(ids) + 100, dtype=np.uint32))
+    again = np.array(gpu.test_box_batch(sysb, boxes))
+    splits = np.searchsorted(again[:, 0], np.arange(nq + 1))
+    for q in range(0, nq, 211):
+        assert np.array_equal(again[splits[q]:splits[q + 1], 1], ref.test_box(sysb, (boxes[q, :dim], boxes[q, dim:])))
