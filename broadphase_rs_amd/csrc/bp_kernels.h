@@ -141,7 +141,7 @@ hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t s
 // blockfill != nullptr: `in` is the block-structured output of the expanding scan (n = its extent, n_out records exist)
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
                            size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream,
-                           const uint32_t* blockfill = nullptr, size_t n_out = 0);
+                           const uint32_t* blockfill = nullptr, size_t n_out = 0, const unsigned long long* ready_hist = nullptr);
 // entries per cell at split_depth; slot n_cells counts the coarse entries
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                             uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream);
@@ -203,7 +203,9 @@ hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids,
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
-                              const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr);
+                              const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,
+                              const uint32_t* owner_bounds = nullptr, int owner_n = -1);
+// owner_bounds / owner_n (instead of hist_plan): count the pairs per owner rank of the first id into hist[0..255]
 // hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
 // hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)
 // Batched Layer::test_box / test_ray: (query << 32 | id) records for every entry whose cell the reference's

@@ -1230,6 +1230,10 @@ struct ExpandParams {
     u64* hist;
     int hist_passes;
     int hist_shift[SX_HIST_MAX];
+    // multi-GPU: instead, count the pairs per OWNER of the first id (owner_n >= 0: bounds[i] = first id of rank
+    // i + 1, as PairOwnerDigit) into row 0 of hist -- the bucketing pass that follows then needs no histogram read
+    int owner_n;
+    u32 owner_bounds[15];
 };
 
 // first index > j whose key is >= upper (m if none); keys[j] < upper
@@ -1324,6 +1328,13 @@ struct WaveStage {
                     __hip_atomic_fetch_add(&hist[q * 256 + ((u32)(pair >> p.hist_shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (p.owner_n >= 0) {
+                const u32 first = (u32)(pair >> 32);
+                u32 o = 0;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) o += (i < p.owner_n && first >= p.owner_bounds[i]) ? 1u : 0u;
+                __hip_atomic_fetch_add(&hist[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         const u32 before = wp / SX_BLOCK;
         wp += n;
@@ -1337,13 +1348,14 @@ struct WaveStage {
     }
 };
 
+__device__ __forceinline__ int sx_hist_rows(const ExpandParams& p) { return p.owner_n >= 0 ? 1 : p.hist_passes; }
 __device__ __forceinline__ void sx_hist_clear(u32* s_hist, const ExpandParams& p) {
-    for (int k = (int)threadIdx.x; k < p.hist_passes * 256; k += SX_THREADS) s_hist[k] = 0;
+    for (int k = (int)threadIdx.x; k < sx_hist_rows(p) * 256; k += SX_THREADS) s_hist[k] = 0;
     __syncthreads();
 }
 __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandParams& p) {
     __syncthreads();
-    for (int k = (int)threadIdx.x; k < p.hist_passes * 256; k += SX_THREADS) {
+    for (int k = (int)threadIdx.x; k < sx_hist_rows(p) * 256; k += SX_THREADS) {
         const u32 c = s_hist[k];
         if (c) atomicAdd(&p.hist[k], (u64)c);
     }
@@ -1928,7 +1940,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
 template <typename V, typename DigitFn>
 static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, size_t n, DigitFn fn, void* workspace,
                                  size_t workspace_bytes, DevScalars* sc, const u64** d_hist, hipStream_t stream,
-                                 const uint8_t* box_in = nullptr, const u32* blockfill = nullptr, size_t n_out = 0) {
+                                 const uint8_t* box_in = nullptr, const u32* blockfill = nullptr, size_t n_out = 0,
+                                 const u64* ready_hist = nullptr) {
     // blockfill: ki is block-structured (n = extent, n_out = records that exist); the output is dense
     if (n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (radix_workspace_bytes(n, 1) > workspace_bytes) return hipErrorInvalidValue;
@@ -1941,7 +1954,12 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
     if (e != hipSuccess) return e;
     *d_hist = hist;
     if (n == 0) return hipSuccess;
-    digit_hist_kernel<DigitFn><<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(ki, n, fn, hist, blockfill);
+    if (ready_hist) {  // the producer of the records counted the buckets already
+        e = hipMemcpyAsync(hist, ready_hist, RS_BINS * sizeof(u64), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    } else {
+        digit_hist_kernel<DigitFn><<<grid_for(n, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(ki, n, fn, hist, blockfill);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<1, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1972,12 +1990,13 @@ hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t s
 
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
                            size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream,
-                           const uint32_t* blockfill, size_t n_out) {
+                           const uint32_t* blockfill, size_t n_out, const unsigned long long* ready_hist) {
     PairOwnerDigit fn;
     fn.n = n_bounds;
     for (int i = 0; i < 15; ++i) fn.bounds[i] = i < n_bounds ? bounds[i] : 0xFFFFFFFFu;
     return partition_pass<NoVal, PairOwnerDigit>((const u64*)in, (u64*)out, (const NoVal*)nullptr, (NoVal*)nullptr, n, fn, workspace,
-                                                 workspace_bytes, sc, (const u64**)d_hist, stream, nullptr, blockfill, n_out);
+                                                 workspace_bytes, sc, (const u64**)d_hist, stream, nullptr, blockfill, n_out,
+                                                 (const u64*)ready_hist);
 }
 
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
@@ -2074,7 +2093,7 @@ static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipSt
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
-                              const RadixPlan* hist_plan, unsigned long long* hist) {
+                              const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n) {
     if (m == 0) return hipSuccess;
     // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
@@ -2088,6 +2107,12 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
         p.hist_passes = hist_plan->n_passes;
         for (int q = 0; q < hist_plan->n_passes; ++q) p.hist_shift[q] = hist_plan->shift[q];
+    }
+    p.owner_n = -1;
+    for (int i = 0; i < 15; ++i) p.owner_bounds[i] = 0xFFFFFFFFu;
+    if (hist && owner_bounds && owner_n >= 0 && owner_n <= 15 && p.hist_passes == 0) {
+        p.owner_n = owner_n;
+        for (int i = 0; i < owner_n; ++i) p.owner_bounds[i] = owner_bounds[i];
     }
     switch (kind) {
         case 0: return launch_scan_expand_kind<0>(p, max_grid, stream);
@@ -2304,7 +2329,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
-    p.n_waves = 0; p.filt_bounds = nullptr; p.hist = nullptr; p.hist_passes = 0;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {

@@ -84,6 +84,7 @@ struct bp_layer {
     DevBuf pair_hist;                   // digit counts of the raw stream, accumulated by the scan for pair_hist_plan
     RadixPlan pair_hist_plan{};
     bool pair_hist_valid = false;
+    bool owner_hist_valid = false;      // pair_hist row 0 holds the per-owner pair counts of the last shard scan
     size_t raw_extent = 0;
     uint64_t epoch = 1;                 // bumped whenever the sorted tree's content may have changed
     uint64_t ctx_epoch = 0;             // epoch idctx was computed for (0: never), with ...
@@ -541,6 +542,7 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
     BP_TRY(sort_tree(L));  // src/layer.rs:465, 499
     L->n_raw = 0;
     L->raw_holes = false;
+    L->owner_hist_valid = false;
     if (L->m == 0) return BP_OK;
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     const size_t nb = scan_blocks(L->m);
@@ -730,12 +732,14 @@ int make_raw_dense(bp_layer* L);
 // hist_plan: the radix plan of the pair sort that will follow (its digit histograms are then counted
 // by the scan itself and the sort skips its histogram kernel)
 int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup, const float* filt_bounds = nullptr,
-                      uint32_t filt_rows = 0, bool allow_holes = false, const RadixPlan* hist_plan = nullptr) {
+                      uint32_t filt_rows = 0, bool allow_holes = false, const RadixPlan* hist_plan = nullptr,
+                      const uint32_t* owner_bounds = nullptr, int owner_n = -1) {
     BP_TRY(sort_tree(L));
     L->n_raw = 0;
     L->raw_is_unique = false;
     L->raw_holes = false;
     L->pair_hist_valid = false;
+    L->owner_hist_valid = false;
     if (L->m == 0) return BP_OK;
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
     ScanParams p;
@@ -782,7 +786,9 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
             HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
             const bool count_digits = allow_holes && hist_plan && hist_plan->n_passes > 0 && hist_plan->n_passes <= SX_HIST_MAX;
-            if (count_digits) {
+            const bool count_owners = allow_holes && !count_digits && owner_n >= 0 && owner_n <= 15;
+            L->owner_hist_valid = false;
+            if (count_digits || count_owners) {
                 BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
                 HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
             }
@@ -793,7 +799,8 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                               (uint64_t*)L->big_list.p,
                                               (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
                                               (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
-                                              count_digits ? (unsigned long long*)L->pair_hist.p : nullptr));
+                                              (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
+                                              count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
             DevScalars sc;
@@ -817,6 +824,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 L->raw_holes = true;
                 L->raw_extent = extent_blocks * SX_BLOCK;
                 if (count_digits) { L->pair_hist_plan = *hist_plan; L->pair_hist_valid = true; }
+                if (count_owners) L->owner_hist_valid = true;
                 if (!allow_holes) BP_TRY(make_raw_dense(L));
                 return BP_OK;
             }
@@ -1551,7 +1559,7 @@ int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uin
 namespace {
 // n records at d_packed (block-structured when holes: extent slots, L->blockfill) -> grouped by owner rank
 int partition_pairs_impl(bp_layer* L, const uint64_t* d_packed, size_t n, bool holes, const uint32_t* bounds, uint32_t n_bounds,
-                         uint64_t* counts, const uint64_t** d_out) {
+                         uint64_t* counts, const uint64_t** d_out, bool owner_hist_ready = false) {
     for (uint32_t i = 0; i <= n_bounds; ++i) counts[i] = 0;
     // write into whichever pair buffer is not the input
     DevBuf& dst = (d_packed == (const uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];
@@ -1566,7 +1574,8 @@ int partition_pairs_impl(bp_layer* L, const uint64_t* d_packed, size_t n, bool h
     {
         ProfScope ps(L, BP_K_MISC);
         HIP_TRY(L, partition_pairs(d_packed, (uint64_t*)dst.p, extent, bounds, (int)n_bounds, L->radix_ws.p, L->radix_ws.cap,
-                                   (DevScalars*)L->d_sc.p, &d_hist, L->stream, holes ? (const uint32_t*)L->blockfill.p : nullptr, n));
+                                   (DevScalars*)L->d_sc.p, &d_hist, L->stream, holes ? (const uint32_t*)L->blockfill.p : nullptr, n,
+                                   owner_hist_ready ? (const unsigned long long*)L->pair_hist.p : nullptr));
     }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
@@ -1590,7 +1599,7 @@ int bp_layer_scan_shard_partition_device(bp_layer_t* L, uint32_t coarse_depth, i
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_shard_partition: bad argument");
     DeviceGuard g(L->device);
     if (L->ids_distinct) {
-        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, true, nullptr, 0, /*allow_holes=*/true));
+        BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, true, nullptr, 0, /*allow_holes=*/true, nullptr, bounds, (int)n_bounds));
     } else {
         BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse));
         BP_TRY(sync_stream(L));
@@ -1600,7 +1609,9 @@ int bp_layer_scan_shard_partition_device(bp_layer_t* L, uint32_t coarse_depth, i
     *unique = L->raw_is_unique ? 1 : 0;
     const bool holes = L->raw_holes;
     L->raw_holes = false;  // consumed here: the partition pass reads around the holes
-    return partition_pairs_impl(L, (const uint64_t*)L->pairs[0].p, L->n_raw, holes, bounds, n_bounds, counts, d_out);
+    const bool ready = L->owner_hist_valid && holes;
+    L->owner_hist_valid = false;
+    return partition_pairs_impl(L, (const uint64_t*)L->pairs[0].p, L->n_raw, holes, bounds, n_bounds, counts, d_out, ready);
 }
 
 int bp_layer_sort_unique_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask,
