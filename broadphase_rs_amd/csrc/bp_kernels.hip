@@ -1316,6 +1316,7 @@ struct WaveStage {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    template <bool OWNER = false>
     __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
         const u64 mask = __ballot(keep);
         const u32 n = (u32)__popcll(mask);
@@ -1328,7 +1329,7 @@ struct WaveStage {
                     __hip_atomic_fetch_add(&hist[q * 256 + ((u32)(pair >> p.hist_shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (p.owner_n >= 0) {
+            if (OWNER) {
                 const u32 first = (u32)(pair >> 32);
                 u32 o = 0;
 #pragma unroll
@@ -1369,7 +1370,7 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #else
 #define SX_OCC_ATTR
 #endif
-template <int KIND, bool FILT>
+template <int KIND, bool FILT, bool OWNER>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
@@ -1445,7 +1446,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 bool keep = cur.act && ctx_keep((u32)cur.wi, cur.cbdd & 63u, cur.cbdd >> 8);
                 if (FILT && keep)
                     keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)cur.idj * (2 * FDIM));
-                st.push(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
+                st.template push<OWNER>(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
                 cur = nxt;
             }
         }
@@ -1456,7 +1457,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
 }
 
 // work-list slices of the long ranges: one slice per workgroup iteration
-template <int KIND, bool FILT>
+template <int KIND, bool FILT, bool OWNER>
 __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
@@ -1491,7 +1492,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
                 if (FILT && keep)
                     keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)idj * (2 * FDIM));
             }
-            st.push(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
+            st.template push<OWNER>(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
         }
     }
     st.finish(p);
@@ -2075,20 +2076,22 @@ static unsigned resident_blocks(Kern kernel, int threads) {
     return (unsigned)(cus * per_cu);
 }
 
+template <int KIND, bool FILT, bool OWNER>
+static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
+    static const unsigned resident = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER>, SX_THREADS);
+    const unsigned grid = (unsigned)std::min<size_t>(max_grid, resident);
+    p.n_waves = grid * SX_WAVES;
+    scan_expand_kernel<KIND, FILT, OWNER><<<grid, SX_THREADS, 0, stream>>>(p);
+    scan_expand_big_kernel<KIND, FILT, OWNER><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
+    return hipGetLastError();
+}
 template <int KIND>
 static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream) {
-    static const unsigned res_plain = resident_blocks(scan_expand_kernel<KIND, false>, SX_THREADS);
-    static const unsigned res_filt = resident_blocks(scan_expand_kernel<KIND, true>, SX_THREADS);
-    const unsigned grid = (unsigned)std::min<size_t>(max_grid, p.filt_bounds ? res_filt : res_plain);
-    p.n_waves = grid * SX_WAVES;
-    if (p.filt_bounds) {
-        scan_expand_kernel<KIND, true><<<grid, SX_THREADS, 0, stream>>>(p);
-        scan_expand_big_kernel<KIND, true><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
-    } else {
-        scan_expand_kernel<KIND, false><<<grid, SX_THREADS, 0, stream>>>(p);
-        scan_expand_big_kernel<KIND, false><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
-    }
-    return hipGetLastError();
+    const bool owner = p.owner_n >= 0;  // the owner-counting variant is a separate instantiation: the default kernel pays nothing
+    if (p.filt_bounds) return owner ? launch_scan_expand_variant<KIND, true, true>(p, max_grid, stream)
+                                    : launch_scan_expand_variant<KIND, true, false>(p, max_grid, stream);
+    return owner ? launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream)
+                 : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
 }
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
