@@ -170,8 +170,9 @@ class TorchComm:
         dist.all_gather(parts, mine, group=self.group)
         return np.stack([p.cpu().numpy() for p in parts])
 
-    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None):
-        """variable-size all-to-all of a tensor that is already grouped by destination"""
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None, sync=True):
+        """variable-size all-to-all of a tensor that is already grouped by destination.  sync=False leaves the
+        exchange in flight (the caller's next exchange or backend.sync() fences it): back-to-back exchanges overlap"""
         torch, dist = self.torch, self.dist
         send_counts = [int(c) for c in send_counts]
         if recv_counts is None:
@@ -206,7 +207,8 @@ class TorchComm:
                     a = int(roff[d]) + min(recv_counts[d], r * ch)
                     recv[a:a + osz[d]] = stage_out[o:o + osz[d]]
                     o += osz[d]
-        backend.sync()
+        if sync:
+            backend.sync()
         return recv
 
     def all_gather_v(self, t, dtype, backend, sizes=None):
@@ -306,7 +308,7 @@ class ShardedLayer:
         n_recv, n_coarse = int(recv_counts.sum()), int(coarse_sizes.sum())
         sk, si = be.shard_begin(n_recv + n_coarse)
         comm._global_max_hint = int(cm[:, :G].max())
-        comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be, recv_counts, out=sk)
+        comm.all_to_all_v(keys[:n_fine], counts[:G], torch.int64, be, recv_counts, out=sk, sync=False)   # keys and ids in flight together
         comm.all_to_all_v(ids[:n_fine], counts[:G], torch.int32, be, recv_counts, out=si)
         comm._global_max_hint = None
         if n_coarse:

@@ -44,7 +44,7 @@ class ThreadComm:
     def all_gather_counts(self, counts, backend):
         return np.stack(self._exchange(np.asarray([int(c) for c in counts], dtype=np.int64)))
 
-    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None):
+    def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None, sync=True):
         import torch
         offs = np.concatenate([[0], np.cumsum([int(c) for c in send_counts])])
         vals = self._exchange([send[int(offs[d]):int(offs[d + 1])].clone() for d in range(self.world)])
