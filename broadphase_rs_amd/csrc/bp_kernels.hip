@@ -548,7 +548,7 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 //   5 tile-local scatter of the keys into LDS (needs no global information)
 //   6 look-back for the global digit bases (predecessors have had phase 5 to publish), PREFIX publish
 //   7 coalesced global stores (+ payload round trip through LDS)
-template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool BALLOT_MATCH = false>
+template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
 __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
@@ -618,31 +618,17 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
         const u32 dg = digit(key[r]);
         u64 peers = 0;
         u32 old = 0;
-        if constexpr (BALLOT_MATCH) {
-            // match on the 8 digit bits with wave64 ballots: no LDS traffic, ~50 VALU per round
-            peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (dg >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            if (valid) old = s_cnt[w][dg];
-            else peers = 0;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                peers = s_mask[dg];
-                old = s_cnt[w][dg];
-            }
-            __builtin_amdgcn_wave_barrier();
+        if (valid) __hip_atomic_fetch_or(&s_mask[dg], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            peers = s_mask[dg];
+            old = s_cnt[w][dg];
         }
+        __builtin_amdgcn_wave_barrier();
         const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(peers >> 32), __builtin_amdgcn_mbcnt_lo((u32)peers, 0u));
         if (valid && below == 0) {  // lowest peer lane: bump the (wave, digit) counter, clear the mask
             s_cnt[w][dg] = old + (u32)__popcll(peers);
-            if constexpr (!BALLOT_MATCH) s_mask[dg] = 0ull;
+            s_mask[dg] = 0ull;
         }
         __builtin_amdgcn_wave_barrier();
         packed[r] = dg | ((old + below) << 8);
