@@ -971,7 +971,10 @@ int bp_layer_destroy(bp_layer_t* L) {
     for (int i = 0; i < 2; ++i) { free_dev(L->keys[i]); free_dev(L->ids[i]); free_dev(L->pairs[i]); free_dev(L->box[i]); }
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
+    free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
+    free_dev(L->pair_hist); free_dev(L->qtab);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
+    free_host(L->h_shards);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
     return BP_OK;

@@ -541,3 +541,27 @@ def test_region_queries_large_batch_uses_the_slice_table(kind):
     splits = np.searchsorted(again[:, 0], np.arange(nq + 1))
     for q in range(0, nq, 211):
         assert np.array_equal(again[splits[q]:splits[q + 1], 1], ref.test_box(sysb, (boxes[q, :dim], boxes[q, dim:])))
+
+
+def test_destroy_releases_every_device_buffer():
+    import gc
+    import torch
+    sysb, bounds, ids = scenes.gen_boxes(200000, seed=1)
+    boxes = np.concatenate([bounds[:5000, :3] - 1, bounds[:5000, 3:] + 1], axis=1).astype(np.float32)
+
+    def once():
+        lay = bp.Layer(bp.Index64_3D, 0)
+        lay.extend(sysb, bounds, ids)
+        n = len(lay.par_scan())
+        lay.test_box_batch(sysb, boxes)
+        del lay
+        gc.collect()
+        return n
+    once()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        once()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (32 << 20), "destroy leaks %d MB per layer" % ((free0 - free1) >> 20 // 12)
