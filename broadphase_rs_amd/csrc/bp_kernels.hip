@@ -1835,7 +1835,13 @@ RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // tile geometry: 512 threads x 16 records (8192-record tiles, 2 workgroups per CU)
-constexpr int RS_THREADS_DEF = 512, RS_ITEMS_DEF = 16;
+#ifndef RS_THREADS_MACRO
+#define RS_THREADS_MACRO 512
+#endif
+#ifndef RS_ITEMS_MACRO
+#define RS_ITEMS_MACRO 16
+#endif
+constexpr int RS_THREADS_DEF = RS_THREADS_MACRO, RS_ITEMS_DEF = RS_ITEMS_MACRO;
 static size_t rs_tile_size() { return (size_t)RS_THREADS_DEF * RS_ITEMS_DEF; }
 static size_t rs_num_tiles(size_t n) { return (n + rs_tile_size() - 1) / rs_tile_size(); }
 
