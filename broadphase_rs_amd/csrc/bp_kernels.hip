@@ -1600,6 +1600,7 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* 
         }
         u32 rank = 0;
         const u32* s_lo = reinterpret_cast<const u32*>(s_win);  // low dword = second id (first ids are equal)
+#pragma unroll 4  // segments hold ~9 pairs: the compiler's 16-wide unrolling mostly runs its remainder loops
         for (u32 y = start; y < end; ++y) rank += s_lo[2 * y] < vb ? 1u : 0u;  // independent LDS reads
         out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
     }
