@@ -137,6 +137,8 @@ hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const 
                              const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in = nullptr);
 // ids[i] = packed & BOX_ID_MASK, box[i] = packed >> BOX_ID_BITS (in place on ids)
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream);
+// the inverse: ids[i] |= box_to_packed(box[i]) << BOX_ID_BITS (in place)
+hipError_t launch_pack_box(uint32_t* ids, const uint8_t* box, size_t m, hipStream_t stream);
 // packed pairs -> owner rank of the first id; bounds[i] = first id owned by rank i+1
 // blockfill != nullptr: `in` is the block-structured output of the expanding scan (n = its extent, n_out records exist)
 hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const uint32_t* bounds, int n_bounds, void* workspace,
@@ -220,6 +222,10 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
                                const uint32_t* qtab = nullptr, uint32_t qtab_levels = 0);
 uint32_t query_table_entries(int kind, uint32_t levels);
 hipError_t launch_query_table(int kind, const uint64_t* keys, size_t m, uint32_t levels, uint32_t* qtab, hipStream_t stream);
+// merge of two (key, id)-sorted runs A, B (box bytes ride along when bo != nullptr) into ko / io / bo
+hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8_t* ba, size_t na, const uint64_t* kb,
+                             const uint32_t* ib, const uint8_t* bb, size_t nb, uint64_t* ko, uint32_t* io, uint8_t* bo,
+                             hipStream_t stream);
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

@@ -1905,6 +1905,11 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     u64* kb[2] = {(u64*)keys0, (u64*)keys1};
     u32* vb[2] = {vals0, vals1};
     int cur = 0;
+    int first_key_pass = -1;
+    for (int p = 0; p < np && first_key_pass < 0; ++p)
+        if (!plan.from_val[p]) first_key_pass = p;
+    if (box_in && first_key_pass != 0) return hipErrorInvalidValue;                   // must be gathered before any permutation
+    if (box_out && (first_key_pass < 0 || plan.from_val[np - 1])) return hipErrorInvalidValue;  // no key pass to split them off
     for (int p = 0; p < np; ++p) {
         if (mark) mark(mark_ctx, class_sort);  // one timed region per pass = per kernel launch
         const u64* bb = bin_base + (size_t)p * RS_BINS;
@@ -1918,6 +1923,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         } else if (plan.from_val[p]) {
             e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else {
+            // box_in (bytes in the records' CURRENT order) can only be gathered by the very first pass; the codes are
+            // split off again by the last pass, which must be a key pass
             e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
                                           p == 0 ? box_in : nullptr, p == np - 1 ? box_out : nullptr);
         }
@@ -1975,6 +1982,15 @@ __global__ __launch_bounds__(256) void split_box_kernel(u32* __restrict__ ids, u
         box[i] = (uint8_t)box_from_packed(v >> BOX_ID_BITS);
         ids[i] = v & BOX_ID_MASK;
     }
+}
+__global__ __launch_bounds__(256) void pack_box_kernel(u32* __restrict__ ids, const uint8_t* __restrict__ box, size_t m) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256)
+        ids[i] = (ids[i] & BOX_ID_MASK) | (box_to_packed(box[i]) << BOX_ID_BITS);
+}
+hipError_t launch_pack_box(uint32_t* ids, const uint8_t* box, size_t m, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    pack_box_kernel<<<grid_for(m, 256, 4096), 256, 0, stream>>>(ids, box, m);
+    return hipGetLastError();
 }
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream) {
     if (m == 0) return hipSuccess;
@@ -2293,6 +2309,66 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
     st.finish(p);
 }
 
+// =================================================================================================
+// Sorted merge of two (key, id)-sorted runs (static-layer reuse): the crate's per-frame
+// pattern merges a pre-sorted static layer into the frame's dynamic layer (src/layer.rs:123-138) and sorts
+// again; with the static entries kept as one sorted run only the dynamic run needs a radix sort, then one
+// merge pass.  Merge path: every workgroup finds where its MG_TILE output slots start in A and B (bisection on
+// its diagonal), loads the two pieces into LDS and places each element at own index + rank in the other
+// piece (A before B on ties: exact duplicates are identical records).
+// =================================================================================================
+constexpr int MG_THREADS = 256;
+constexpr int MG_TILE = 2048;
+__device__ __forceinline__ bool rec_less(u64 ka, u32 ia, u64 kb, u32 ib) { return ka < kb || (ka == kb && ia < ib); }
+__global__ __launch_bounds__(MG_THREADS) void merge_runs_kernel(const u64* __restrict__ ka, const u32* __restrict__ ia,
+                                                               const uint8_t* __restrict__ ba, u32 na,
+                                                               const u64* __restrict__ kb, const u32* __restrict__ ib,
+                                                               const uint8_t* __restrict__ bb, u32 nb, u64* __restrict__ ko,
+                                                               u32* __restrict__ io, uint8_t* __restrict__ bo) {
+    __shared__ u64 s_k[MG_TILE];
+    __shared__ u32 s_i[MG_TILE];
+    __shared__ u32 s_split[2];
+    const u32 total = na + nb;
+    const u32 d0 = blockIdx.x * MG_TILE, d1 = min(d0 + (u32)MG_TILE, total);
+    if (threadIdx.x < 2) {  // merge-path split of diagonal d: a = #elements of A among the first d outputs
+        const u32 d = threadIdx.x == 0 ? d0 : d1;
+        u32 lo = d > nb ? d - nb : 0u, hi = min(d, na);
+        while (lo < hi) {
+            const u32 a = lo + ((hi - lo) >> 1), b = d - a;  // A[a] vs B[b - 1]: is A[a] among the first d?
+            // A[a] precedes B[b - 1] (ties: A first) -> the split lies further right
+            if (b > 0 && !rec_less(kb[b - 1], ib[b - 1], ka[a], ia[a])) lo = a + 1; else hi = a;
+        }
+        s_split[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const u32 a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
+    const u32 la = a1 - a0, lb = b1 - b0;  // la + lb = d1 - d0 <= MG_TILE
+    for (u32 k = threadIdx.x; k < la + lb; k += MG_THREADS) {
+        const bool from_a = k < la;
+        s_k[k] = from_a ? ka[a0 + k] : kb[b0 + (k - la)];
+        s_i[k] = from_a ? ia[a0 + k] : ib[b0 + (k - la)];
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < la + lb; k += MG_THREADS) {
+        const bool from_a = k < la;
+        const u64 key = s_k[k];
+        const u32 id = s_i[k];
+        u32 lo, hi;
+        if (from_a) { lo = la; hi = la + lb; } else { lo = 0; hi = la; }
+        // rank in the other piece: A counts B elements strictly less; B counts A elements less-or-equal
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            const bool go_right = from_a ? rec_less(s_k[mid], s_i[mid], key, id) : !rec_less(key, id, s_k[mid], s_i[mid]);
+            if (go_right) lo = mid + 1; else hi = mid;
+        }
+        const u32 pos = from_a ? k + (lo - la) : (k - la) + lo;
+        const size_t o = (size_t)d0 + pos;
+        ko[o] = key;
+        io[o] = id;
+        if (bo) bo[o] = from_a ? ba[a0 + k] : bb[b0 + (k - la)];
+    }
+}
+
 __global__ __launch_bounds__(256) void blockfill_to_u64_kernel(const u32* __restrict__ f, size_t nb, u64* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nb) out[i] = f[i];
@@ -2333,6 +2409,16 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     } else {
         BP_DISPATCH_KIND(kind, (region_query_kernel<K, false><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth, qtab, qtab_levels)));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8_t* ba, size_t na, const uint64_t* kb,
+                             const uint32_t* ib, const uint8_t* bb, size_t nb, uint64_t* ko, uint32_t* io, uint8_t* bo,
+                             hipStream_t stream) {
+    if (na + nb == 0) return hipSuccess;
+    if (na + nb >= 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const unsigned g = (unsigned)((na + nb + MG_TILE - 1) / MG_TILE);
+    merge_runs_kernel<<<g, MG_THREADS, 0, stream>>>((const u64*)ka, ia, ba, (u32)na, (const u64*)kb, ib, bb, (u32)nb, (u64*)ko, io, bo);
     return hipGetLastError();
 }
 

@@ -49,6 +49,10 @@ struct bp_layer {
     int cur = 0;
     size_t m = 0;
     bool sorted = true;
+    // static-layer reuse: entries [run_split, m) were merged in from a SORTED layer and nothing was appended
+    // since, so the next sort only has to sort [0, run_split) and merge the two runs
+    bool tail_run = false;
+    size_t run_split = 0;
 
     // facts about the tree that steer kernel selection (never change results)
     bool have_ids = false;      // anything appended since the last clear
@@ -380,6 +384,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
                                       count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0));
     }
     if (pack) { L->ids_packed = true; L->box_valid = false; }  // until the sort (or ensure_unpacked) splits them off
+    L->tail_run = false;
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
     BP_TRY(sync_stream(L));
     L->m += add;
@@ -422,11 +427,24 @@ bool box_can_ride(const bp_layer* L) {  // the box codes travel in the id payloa
 int sort_tree_full(bp_layer* L, bool payload_already_packed) {
     const RadixPlan plan = make_radix_plan(L->key_or ^ L->key_and, L->order_ok ? 0 : 1, L->id_or ^ L->id_and);
     L->stats.tree_sort_passes += (uint32_t)plan.n_passes;
+    // the box codes ride in the id payload of the KEY passes; without one (all index values equal) they cannot
+    const bool has_key_pass = (L->key_or ^ L->key_and) != 0;
+    if (payload_already_packed && (plan.n_passes == 0 || !has_key_pass)) {
+        L->ids_packed = true;
+        BP_TRY(ensure_unpacked(L));  // split the codes off first
+        payload_already_packed = false;
+    }
     if (plan.n_passes == 0) return BP_OK;
     const int other = L->cur ^ 1;
     BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
     BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
-    const bool ride = payload_already_packed || box_can_ride(L);
+    const bool ride = has_key_pass && (payload_already_packed ||
+                                       (L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0));
+    if (ride && !payload_already_packed && plan.from_val[0]) {
+        // id passes come first and permute the records: the codes must be inside the ids before that
+        HIP_TRY(L, launch_pack_box(cur_ids(L), (const uint8_t*)L->box[L->cur].p, L->m, L->stream));
+        payload_already_packed = true;
+    }
     const int dest = (plan.n_passes & 1) ? other : L->cur;
     if (ride) BP_TRY(ensure_dev(L, L->box[dest], L->m, dest == L->cur ? L->m : 0));
     BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, plan.n_passes)));
@@ -469,9 +487,63 @@ bool same_plan(const RadixPlan& a, const RadixPlan& b) {
     return true;
 }
 
+int sort_tree(bp_layer* L);
+// tree = [head | sorted tail run]: sort the head alone, then one merge pass.  Returns 1 when it did the job.
+int sort_tree_by_merge(bp_layer* L, int* handled) {
+    static const bool disabled = getenv("BP_NO_MERGE_SORT") != nullptr;  // A/B switch
+    *handled = 0;
+    const size_t m = L->m, n_head = L->run_split, n_tail = m - n_head;
+    L->tail_run = false;
+    if (disabled || n_head > n_tail || m >= 0xFFFFFFFFull) return BP_OK;  // a large head: one full sort is cheaper
+    BP_TRY(ensure_unpacked(L));
+    const int tail_buf = L->cur;
+    if (n_head > 0) {
+        // sort the head in place of the whole tree (the tail stays where it is, beyond the first n_head slots);
+        // the tree-wide facts are a superset of the head's, so every kernel choice stays valid
+        L->m = n_head;
+        const int rc = sort_tree(L);
+        L->m = m;
+        if (rc != BP_OK) return rc;
+        L->sorted = false;
+        if (L->cur != tail_buf) {  // the sorted head ended in the other buffer: bring it next to the tail
+            HIP_TRY(L, hipMemcpyAsync(L->keys[tail_buf].p, L->keys[L->cur].p, n_head * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(L, hipMemcpyAsync(L->ids[tail_buf].p, L->ids[L->cur].p, n_head * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+            if (L->box_valid)
+                HIP_TRY(L, hipMemcpyAsync(L->box[tail_buf].p, L->box[L->cur].p, n_head, hipMemcpyDeviceToDevice, L->stream));
+            L->cur = tail_buf;
+        }
+    }
+    const int src = L->cur, dst = src ^ 1;
+    BP_TRY(ensure_dev(L, L->keys[dst], m * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->ids[dst], m * sizeof(uint32_t)));
+    if (L->box_valid) BP_TRY(ensure_dev(L, L->box[dst], m));
+    {
+        ProfScope ps(L, BP_K_TREE_SORT);
+        HIP_TRY(L, launch_merge_runs((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p,
+                                     L->box_valid ? (const uint8_t*)L->box[src].p : nullptr, n_head,
+                                     (const uint64_t*)L->keys[src].p + n_head, (const uint32_t*)L->ids[src].p + n_head,
+                                     L->box_valid ? (const uint8_t*)L->box[src].p + n_head : nullptr, n_tail,
+                                     (uint64_t*)L->keys[dst].p, (uint32_t*)L->ids[dst].p,
+                                     L->box_valid ? (uint8_t*)L->box[dst].p : nullptr, L->stream));
+    }
+    BP_TRY(sync_stream(L));
+    L->cur = dst;
+    L->sorted = true;
+    L->order_ok = true;
+    ++L->stats.tree_sort_passes;
+    *handled = 1;
+    return BP_OK;
+}
+
 int sort_tree(bp_layer* L) {
     if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
     ++L->epoch;
+    if (L->tail_run && L->m > 1) {
+        int handled = 0;
+        BP_TRY(sort_tree_by_merge(L, &handled));
+        if (handled) return BP_OK;
+    }
+    L->tail_run = false;
     L->stats.tree_sort_passes = 0;
     if (L->m > 1) {
         const unsigned long long varying = L->key_or ^ L->key_and;
@@ -983,6 +1055,7 @@ int bp_layer_destroy(bp_layer_t* L) {
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     L->tree_hist_valid = false;
+    L->tail_run = false;
     L->m = 0;
     L->sorted = true;  // src/layer.rs:84-88
     reset_tree_facts(L);
@@ -1038,6 +1111,7 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     L->box_all_known = false;
     BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
     L->tree_hist_valid = false;
+    L->tail_run = false;
     L->m += m;
     L->sorted = false;
     L->stats.entries = L->m;
@@ -1091,7 +1165,11 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
             L->have_ids = L->have_ids || other->have_ids;
         }
         L->tree_hist_valid = false;
-    L->m += m;
+        // the appended entries form one sorted run if `other` was sorted (and no earlier run is pending)
+        const bool had_run = L->tail_run;
+        L->tail_run = !had_run && other->sorted;
+        L->run_split = L->m;
+        L->m += m;
     }
     L->sorted = false;  // unconditional: src/layer.rs:137
     L->stats.entries = L->m;
@@ -1430,6 +1508,7 @@ int bp_layer_commit_entries(bp_layer_t* L, size_t m, const bp_facts* f) {
     if (m * sizeof(uint64_t) > L->keys[L->cur].cap) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: more entries than begun");
     if (m == 0) return BP_OK;
     L->tree_hist_valid = false;
+    L->tail_run = false;
     L->m = m;
     L->sorted = false;
     L->stats.entries = m;

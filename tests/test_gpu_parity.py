@@ -565,3 +565,45 @@ def test_destroy_releases_every_device_buffer():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (32 << 20), "destroy leaks %d MB per layer" % ((free0 - free1) >> 20 // 12)
+
+
+@pytest.mark.parametrize("kind,n_static,n_dyn", [(2, 60000, 3000), (2, 5000, 1), (0, 20000, 2500), (2, 3000, 9000)])
+def test_static_layer_merge_sorts_by_merging_runs(kind, n_static, n_dyn):
+    # the crate's per-frame pattern (src/layer.rs:123-138): dynamic.clear(); dynamic.extend(..); dynamic.merge(&static)
+    # -- the static entries arrive as one sorted run, so the sort is "sort the dynamic run + one merge pass"
+    # (n_dyn > n_static: the plain sort is chosen instead).  Tree and pairs must not change.
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, _ = scenes.gen_boxes(n_static + n_dyn, seed=70 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2]); bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    sb, db = bounds[:n_static], bounds[n_static:]
+    sid = np.arange(n_static, dtype=np.uint32)
+    did = np.arange(n_static, n_static + n_dyn, dtype=np.uint32)
+    st_g, st_r = both(kind, 0)
+    st_g.extend(sysb, sb, sid); st_r.extend(sysb, sb, sid)
+    st_g.par_sort(); st_r.sort()
+    dyn_g, dyn_r = both(kind, 0)
+    for frame in range(2):
+        dyn_g.clear(); dyn_r.clear()
+        shift = np.float32(0.01 * frame)
+        dyn_g.extend(sysb, db + shift, did); dyn_r.extend(sysb, db + shift, did)
+        dyn_g.merge(st_g); dyn_r.merge(st_r)
+        assert not dyn_g.sorted
+        assert_tree_equal(dyn_g, dyn_r, "merged, unsorted (append order is part of the contract)")
+        dyn_g.par_sort(); dyn_r.sort()
+        assert_tree_equal(dyn_g, dyn_r, "merged, sorted")
+        assert_pairs_equal(dyn_g.par_scan(), dyn_r.scan(), "scan of the merged layer, frame %d" % frame)
+    if n_dyn <= n_static:
+        st = dyn_g.stats()
+        assert st["raw_pairs"] == st["pairs"]                        # box codes survived the merge: still unique at the source
+    # merging into an EMPTY layer: the whole tree is one sorted run (nothing to sort)
+    e_g, e_r = both(kind, 0)
+    e_g.merge(st_g); e_r.merge(st_r)
+    assert not e_g.sorted
+    e_g.sort(); e_r.sort()
+    assert_tree_equal(e_g, e_r, "empty.merge(static).sort()")
+    # a second merge cancels the run bookkeeping (two runs in the tail): plain sort, same result
+    e_g.merge(st_g); e_r.merge(st_r)
+    e_g.merge(dyn_g); e_r.merge(dyn_r)
+    e_g.sort(); e_r.sort()
+    assert_tree_equal(e_g, e_r, "two merges then sort")
