@@ -33,7 +33,11 @@ def _scan(gpu, ref, what, rng):
     assert gpu.sorted and ref.sorted
 
 
-@pytest.mark.parametrize("seed", range(48))
+import os
+N_SEEDS = int(os.environ.get("BP_FUZZ_SEEDS", "48"))   # BP_FUZZ_SEEDS=400 for a long soak
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_operation_sequences(seed):
     rng = np.random.default_rng(1000 + seed)
     min_depth = int(rng.choice([0, 0, 0, 3, 6]))
