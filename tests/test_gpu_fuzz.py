@@ -81,7 +81,7 @@ def test_random_operation_sequences(seed):
 
     for _step in range(int(rng.integers(6, 14))):
       try:
-        op = rng.integers(0, 10)
+        op = rng.integers(0, 11)
         which = int(rng.integers(0, 2))
         g, r = layers[which]
         if op <= 3:
@@ -108,6 +108,21 @@ def test_random_operation_sequences(seed):
             assert c == g
             layers[which] = (c, r)       # keep working on the clone
             log.append("clone[%d]" % which)
+        elif op == 10:       # region queries sort the layer first, like Layer::test (src/layer.rs:260)
+            dim = kind.dim
+            L = float(sysb[1][0])
+            c = rng.uniform(0, L, size=(4, dim)); h = rng.uniform(0.5, L / 8, size=(4, dim))
+            boxes = np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+            md = [None, 3, 7][int(rng.integers(0, 3))]
+            rows = np.array(g.test_box_batch(sysb, boxes, md))
+            log.append("test_box[%d]" % which)
+            for q in range(4):
+                exp = r.test_box(sysb, (boxes[q, :dim], boxes[q, dim:]), md)
+                assert np.array_equal(rows[rows[:, 0] == q, 1], exp), " | ".join(log[-6:])
+            d = rng.normal(size=dim).astype(np.float32)
+            got = g.test_ray(sysb, c[0].astype(np.float32), d, 0.0, L / 4, md)
+            assert np.array_equal(got, r.test_ray(sysb, c[0].astype(np.float32), d, 0.0, L / 4, md)), " | ".join(log[-6:])
+            assert g.sorted and r.sorted
         else:
             raw_g = np.array(g.scan_raw()).reshape(-1, 2)
             raw_r, _ = r.scan_raw()
