@@ -45,6 +45,7 @@ enum : unsigned {
     KERR_COUNT_OVERFLOW = 2u,    // an object expands to more cells than a launch can index
     KERR_SEGMENT_TOO_LONG = 4u,  // segment_finish: one first id owns more pairs than its window holds
     KERR_BIGLIST_OVERFLOW = 8u,  // expanding scan: more long-range slices than the work list holds
+    KERR_BAD_ID = 16u,           // pick_ray: an id of the tree has no row in the bounds table
 };
 
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
@@ -222,6 +223,11 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
                                const uint32_t* qtab = nullptr, uint32_t qtab_levels = 0);
 uint32_t query_table_entries(int kind, uint32_t levels);
 hipError_t launch_query_table(int kind, const uint64_t* keys, size_t m, uint32_t levels, uint32_t* qtab, hipStream_t stream);
+// Batched Layer::pick_ray with the built-in ray/AABB distance: rays = n_queries rows [origin(dim), direction(dim),
+// max_dist]; bounds = n_rows rows of 2*dim f32 indexed by id; out_id = 0xFFFFFFFF (out_dist = inf) when nothing is hit
+hipError_t launch_pick_ray(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* rays,
+                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, const float* bounds, uint32_t n_rows,
+                           float* out_dist, uint32_t* out_id, DevScalars* sc, hipStream_t stream);
 // merge of two (key, id)-sorted runs A, B (box bytes ride along when bo != nullptr) into ko / io / bo
 hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8_t* ba, size_t na, const uint64_t* kb,
                              const uint32_t* ib, const uint8_t* bb, size_t nb, uint64_t* ko, uint32_t* io, uint8_t* bo,

@@ -2310,6 +2310,158 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
 }
 
 // =================================================================================================
+// Batched nearest-hit queries: Layer::pick_ray (src/layer.rs:418-446 -> pick :364-404 -> test_impl :167-239) with
+// a built-in distance callback in place of the caller's closure: the entry distance of the ray into the AABB of
+// the object (rows of `bounds` indexed by id; slab test, 0 when the origin is inside, INFINITY on a miss).
+// One lane per ray walks the reference's recursion in RayTestGeometry::test_order (src/geom.rs:664-684) with the
+// nearest-hit pruning of should_test (:686-688); `nearest` only ever shrinks, the id is replaced on a strict
+// improvement (layer.rs:389-392), so ties keep the first candidate in the reference's visiting order.
+// =================================================================================================
+template <int DIM> __device__ __forceinline__ float ray_aabb_distance(const float* o, const float* d, const float* __restrict__ row) {
+    float tmin = 0.0f, tmax = INFINITY;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+        const float bmin = row[a], bmax = row[DIM + a];
+        if (d[a] == 0.0f) {
+            if (o[a] < bmin || o[a] > bmax) miss = true;
+        } else {
+            float t0 = (bmin - o[a]) / d[a], t1 = (bmax - o[a]) / d[a];
+            if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+        }
+    }
+    return (!miss && tmin <= tmax) ? tmin : INFINITY;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void pick_ray_kernel(const u64* __restrict__ keys, const u32* __restrict__ ids, u32 m, SysBounds sb,
+                                                       const float* __restrict__ rays, u32 n_queries, int has_max_depth,
+                                                       u32 max_depth, const float* __restrict__ bounds, u32 n_rows,
+                                                       float* __restrict__ out_dist, u32* __restrict__ out_id, DevScalars* sc) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, NSUB = 1u << DIM;
+    constexpr u32 TOP = DIM * AB + DB;
+    const u32 q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_queries) return;
+    const float* row = rays + (size_t)q * (2 * DIM + 1);
+    float org[DIM], dir[DIM];
+#pragma unroll
+    for (u32 a = 0; a < DIM; ++a) { org[a] = row[a]; dir[a] = row[DIM + a]; }
+    const float max_dist = row[2 * DIM];
+    // RayTestGeometry::test_order
+    u32 order[NSUB];
+    {
+        float ab[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (u32 a = 0; a < DIM; ++a) ab[a] = fabsf(dir[a]);
+        u32 ax0, ax1, ax2 = 2;
+        if (DIM == 2) {
+            if (ab[0] <= ab[1]) { ax0 = 0; ax1 = 1; } else { ax0 = 1; ax1 = 0; }
+        } else if (ab[0] <= ab[1] && ab[0] <= ab[2]) {
+            if (ab[1] <= ab[2]) { ax0 = 0; ax1 = 1; ax2 = 2; } else { ax0 = 0; ax1 = 2; ax2 = 1; }
+        } else if (ab[1] <= ab[2]) {
+            if (ab[0] <= ab[2]) { ax0 = 1; ax1 = 0; ax2 = 2; } else { ax0 = 1; ax1 = 2; ax2 = 0; }
+        } else {
+            if (ab[0] <= ab[1]) { ax0 = 2; ax1 = 0; ax2 = 1; } else { ax0 = 2; ax1 = 1; ax2 = 0; }
+        }
+        const u32 axes[3] = {ax0, ax1, ax2};
+#pragma unroll
+        for (u32 src = 0; src < NSUB; ++src) {
+            u32 dst = 0;
+#pragma unroll
+            for (u32 k = 0; k < DIM; ++k) {
+                const bool bit = (((src >> k) & 1u) != 0) == (dir[axes[k]] >= 0.0f);
+                dst |= (bit ? 1u : 0u) << axes[k];
+            }
+            order[src] = dst;
+        }
+    }
+    // per-level stack (dynamically indexed -> scratch)
+    u32 bnd[AB + 1][NSUB + 1];   // slice boundaries of the children (bnd[l][NSUB] = end of the node's slice)
+    u32 pos[AB + 1];             // next position in `order`; NSUB + 1 marks "node not entered yet"
+    u32 lo[AB + 1], hi[AB + 1];
+    float mn[AB + 1][DIM], mx[AB + 1][DIM], rmin[AB + 1], rmax[AB + 1];
+    u64 cell[AB + 1];
+    float r0 = 0.0f, r1 = max_dist;  // pick_ray: with_system_bounds(.., 0, max_dist) (layer.rs:434-439)
+#pragma unroll
+    for (u32 a = 0; a < DIM; ++a) {
+        mn[0][a] = sb.mn[a]; mx[0][a] = sb.mx[a];
+        const float distance_0 = (sb.mn[a] - org[a]) / dir[a], distance_1 = (sb.mx[a] - org[a]) / dir[a];
+        const bool is_forward = dir[a] > 0.0f;
+        const float d0 = is_forward ? distance_0 : distance_1, d1 = is_forward ? distance_1 : distance_0;
+        if (isfinite(d0)) r0 = fmaxf(r0, d0);
+        if (isfinite(d1)) r1 = fminf(r1, d1);
+    }
+    rmin[0] = r0; rmax[0] = r1;
+    lo[0] = 0; hi[0] = m; cell[0] = 0ull; pos[0] = NSUB + 1u;
+    int level = 0;
+    float nearest = max_dist;
+    u32 result = 0xFFFFFFFFu;
+    bool bad_id = false;
+    auto fold = [&](u32 a, u32 b) {  // callback(...).min(nearest) over a slice (layer.rs:193-196, 216-219)
+        for (u32 e = a; e < b; ++e) {
+            const u32 id = ids[e];
+            if (id >= n_rows) { bad_id = true; continue; }
+            const float dist = ray_aabb_distance<(int)DIM>(org, dir, bounds + (size_t)id * (2 * DIM));
+            if (isfinite(dist)) {
+                if (dist < nearest) result = id;
+                nearest = fminf(dist, nearest);
+            }
+        }
+    };
+    while (level >= 0) {
+        const int l = level;
+        if (pos[l] == NSUB + 1u) {  // entering the node
+            if (!(lo[l] < hi[l] && rmin[l] < rmax[l] && rmin[l] < nearest)) { --level; continue; }
+            if ((has_max_depth && (u32)l >= max_depth) || (u32)l >= AB) { fold(lo[l], hi[l]); --level; continue; }
+            const u32 shift = TOP - DIM * ((u32)l + 1u);
+            const u64 base_key = (cell[l] & ~(u64)((1u << DB) - 1u)) | (u64)((u32)l + 1u);
+            u32 a = lo[l];
+            for (u32 c = 0; c < NSUB; ++c) {  // the reference's successive binary_search_by splits
+                u32 b = hi[l];
+                const u64 key = base_key | ((u64)c << shift);
+                while (a < b) { const u32 mid = a + ((b - a) >> 1); if (keys[mid] < key) a = mid + 1; else b = mid; }
+                bnd[l][c] = a;
+            }
+            bnd[l][NSUB] = hi[l];
+            fold(lo[l], bnd[l][0]);
+            pos[l] = 0;
+            continue;
+        }
+        if (pos[l] >= NSUB) { --level; continue; }
+        const u32 c = order[pos[l]];
+        pos[l] += 1u;
+        const u32 a0 = bnd[l][c], b0 = bnd[l][c + 1u];
+        if (a0 >= b0) continue;
+        const u32 shift = TOP - DIM * ((u32)l + 1u);
+        float c0 = rmin[l], c1 = rmax[l];
+#pragma unroll
+        for (u32 a = 0; a < DIM; ++a) {
+            const float ctr = mn[l][a] + (mx[l][a] - mn[l][a]) / 2.0f;
+            const bool upper = (c >> a) & 1u;
+            const float distance = (ctr - org[a]) / dir[a];
+            if (isfinite(distance)) {
+                const bool is_towards = (dir[a] > 0.0f) != upper;
+                if (is_towards) c1 = fminf(c1, distance); else c0 = fmaxf(c0, distance);
+            } else if ((org[a] > ctr) != upper) {
+                c0 = INFINITY; c1 = -INFINITY;
+            }
+            mn[l + 1][a] = upper ? ctr : mn[l][a];
+            mx[l + 1][a] = upper ? mx[l][a] : ctr;
+        }
+        rmin[l + 1] = c0; rmax[l + 1] = c1;
+        lo[l + 1] = a0; hi[l + 1] = b0;
+        cell[l + 1] = ((cell[l] & ~(u64)((1u << DB) - 1u)) | (u64)((u32)l + 1u)) | ((u64)c << shift);
+        pos[l + 1] = NSUB + 1u;
+        level = l + 1;
+    }
+    out_dist[q] = result == 0xFFFFFFFFu ? INFINITY : nearest;
+    out_id[q] = result;
+    if (bad_id) atomicOr(&sc->err, (u32)KERR_BAD_ID);
+}
+
+// =================================================================================================
 // Sorted merge of two (key, id)-sorted runs (static-layer reuse): the crate's per-frame
 // pattern merges a pre-sorted static layer into the frame's dynamic layer (src/layer.rs:123-138) and sorts
 // again; with the static entries kept as one sorted run only the dynamic run needs a radix sort, then one
@@ -2409,6 +2561,16 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     } else {
         BP_DISPATCH_KIND(kind, (region_query_kernel<K, false><<<g, SX_THREADS, 0, stream>>>(p, ids, sb, boxes, n_queries, has_max_depth, max_depth, qtab, qtab_levels)));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pick_ray(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, SysBounds sb, const float* rays,
+                           uint32_t n_queries, int has_max_depth, uint32_t max_depth, const float* bounds, uint32_t n_rows,
+                           float* out_dist, uint32_t* out_id, DevScalars* sc, hipStream_t stream) {
+    if (n_queries == 0) return hipSuccess;
+    const unsigned g = (n_queries + 255) / 256;
+    BP_DISPATCH_KIND(kind, (pick_ray_kernel<K><<<g, 256, 0, stream>>>((const u64*)keys, ids, (u32)m, sb, rays, n_queries, has_max_depth,
+                                                                      max_depth, bounds, n_rows, out_dist, out_id, sc)));
     return hipGetLastError();
 }
 

@@ -1436,6 +1436,62 @@ int bp_layer_test_ray_batch(bp_layer_t* L, const float* sys_min, const float* sy
     return pairs_to_host(L, rows, n_rows);
 }
 
+// Batched Layer::pick_ray with the built-in ray/AABB distance (src/layer.rs:418-446)
+int bp_layer_pick_ray_aabb_batch(bp_layer_t* L, const float* sys_min, const float* sys_max, const float* rays, size_t n_queries,
+                                 int has_max_depth, uint32_t max_depth, const float* bounds_by_id, size_t n_rows, float* out_dist,
+                                 uint32_t* out_id) {
+    if (!L || !sys_min || !sys_max || (n_queries && (!rays || !out_dist || !out_id)) || !bounds_by_id)
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_pick_ray_aabb_batch: null argument");
+    if (n_queries > 0x7FFFFFFFull || n_rows > 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "bp_layer_pick_ray_aabb_batch: too many rays / rows");
+    DeviceGuard g(L->device);
+    BP_TRY(sort_tree(L));  // src/layer.rs:374
+    if (n_queries == 0) return sync_stream(L);
+    if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "pick_ray: more than 2^32-1 index entries");
+    const KindInfo ki = kind_info(L->kind);
+    SysBounds sb;
+    for (uint32_t a = 0; a < 3; ++a) {
+        sb.mn[a] = a < ki.dim ? sys_min[a] : 0.f;
+        sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
+    }
+    const float* d_rays = rays;
+    if (!is_device_ptr(rays)) {
+        const size_t bytes = n_queries * (2 * ki.dim + 1) * sizeof(float);
+        BP_TRY(ensure_dev(L, L->in_ids, bytes));
+        HIP_TRY(L, hipMemcpyAsync(L->in_ids.p, rays, bytes, hipMemcpyHostToDevice, L->stream));
+        d_rays = (const float*)L->in_ids.p;
+    }
+    const float* d_bounds = bounds_by_id;
+    if (!is_device_ptr(bounds_by_id)) {
+        const size_t bytes = n_rows * 2 * ki.dim * sizeof(float);
+        BP_TRY(ensure_dev(L, L->in_bounds, std::max<size_t>(bytes, 4)));
+        if (bytes) HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, bounds_by_id, bytes, hipMemcpyHostToDevice, L->stream));
+        d_bounds = (const float*)L->in_bounds.p;
+    }
+    const bool out_dev = is_device_ptr(out_dist);
+    if (out_dev != is_device_ptr(out_id)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_pick_ray_aabb_batch: outputs must live in the same memory space");
+    float* d_dist = out_dist;
+    uint32_t* d_id = out_id;
+    if (!out_dev) {
+        BP_TRY(ensure_dev(L, L->counts, n_queries * (sizeof(float) + sizeof(uint32_t))));
+        d_dist = (float*)L->counts.p;
+        d_id = (uint32_t*)((float*)L->counts.p + n_queries);
+    }
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_SCAN_EMIT);
+        HIP_TRY(L, launch_pick_ray(L->kind, cur_keys(L), cur_ids(L), L->m, sb, d_rays, (uint32_t)n_queries, has_max_depth, max_depth,
+                                   d_bounds, (uint32_t)n_rows, d_dist, d_id, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    if (!out_dev) {
+        HIP_TRY(L, hipMemcpyAsync(out_dist, d_dist, n_queries * sizeof(float), hipMemcpyDeviceToHost, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(out_id, d_id, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    if (sc.err & KERR_BAD_ID) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_pick_ray_aabb_batch: an id of the layer has no row in bounds_by_id");
+    return BP_OK;
+}
+
 int bp_layer_sort_unique_pairs_device(bp_layer_t* L, const uint32_t* d_pairs_in, size_t n, const uint32_t** d_pairs,
                                       size_t* n_pairs) {
     if (!L || !d_pairs || !n_pairs || (n && !d_pairs_in)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_unique_pairs: null argument");

@@ -76,6 +76,7 @@ EXPORTS = [
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
     "bp_layer_test_box_batch", "bp_layer_test_box_batch_device", "bp_layer_test_ray_batch", "bp_layer_test_ray_batch_device",
+    "bp_layer_pick_ray_aabb_batch",
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
@@ -188,6 +189,7 @@ def load_library():
     L.bp_layer_stats.argtypes = [vp, C.POINTER(_Stats)]
     L.bp_layer_profile_enable.argtypes = [vp, C.c_int]
     L.bp_layer_profile_reset.argtypes = [vp]
+    L.bp_layer_pick_ray_aabb_batch.argtypes = [vp, f32p, f32p, vp, C.c_size_t, C.c_int, C.c_uint32, vp, C.c_size_t, vp, vp]
     for fn in (L.bp_layer_test_box_batch, L.bp_layer_test_box_batch_device, L.bp_layer_test_ray_batch,
                L.bp_layer_test_ray_batch_device):
         fn.argtypes = [vp, f32p, f32p, vp, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -437,6 +439,31 @@ class Layer:
         self._check(fn(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p), C.c_void_p(ptr), n_rays,
                        0 if max_depth is None else 1, 0 if max_depth is None else int(max_depth), C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self) if device else self._host_pairs(p, n)
+
+    def pick_ray_aabb_batch(self, system_bounds, rays, bounds_by_id, max_depth=None):
+        """Layer::pick_ray (src/layer.rs:418-446) for many rays with the built-in ray/AABB distance.
+        rays: rows [origin(dim), direction(dim), max_dist] -> (dist f32[n] (+inf: no hit), id u32[n] (0xFFFFFFFF: no hit))"""
+        f32p = C.POINTER(C.c_float)
+        smin = np.ascontiguousarray(system_bounds[0], dtype=np.float32)
+        smax = np.ascontiguousarray(system_bounds[1], dtype=np.float32)
+        rptr, n_rays, _k1 = self._query_rows(rays, 2 * self.index.dim + 1)
+        bptr, n_rows, _k2 = self._bounds_arg(bounds_by_id)
+        dist = np.empty(n_rays, dtype=np.float32)
+        ids = np.empty(n_rays, dtype=np.uint32)
+        self._check(self._L.bp_layer_pick_ray_aabb_batch(
+            self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p), C.c_void_p(rptr), n_rays,
+            0 if max_depth is None else 1, 0 if max_depth is None else int(max_depth), C.c_void_p(bptr), n_rows,
+            C.c_void_p(dist.ctypes.data), C.c_void_p(ids.ctypes.data)))
+        return dist, ids
+
+    def pick_ray_aabb(self, system_bounds, origin, direction, max_dist, bounds_by_id, max_depth=None):
+        """(dist, id, point) of the nearest box hit, or None  (src/layer.rs:418-446)"""
+        o = np.asarray(origin, np.float32); d = np.asarray(direction, np.float32)
+        row = np.concatenate([o, d, np.array([max_dist], np.float32)])
+        dist, ids = self.pick_ray_aabb_batch(system_bounds, row[None, :], bounds_by_id, max_depth)
+        if ids[0] == 0xFFFFFFFF:
+            return None
+        return float(dist[0]), int(ids[0]), o + d * dist[0]
 
     def test_ray(self, system_bounds, origin, direction, range_min=-np.inf, range_max=np.inf, max_depth=None):  # src/layer.rs:327-351
         row = np.concatenate([np.asarray(origin, np.float32), np.asarray(direction, np.float32),

@@ -252,6 +252,16 @@ int bp_layer_test_ray_batch_device(bp_layer_t *layer, const float *sys_min, cons
                                    size_t n_queries, int has_max_depth, uint32_t max_depth, const uint32_t **d_rows,
                                    size_t *n_rows);
 
+/* Layer::pick_ray (src/layer.rs:418-446; pick :364-404) for n_queries rays at once, with a BUILT-IN distance
+ * callback in place of the caller's closure: the entry distance of the ray into the AABB of the object
+ * (bounds_by_id: n_rows rows of 2*dim f32 indexed by id; 0 when the origin is inside the box).  rays: rows of
+ * 2*dim + 1 f32 [origin..., direction..., max_dist].  out_id[q] = the nearest object hit within max_dist
+ * (first one in the reference's visiting order on ties) or 0xFFFFFFFF, out_dist[q] = its distance or +inf; the
+ * reference's third result is origin + direction * dist.  Inputs and outputs may be host or device memory. */
+int bp_layer_pick_ray_aabb_batch(bp_layer_t *layer, const float *sys_min, const float *sys_max, const float *rays,
+                                 size_t n_queries, int has_max_depth, uint32_t max_depth, const float *bounds_by_id,
+                                 size_t n_rows, float *out_dist, uint32_t *out_id);
+
 /* Kernel classes timed with HIP events on the layer's own stream when profiling is enabled */
 typedef enum bp_kernel_class {
     BP_K_ENCODE = 0,      /* encode_count + encode_emit                   */

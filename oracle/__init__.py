@@ -118,6 +118,9 @@ def lib():
     L.orc_layer_test_box.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_uint32, u32p, sz]
     L.orc_layer_test_ray.restype = C.c_long
     L.orc_layer_test_ray.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_uint32, u32p, sz]
+    L.orc_layer_pick_ray_aabb.restype = C.c_int
+    L.orc_layer_pick_ray_aabb.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_float, C.c_int, C.c_uint32, f32p, sz,
+                                          C.POINTER(C.c_float), u32p]
     L.orc_brute_force_overlaps.restype = sz
     L.orc_brute_force_overlaps.argtypes = [C.c_uint32, f32p, sz, u32p, sz]
     L.orc_hw_threads.restype = C.c_int
@@ -278,6 +281,20 @@ class OracleLayer:
         if n < 0:
             raise RuntimeError("orc_layer_test_ray failed (%d)" % n)
         return out[:n].copy()
+
+    def pick_ray_aabb(self, system_bounds, origin, direction, max_dist, bounds_by_id, max_depth=None):
+        """Layer::pick_ray (layer.rs:418-446) with the built-in ray/AABB distance: (dist, id) or None"""
+        sys_min, sys_max = _f32(system_bounds[0]), _f32(system_bounds[1])
+        o, d = _f32(origin), _f32(direction)
+        b = _f32(bounds_by_id).reshape(-1, 2 * self.dim)
+        dist, idv = C.c_float(), C.c_uint32()
+        rc = self._L.orc_layer_pick_ray_aabb(self._h, _ptr(sys_min, C.c_float), _ptr(sys_max, C.c_float), _ptr(o, C.c_float),
+                                             _ptr(d, C.c_float), float(max_dist), 0 if max_depth is None else 1,
+                                             0 if max_depth is None else int(max_depth), _ptr(b, C.c_float), len(b),
+                                             C.byref(dist), C.byref(idv))
+        if rc < 0:
+            raise RuntimeError("orc_layer_pick_ray_aabb failed (%d)" % rc)
+        return (dist.value, idv.value) if rc else None
 
     def __len__(self):
         return self._L.orc_layer_len(self._h)

@@ -833,6 +833,137 @@ long orc_layer_test_ray(orc_layer_t *l, const float *sys_min, const float *sys_m
     return run_region_test(l, &t, &root, out, cap);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* nearest-hit query: Layer::pick / pick_ray (layer.rs:364-446) with a BUILT-IN distance callback  */
+/* (ray vs. the AABB of the object, rows of bounds indexed by id) in place of the caller's closure  */
+
+/* RayTestGeometry::test_order (2-D geom.rs:591-607, 3-D :664-684) */
+static void ray_test_order(uint32_t dim, const float *direction, uint32_t *order) {
+    float ab[3] = {0, 0, 0};
+    for (uint32_t a = 0; a < dim; ++a) ab[a] = fabsf(direction[a]);
+    uint32_t axes[3] = {0, 1, 2};
+    if (dim == 2) {
+        if (ab[0] <= ab[1]) { axes[0] = 0; axes[1] = 1; } else { axes[0] = 1; axes[1] = 0; }
+    } else {
+        if (ab[0] <= ab[1] && ab[0] <= ab[2]) {
+            if (ab[1] <= ab[2]) { axes[0] = 0; axes[1] = 1; axes[2] = 2; } else { axes[0] = 0; axes[1] = 2; axes[2] = 1; }
+        } else if (ab[1] <= ab[2]) {
+            if (ab[0] <= ab[2]) { axes[0] = 1; axes[1] = 0; axes[2] = 2; } else { axes[0] = 1; axes[1] = 2; axes[2] = 0; }
+        } else {
+            if (ab[0] <= ab[1]) { axes[0] = 2; axes[1] = 0; axes[2] = 1; } else { axes[0] = 2; axes[1] = 1; axes[2] = 0; }
+        }
+    }
+    for (uint32_t src = 0; src < (1u << dim); ++src) {
+        uint32_t dst = 0;
+        for (uint32_t k = 0; k < dim; ++k) {
+            const uint32_t bit = (((src >> k) & 1u) != 0) == (direction[axes[k]] >= 0.0f);
+            dst |= bit << axes[k];
+        }
+        order[src] = dst;
+    }
+}
+
+/* the built-in GetDist: slab test of origin + t * direction, t >= 0, against the inclusive box; entry distance
+ * (0 when the origin is inside), INFINITY on a miss.  Written once here and once in the kernel, same f32 steps. */
+static float ray_aabb_distance(uint32_t dim, const float *o, const float *d, const float *bmin, const float *bmax) {
+    float tmin = 0.0f, tmax = INFINITY;
+    for (uint32_t a = 0; a < dim; ++a) {
+        if (d[a] == 0.0f) {
+            if (o[a] < bmin[a] || o[a] > bmax[a]) return INFINITY;
+        } else {
+            float t0 = (bmin[a] - o[a]) / d[a], t1 = (bmax[a] - o[a]) / d[a];
+            if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+        }
+    }
+    return tmin <= tmax ? tmin : INFINITY;
+}
+
+typedef struct {
+    regiontest_t t;
+    const float *bounds_by_id; size_t n_rows;
+    uint32_t order[8];
+    int have; uint32_t result;
+} picktest_t;
+
+/* the closure of Layer::pick (layer.rs:386-401) around the built-in distance; `processed` (a set that makes the
+ * user's closure run once per id) is dropped: the built-in distance is pure, a repeat cannot beat `nearest` */
+static float pick_callback(picktest_t *p, float nearest, uint32_t id) {
+    if ((size_t)id >= p->n_rows) { p->t.err = -4; return INFINITY; }
+    const float *row = p->bounds_by_id + (size_t)id * 2 * p->t.dim;
+    const float dist = ray_aabb_distance(p->t.dim, p->t.origin, p->t.direction, row, row + p->t.dim);
+    if (isfinite(dist)) {
+        if (dist < nearest) { p->result = id; p->have = 1; }
+        return dist;
+    }
+    return INFINITY;
+}
+static float pick_fold(picktest_t *p, const rec_t *tree, size_t n, float nearest) {   /* layer.rs:193-196 */
+    for (size_t i = 0; i < n; ++i) nearest = fminf(pick_callback(p, nearest, tree[i].id), nearest);
+    return nearest;
+}
+/* test_impl (layer.rs:167-239) with nearest-hit pruning: should_test(nearest) geom.rs:686-688 */
+static float pick_impl(picktest_t *p, const rec_t *tree, size_t n, uint64_t cell, const tgeom_t *g, float nearest) {
+    regiontest_t *t = &p->t;
+    if (n == 0 || !(g->range_min < g->range_max && g->range_min < nearest)) return nearest;
+    if (tree[0].key < cell || !orc_overlaps(t->kind, cell, tree[n - 1].key)) { t->err = -2; return nearest; }
+    uint32_t depth = orc_depth(t->kind, cell);
+    if (t->has_max_depth && depth >= t->max_depth) return pick_fold(p, tree, n, nearest);
+    uint64_t sub[8];
+    if (!subdivide_index(t->kind, cell, sub)) return pick_fold(p, tree, n, nearest);
+    const uint32_t nsub = 1u << t->dim;
+    size_t start[9];
+    const rec_t *rest = tree; size_t nrest = n, consumed = 0;
+    for (uint32_t c = 0; c < nsub; ++c) {
+        size_t lo = 0, hi = nrest;
+        while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (rest[mid].key < sub[c]) lo = mid + 1; else hi = mid; }
+        start[c] = consumed + lo;
+        rest += lo; nrest -= lo; consumed += lo;
+    }
+    start[nsub] = n;
+    nearest = pick_fold(p, tree, start[0], nearest);                                           /* :216-219 */
+    for (uint32_t k = 0; k < nsub; ++k) {                                                      /* :224-232, in test_order */
+        const uint32_t c = p->order[k];
+        tgeom_t child;
+        geom_child(t, g, c, &child);
+        nearest = pick_impl(p, tree + start[c], start[c + 1] - start[c], sub[c], &child, nearest);
+        if (t->err) return nearest;
+    }
+    return nearest;
+}
+
+/* Layer::pick_ray (layer.rs:418-446) with the built-in ray/AABB distance.  Returns 1 and (*dist, *id) when
+ * something was hit within max_dist, 0 when nothing was, < 0 on error. */
+int orc_layer_pick_ray_aabb(orc_layer_t *l, const float *sys_min, const float *sys_max, const float *origin,
+                            const float *direction, float max_dist, int has_max_depth, uint32_t max_depth,
+                            const float *bounds_by_id, size_t n_rows, float *dist, uint32_t *id) {
+    orc_kind_t k; orc_kind(l->kind, &k);
+    picktest_t p; memset(&p, 0, sizeof p);
+    p.t.kind = l->kind; p.t.dim = k.dim; p.t.is_ray = 1; p.t.origin = origin; p.t.direction = direction;
+    p.t.has_max_depth = has_max_depth; p.t.max_depth = max_depth;
+    p.bounds_by_id = bounds_by_id; p.n_rows = n_rows;
+    ray_test_order(k.dim, direction, p.order);
+    tgeom_t root; memset(&root, 0, sizeof root);
+    float range_min = 0.0f, range_max = max_dist;                                              /* :434-439 */
+    for (uint32_t a = 0; a < k.dim; ++a) {
+        root.cell_bounds.mn[a] = sys_min[a]; root.cell_bounds.mx[a] = sys_max[a];
+        const float distance_0 = (sys_min[a] - origin[a]) / direction[a];
+        const float distance_1 = (sys_max[a] - origin[a]) / direction[a];
+        const int is_forward = direction[a] > 0.0f;
+        const float d0 = is_forward ? distance_0 : distance_1, d1 = is_forward ? distance_1 : distance_0;
+        if (isfinite(d0)) range_min = fmaxf(range_min, d0);
+        if (isfinite(d1)) range_max = fminf(range_max, d1);
+    }
+    root.range_min = range_min; root.range_max = range_max;
+    orc_layer_sort(l);                                                                          /* :374 */
+    const float d = pick_impl(&p, l->tree.p, l->tree.n, 0, &root, max_dist);
+    if (p.t.err) return p.t.err;
+    if (!p.have) return 0;
+    *dist = d; *id = p.result;
+    return 1;
+}
+
 /* geom.rs:112-119 (Bounds::overlaps, inclusive) over all i<j */
 size_t orc_brute_force_overlaps(uint32_t dim, const float *b, size_t n, uint32_t *pairs, size_t cap) {
     size_t cnt = 0;

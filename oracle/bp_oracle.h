@@ -109,6 +109,12 @@ long orc_layer_test_ray(orc_layer_t *, const float *sys_min, const float *sys_ma
                         const float *direction, float range_min, float range_max, int has_max_depth, uint32_t max_depth,
                         uint32_t *out, size_t cap);
 
+/* Layer::pick_ray (layer.rs:418-446; pick :364-404) with a built-in distance callback: entry distance of the ray
+ * into the AABB bounds_by_id[id] (rows of 2*dim f32).  1 = hit (*dist, *id), 0 = none, < 0 = error */
+int orc_layer_pick_ray_aabb(orc_layer_t *, const float *sys_min, const float *sys_max, const float *origin,
+                            const float *direction, float max_dist, int has_max_depth, uint32_t max_depth,
+                            const float *bounds_by_id, size_t n_rows, float *dist, uint32_t *id);
+
 size_t orc_brute_force_overlaps(uint32_t dim, const float *bounds, size_t n, uint32_t *pairs, size_t cap);
 
 /* number of hardware threads the par_* baseline can use */

@@ -607,3 +607,43 @@ def test_static_layer_merge_sorts_by_merging_runs(kind, n_static, n_dyn):
     e_g.merge(dyn_g); e_r.merge(dyn_r)
     e_g.sort(); e_r.sort()
     assert_tree_equal(e_g, e_r, "two merges then sort")
+
+
+@pytest.mark.parametrize("kind,min_depth", [(2, 0), (1, 0), (0, 3)])
+def test_pick_ray_batch_matches_reference_traversal(kind, min_depth):
+    # Layer::pick_ray (src/layer.rs:418-446) with the built-in ray/AABB distance: same visiting order
+    # (RayTestGeometry::test_order), same pruning, same winner on ties as the oracle's restatement of test_impl
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(8000, seed=80 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2]); bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    bounds[100:140] = bounds[100]                                   # 40 identical boxes: exact distance ties
+    gpu, ref = both(kind, min_depth)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(200 + kind)
+    L = float(sysb[1][0])
+    nq = 400
+    org = rng.uniform(-0.1 * L, 1.1 * L, size=(nq, dim)).astype(np.float32)
+    dirs = rng.normal(size=(nq, dim)).astype(np.float32)
+    dirs[::9, 0] = 0.0
+    tgt = bounds[100, :dim] + (bounds[100, dim:] - bounds[100, :dim]) * np.float32(0.5)
+    dirs[1::10] = (tgt - org[1::10])                                # aimed at the stack of identical boxes
+    org[3::13] = bounds[3::13][: len(org[3::13]), :dim] + np.float32(0.01)   # origins inside a box: distance 0
+    maxd = np.where(np.arange(nq) % 4 == 0, L / 50, 4 * L).astype(np.float32)
+    rays = np.concatenate([org, dirs, maxd[:, None]], axis=1).astype(np.float32)
+    for max_depth in (None, 6):
+        dist, hit = gpu.pick_ray_aabb_batch(sysb, rays, bounds, max_depth)
+        n_hit = 0
+        for q in range(nq):
+            exp = ref.pick_ray_aabb(sysb, org[q], dirs[q], maxd[q], bounds, max_depth)
+            if exp is None:
+                assert hit[q] == 0xFFFFFFFF and np.isinf(dist[q]), "ray %d: GPU hit %d, reference nothing" % (q, hit[q])
+            else:
+                n_hit += 1
+                assert hit[q] == exp[1] and np.float32(exp[0]) == dist[q], "ray %d: (%r, %d) vs %r" % (q, dist[q], hit[q], exp)
+        assert nq // 4 < n_hit
+    one = gpu.pick_ray_aabb(sysb, org[1], dirs[1], 4 * L, bounds)
+    exp = ref.pick_ray_aabb(sysb, org[1], dirs[1], 4 * L, bounds)
+    assert one is not None and one[1] == exp[1] and np.allclose(one[2], org[1] + dirs[1] * np.float32(exp[0]))
+    with pytest.raises(bp.BroadphaseError):                          # an id without a row in the table
+        gpu.pick_ray_aabb_batch(sysb, rays[:4], bounds[:10])

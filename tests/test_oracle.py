@@ -244,3 +244,43 @@ def test_region_queries_recursive_c_vs_closed_form_python(kind):
         assert w.test_box(sb, ([1.0] * 3, [2.0] * 3)).tolist() == [0, 1, 2]
         assert w.test_box(sb, ([10.0] * 3, [12.0] * 3), 2).tolist() == [2, 3]
         assert w.test_ray(sb, [0.5, 8.0, 8.0], [1.0, 0.0, 0.0]).tolist() == [2, 3]
+
+
+def test_pick_ray_oracle_finds_the_nearest_box():
+    # Layer::pick_ray (layer.rs:418-446) with the built-in ray/AABB distance: the pruned, ordered traversal must
+    # return the same nearest distance as a brute-force slab test over all objects
+    from broadphase_rs_amd import scenes
+    sysb, bounds, ids = scenes.gen_boxes(1500, seed=9)
+    c = oracle.OracleLayer(K3, 0)
+    c.extend(sysb, bounds, ids)
+    rng = np.random.default_rng(4)
+    L = float(sysb[1][0])
+    f = np.float32
+    hits = 0
+    for q in range(120):
+        org = rng.uniform(0, L, 3).astype(f); d = rng.normal(size=3).astype(f)
+        if q % 6 == 0:
+            d[q % 3] = 0
+        maxd = f(L if q % 2 else L / 20)
+        got = c.pick_ray_aabb(sysb, org, d, maxd, bounds)
+        best = None
+        for i in range(len(bounds)):
+            tmin, tmax, ok = f(0), f(np.inf), True
+            for a in range(3):
+                if d[a] == 0:
+                    if org[a] < bounds[i][a] or org[a] > bounds[i][3 + a]:
+                        ok = False
+                        break
+                else:
+                    t0 = f(f(bounds[i][a] - org[a]) / d[a]); t1 = f(f(bounds[i][3 + a] - org[a]) / d[a])
+                    if t0 > t1:
+                        t0, t1 = t1, t0
+                    tmin = max(tmin, t0); tmax = min(tmax, t1)
+            if ok and tmin <= tmax and tmin < maxd and (best is None or tmin < best):
+                best = tmin
+        if got is None:
+            assert best is None
+        else:
+            hits += 1
+            assert best is not None and f(got[0]) == best
+    assert hits > 30
