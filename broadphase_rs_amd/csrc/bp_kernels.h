@@ -135,7 +135,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
                              const unsigned char* d_lut, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                              uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
-                             const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in = nullptr);
+                             const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in = nullptr,
+                             const unsigned long long* ready_hist = nullptr);
 // ids[i] = packed & BOX_ID_MASK, box[i] = packed >> BOX_ID_BITS (in place on ids)
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream);
 // the inverse: ids[i] |= box_to_packed(box[i]) << BOX_ID_BITS (in place)

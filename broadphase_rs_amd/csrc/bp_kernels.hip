@@ -1970,10 +1970,12 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
                              const unsigned char* d_lut, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                              uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
-                             const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in) {
+                             const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in,
+                             const unsigned long long* ready_hist) {
     EntryDestDigit fn{d_lut, cell_shift, depth_mask, split_depth, coarse_bucket};
     return partition_pass<u32, EntryDestDigit>((const u64*)keys_in, (u64*)keys_out, ids_in, ids_out, m, fn, workspace,
-                                               workspace_bytes, sc, (const u64**)d_hist, stream, box_in);
+                                               workspace_bytes, sc, (const u64**)d_hist, stream, box_in, nullptr, 0,
+                                               (const u64*)ready_hist);
 }
 
 __global__ __launch_bounds__(256) void split_box_kernel(u32* __restrict__ ids, uint8_t* __restrict__ box, size_t m) {

@@ -53,6 +53,10 @@ struct bp_layer {
     // since, so the next sort only has to sort [0, run_split) and merge the two runs
     bool tail_run = false;
     size_t run_split = 0;
+    // multi-GPU: the last cell histogram, reused by the entry partition while the tree is unchanged
+    std::vector<unsigned long long> cell_hist_cache;
+    uint32_t cell_hist_depth = 0;
+    bool cell_hist_valid = false;
 
     // facts about the tree that steer kernel selection (never change results)
     bool have_ids = false;      // anything appended since the last clear
@@ -366,7 +370,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     int seg_shift_unused = 0;
     const bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
                               hist_plan.n_passes <= SX_HIST_MAX;
-    L->tree_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false;
     // same situation: the codes can ride in the ids from the start (ids distinct and < 2^27), so the tree
     // sort's first pass has no box bytes to gather and none are written here
     static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;  // A/B switch for measurements
@@ -568,7 +572,7 @@ int sort_tree(bp_layer* L) {
             // first pass packs the box codes into the payload; the finish kernel splits them off again
             // digit counts left behind by encode_emit, if the tree is still exactly that extend's output
             const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(plan, L->tree_hist_plan);
-            L->tree_hist_valid = false;
+            L->tree_hist_valid = false; L->cell_hist_valid = false;
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
@@ -1054,7 +1058,7 @@ int bp_layer_destroy(bp_layer_t* L) {
 
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
-    L->tree_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false;
     L->tail_run = false;
     L->m = 0;
     L->sorted = true;  // src/layer.rs:84-88
@@ -1110,7 +1114,7 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
     L->box_all_known = false;
     BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
-    L->tree_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false;
     L->tail_run = false;
     L->m += m;
     L->sorted = false;
@@ -1164,7 +1168,7 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
             L->min_id = std::min(L->min_id, other->min_id);
             L->have_ids = L->have_ids || other->have_ids;
         }
-        L->tree_hist_valid = false;
+        L->tree_hist_valid = false; L->cell_hist_valid = false;
         // the appended entries form one sorted run if `other` was sorted (and no earlier run is pending)
         const bool had_run = L->tail_run;
         L->tail_run = !had_run && other->sorted;
@@ -1563,7 +1567,7 @@ int bp_layer_commit_entries(bp_layer_t* L, size_t m, const bp_facts* f) {
     if (L->m != 0) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: call bp_layer_begin_entries first");
     if (m * sizeof(uint64_t) > L->keys[L->cur].cap) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: more entries than begun");
     if (m == 0) return BP_OK;
-    L->tree_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false;
     L->tail_run = false;
     L->m = m;
     L->sorted = false;
@@ -1608,6 +1612,9 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, L->block_sums.p, bytes, hipMemcpyDeviceToHost, L->stream));
     BP_TRY(sync_stream(L));
     std::memcpy(hist, L->h_raw.p, bytes);
+    L->cell_hist_cache.assign(hist, hist + n_cells + 1);
+    L->cell_hist_depth = split_depth;
+    L->cell_hist_valid = true;
     return BP_OK;
 }
 
@@ -1640,13 +1647,26 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     BP_TRY(ensure_host(L, L->h_raw, 256 * sizeof(unsigned long long)));
     BP_TRY(sc_reset(L));
     const int cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * split_depth);
+    // bucket sizes straight from the cell histogram the caller just asked for (same tree, same split depth):
+    // the partition pass then needs no histogram read of its own
+    const unsigned long long* ready_hist = nullptr;
+    if (L->cell_hist_valid && L->cell_hist_depth == split_depth && L->cell_hist_cache.size() == n_cells + 1) {
+        unsigned long long* h = (unsigned long long*)L->h_raw.p;
+        std::memset(h, 0, 256 * sizeof(unsigned long long));
+        for (size_t c = 0; c < n_cells; ++c) h[lut[c] < n_dest ? lut[c] : 0] += L->cell_hist_cache[c];
+        h[n_dest] += L->cell_hist_cache[n_cells];  // coarse entries
+        BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+        HIP_TRY(L, hipMemcpyAsync(L->pair_hist.p, h, 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, L->stream));
+        BP_TRY(sync_stream(L));  // h_raw is reused below
+        ready_hist = (const unsigned long long*)L->pair_hist.p;
+    }
     const unsigned long long* d_hist = nullptr;
     {
         ProfScope ps(L, BP_K_MISC);
         HIP_TRY(L, partition_entries(cur_keys(L), (uint64_t*)L->keys[other].p, cur_ids(L), (uint32_t*)L->ids[other].p, L->m,
                                      (const unsigned char*)L->skip.p, cell_shift, (1u << ki.depth_bits) - 1u, split_depth, n_dest,
                                      L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream,
-                                     (pack_box && !already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr));
+                                     (pack_box && !already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr, ready_hist));
     }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
