@@ -70,6 +70,7 @@ struct SysBounds {
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
 constexpr int ENC_STAGE = 2048;   // entries of one round staged in LDS by encode_emit (8 per object)
+constexpr int ENC_CELLS_MAX = 512; // cells encode_emit can histogram (8^3 in 3-D, 4^4 in 2-D)
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
 // workgroups (= block sums / BlockAux partials) for n objects
 inline size_t enc_blocks(size_t n) { return (n + (size_t)ENC_THREADS * ENC_ROUNDS - 1) / ((size_t)ENC_THREADS * ENC_ROUNDS); }
@@ -80,7 +81,10 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
-                              const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0);
+                              const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
+                              unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0);
+// cell_hist / cell_depth: also count the entries per cell at cell_depth (multi-GPU splitter selection) into
+// HIST_COPIES copies of 2^(dim*cell_depth) + 1 counters (zeroed by the caller; at most ENC_CELLS_MAX cells)
 // pack_box: write id | box_to_packed(code) << BOX_ID_BITS into ids_out (box_out may then be nullptr)
 // hist_plan / hist: also count the key digits of every emitted entry for the passes of hist_plan
 // (<= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller)

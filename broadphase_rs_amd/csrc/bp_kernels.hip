@@ -212,6 +212,11 @@ struct DigitCount {
     u64* hist;       // [passes][256], zeroed by the host; nullptr / passes == 0: nothing to count
     int passes;      // <= SX_HIST_MAX
     int shift[SX_HIST_MAX];
+    // multi-GPU: entries per cell at cell_depth (slot n_cells: entries coarser than that), HIST_COPIES copies of
+    // n_cells + 1 counters (zeroed by the host); nullptr: off.  n_cells <= ENC_CELLS_MAX.
+    u64* cell_hist;
+    int cell_shift;
+    u32 cell_depth, n_cells, depth_mask;
 };
 
 template <int KIND>
@@ -226,13 +231,20 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     constexpr u32 DIM = KT<KIND>::DIM;
     __shared__ u32 s_ws[ENC_THREADS / 64];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
+    __shared__ u32 s_cell[ENC_CELLS_MAX + 1];
     for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) s_hist[k] = 0;  // visible after the scan's barriers
+    if (dc.cell_hist)
+        for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) s_cell[k] = 0;
     auto count_digits = [&](u64 key) {
 #pragma unroll
         for (int q = 0; q < SX_HIST_MAX; ++q) {
             if (q < dc.passes)
                 __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(key >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (dc.cell_hist) {
+            const u32 slot = ((u32)key & dc.depth_mask) < dc.cell_depth ? dc.n_cells : (u32)(key >> dc.cell_shift);
+            __hip_atomic_fetch_add(&s_cell[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup; block_offs[blockIdx.x] = first entry of the workgroup.
@@ -293,6 +305,14 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 if (box_out) box_out[this_base + k] = s_box[k];
             }
             __syncthreads();  // the stage is reused by the next round
+        }
+    }
+    if (dc.cell_hist) {  // workgroup-uniform
+        __syncthreads();
+        u64* copy = dc.cell_hist + (size_t)(blockIdx.x % HIST_COPIES) * (dc.n_cells + 1);
+        for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) {
+            const u32 v = s_cell[k];
+            if (v) atomicAdd(&copy[k], (u64)v);
         }
     }
     if (dc.passes) {  // workgroup-uniform.  One device atomic per bin per workgroup would serialise on the bin's
@@ -1775,10 +1795,19 @@ hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, cons
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
-                              const RadixPlan* hist_plan, unsigned long long* hist, int pack_box) {
+                              const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
+                              uint32_t cell_depth) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
+    const KindInfo ki = kind_info(kind);
+    dc.cell_hist = nullptr; dc.cell_shift = 0; dc.cell_depth = 0; dc.n_cells = 0; dc.depth_mask = (1u << ki.depth_bits) - 1u;
+    if (cell_hist && cell_depth > 0 && ki.dim * cell_depth <= 12 && (1u << (ki.dim * cell_depth)) <= (uint32_t)ENC_CELLS_MAX) {
+        dc.cell_hist = (u64*)cell_hist;
+        dc.cell_depth = cell_depth;
+        dc.n_cells = 1u << (ki.dim * cell_depth);
+        dc.cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * cell_depth);
+    }
     dc.hist = (u64*)hist; dc.passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) dc.shift[q] = 0;
     if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {

@@ -57,6 +57,9 @@ struct bp_layer {
     std::vector<unsigned long long> cell_hist_cache;
     uint32_t cell_hist_depth = 0;
     bool cell_hist_valid = false;
+    uint32_t cell_fuse_depth = 0;       // > 0: extend counts the cell histogram at this depth while it emits
+    DevBuf cell_hist_dev;               // its HIST_COPIES copies on the device ...
+    bool cell_dev_valid = false;        // ... describe the current tree (exactly one extend since clear)
 
     // facts about the tree that steer kernel selection (never change results)
     bool have_ids = false;      // anything appended since the last clear
@@ -370,11 +373,18 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     int seg_shift_unused = 0;
     const bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
                               hist_plan.n_passes <= SX_HIST_MAX;
-    L->tree_hist_valid = false; L->cell_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     // same situation: the codes can ride in the ids from the start (ids distinct and < 2^27), so the tree
     // sort's first pass has no box bytes to gather and none are written here
     static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;  // A/B switch for measurements
     const bool pack = !no_emit_pack && L->m == 0 && L->box_valid && L->ids_distinct && (sc.id_or >> BOX_ID_BITS) == 0;
+    const KindInfo kic = kind_info(L->kind);
+    const bool count_cells = L->m == 0 && L->cell_fuse_depth > 0 && kic.dim * L->cell_fuse_depth <= 9;
+    const size_t cell_bytes = count_cells ? (size_t)HIST_COPIES * (((size_t)1 << (kic.dim * L->cell_fuse_depth)) + 1) * sizeof(unsigned long long) : 0;
+    if (count_cells) {
+        BP_TRY(ensure_dev(L, L->cell_hist_dev, cell_bytes));
+        HIP_TRY(L, hipMemsetAsync(L->cell_hist_dev.p, 0, cell_bytes, L->stream));
+    }
     if (count_digits) {
         BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
         HIP_TRY(L, hipMemsetAsync(L->tree_hist.p, 0, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
@@ -385,8 +395,10 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p + L->m, L->stream,
                                       count_digits ? &hist_plan : nullptr,
-                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0));
+                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0,
+                                      count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth));
     }
+    if (count_cells) L->cell_dev_valid = true;
     if (pack) { L->ids_packed = true; L->box_valid = false; }  // until the sort (or ensure_unpacked) splits them off
     L->tail_run = false;
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
@@ -572,7 +584,7 @@ int sort_tree(bp_layer* L) {
             // first pass packs the box codes into the payload; the finish kernel splits them off again
             // digit counts left behind by encode_emit, if the tree is still exactly that extend's output
             const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(plan, L->tree_hist_plan);
-            L->tree_hist_valid = false; L->cell_hist_valid = false;
+            L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
@@ -1048,7 +1060,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
     free_host(L->h_shards);
     if (L->stream) (void)hipStreamDestroy(L->stream);
@@ -1058,7 +1070,7 @@ int bp_layer_destroy(bp_layer_t* L) {
 
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
-    L->tree_hist_valid = false; L->cell_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
     L->m = 0;
     L->sorted = true;  // src/layer.rs:84-88
@@ -1114,7 +1126,7 @@ int bp_layer_append_entries(bp_layer_t* L, const uint64_t* keys, const uint32_t*
     HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
     L->box_all_known = false;
     BP_TRY(absorb_raw_entries(L, cur_keys(L) + L->m, cur_ids(L) + L->m, m));
-    L->tree_hist_valid = false; L->cell_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
     L->m += m;
     L->sorted = false;
@@ -1168,7 +1180,7 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
             L->min_id = std::min(L->min_id, other->min_id);
             L->have_ids = L->have_ids || other->have_ids;
         }
-        L->tree_hist_valid = false; L->cell_hist_valid = false;
+        L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
         // the appended entries form one sorted run if `other` was sorted (and no earlier run is pending)
         const bool had_run = L->tail_run;
         L->tail_run = !had_run && other->sorted;
@@ -1567,7 +1579,7 @@ int bp_layer_commit_entries(bp_layer_t* L, size_t m, const bp_facts* f) {
     if (L->m != 0) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: call bp_layer_begin_entries first");
     if (m * sizeof(uint64_t) > L->keys[L->cur].cap) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_commit_entries: more entries than begun");
     if (m == 0) return BP_OK;
-    L->tree_hist_valid = false; L->cell_hist_valid = false;
+    L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
     L->m = m;
     L->sorted = false;
@@ -1600,6 +1612,22 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_cell_histogram: n_cells must be 2^(dim*split_depth) <= 4096");
     DeviceGuard g(L->device);
     const size_t bytes = (n_cells + 1) * sizeof(unsigned long long);
+    if (L->cell_dev_valid && L->cell_fuse_depth == split_depth) {  // counted by extend: sum the copies, no kernel
+        const size_t all = (size_t)HIST_COPIES * bytes;
+        BP_TRY(ensure_host(L, L->h_raw, all));
+        HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, L->cell_hist_dev.p, all, hipMemcpyDeviceToHost, L->stream));
+        BP_TRY(sync_stream(L));
+        const unsigned long long* c = (const unsigned long long*)L->h_raw.p;
+        for (size_t k = 0; k <= n_cells; ++k) {
+            unsigned long long t = 0;
+            for (int q = 0; q < HIST_COPIES; ++q) t += c[(size_t)q * (n_cells + 1) + k];
+            hist[k] = t;
+        }
+        L->cell_hist_cache.assign(hist, hist + n_cells + 1);
+        L->cell_hist_depth = split_depth;
+        L->cell_hist_valid = true;
+        return BP_OK;
+    }
     BP_TRY(ensure_dev(L, L->block_sums, bytes));
     BP_TRY(ensure_host(L, L->h_raw, bytes));
     HIP_TRY(L, hipMemsetAsync(L->block_sums.p, 0, bytes, L->stream));
@@ -1615,6 +1643,13 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
     L->cell_hist_cache.assign(hist, hist + n_cells + 1);
     L->cell_hist_depth = split_depth;
     L->cell_hist_valid = true;
+    return BP_OK;
+}
+
+int bp_layer_set_cell_histogram_depth(bp_layer_t* L, uint32_t split_depth) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    L->cell_fuse_depth = split_depth;
+    L->cell_dev_valid = false;
     return BP_OK;
 }
 

@@ -252,6 +252,8 @@ class ShardedLayer:
         self.n_global = n_global
         self.max_id_local = -1
         self.last = {}
+        if hasattr(self.backend, "local") and hasattr(self.backend.local, "set_cell_histogram_depth"):
+            self.backend.local.set_cell_histogram_depth(self.split_depth)   # extend counts the splitter histogram itself
 
     @property
     def shard_layer(self):

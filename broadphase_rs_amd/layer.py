@@ -75,6 +75,7 @@ EXPORTS = [
     "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
+    "bp_layer_set_cell_histogram_depth",
     "bp_layer_test_box_batch", "bp_layer_test_box_batch_device", "bp_layer_test_ray_batch", "bp_layer_test_ray_batch_device",
     "bp_layer_pick_ray_aabb_batch",
     "bp_layer_sort_unique_packed_device",
@@ -540,6 +541,10 @@ class Layer:
     def append_entries_assume(self, keys_ptr, ids_ptr, m, order_ok, ids_distinct, ids_carry_box=False, box_all_known=False):
         facts = (1 if order_ok else 0) | (2 if ids_distinct else 0) | (4 if ids_carry_box else 0) | (8 if box_all_known else 0)
         self._check(self._L.bp_layer_append_entries_assume(self._h, C.c_void_p(keys_ptr), C.c_void_p(ids_ptr), m, facts))
+
+    def set_cell_histogram_depth(self, split_depth):
+        self._L.bp_layer_set_cell_histogram_depth.argtypes = [C.c_void_p, C.c_uint32]
+        self._check(self._L.bp_layer_set_cell_histogram_depth(self._h, int(split_depth)))
 
     def cell_histogram(self, split_depth):
         n_cells = 1 << (self.index.dim * split_depth)

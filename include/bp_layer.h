@@ -177,6 +177,9 @@ int bp_layer_commit_entries(bp_layer_t *layer, size_t m, const bp_facts *facts);
 /* entries per Morton cell at split_depth: hist[n_cells + 1] (host), last slot = coarse entries
  * (depth < split_depth).  n_cells must be 2^(dim * split_depth) and <= 4096. */
 int bp_layer_cell_histogram(bp_layer_t *layer, uint32_t split_depth, uint64_t *hist, size_t n_cells);
+/* announce the split depth in advance (0 = off): the next extend into the empty layer then counts this
+ * histogram while it emits the entries and bp_layer_cell_histogram only sums the partial counts */
+int bp_layer_set_cell_histogram_depth(bp_layer_t *layer, uint32_t split_depth);
 /* stable bucketing of the layer's entries by owner: lut[n_cells] (host) maps a cell to its owner
  * 0..n_dest-1, coarse entries form bucket n_dest.  counts[n_dest + 1] (host).  The layer itself
  * is not modified. */

@@ -647,3 +647,27 @@ def test_pick_ray_batch_matches_reference_traversal(kind, min_depth):
     assert one is not None and one[1] == exp[1] and np.allclose(one[2], org[1] + dirs[1] * np.float32(exp[0]))
     with pytest.raises(bp.BroadphaseError):                          # an id without a row in the table
         gpu.pick_ray_aabb_batch(sysb, rays[:4], bounds[:10])
+
+
+@pytest.mark.parametrize("kind,depth", [(2, 3), (0, 4)])
+def test_cell_histogram_counted_by_extend_matches_the_kernel(kind, depth):
+    dim = 2 if kind != 2 else 3
+    sysb, bounds, ids = scenes.gen_boxes(50000, seed=90 + kind)
+    if dim == 2:
+        sysb = np.ascontiguousarray(sysb[:, :2]); bounds = np.ascontiguousarray(bounds[:, [0, 1, 3, 4]])
+    bounds[:3] = np.concatenate([sysb[0], sysb[1]])                 # a few whole-system boxes: coarse entries
+    index = {0: bp.Index32_2D, 1: bp.Index64_2D, 2: bp.Index64_3D}[kind]
+    plain = bp.Layer(index, 0)
+    plain.extend(sysb, bounds, ids)
+    exp = plain.cell_histogram(depth)
+    assert exp[-1] >= 3 and exp.sum() == len(plain)
+    fused = bp.Layer(index, 0)
+    fused.set_cell_histogram_depth(depth)
+    fused.extend(sysb, bounds, ids)
+    assert np.array_equal(fused.cell_histogram(depth), exp)
+    assert np.array_equal(fused.cell_histogram(depth - 1), plain.cell_histogram(depth - 1))   # other depth: kernel path
+    fused.extend(sysb, bounds[:100], np.arange(len(ids), len(ids) + 100, dtype=np.uint32))     # second extend: kernel path
+    plain.extend(sysb, bounds[:100], np.arange(len(ids), len(ids) + 100, dtype=np.uint32))
+    assert np.array_equal(fused.cell_histogram(depth), plain.cell_histogram(depth))
+    fused.clear(); fused.extend(sysb, bounds, ids)                                             # next frame: fused again
+    assert np.array_equal(fused.cell_histogram(depth), exp)
