@@ -128,6 +128,41 @@ template <class Index, class ID = uint32_t> class Layer {
         return out;
     }
 
+    // Layer::test_ray (layer.rs:327-351): ids of the cells the ray origin + t * direction, t in [range_min, range_max],
+    // passes through (the range is clamped to the system bounds); max_depth < 0 stands for None
+    std::vector<ID> test_ray(const Bounds<Index::dim>& system_bounds, const float (&origin)[Index::dim],
+                             const float (&direction)[Index::dim], float range_min, float range_max, int max_depth = -1) {
+        float row[2 * Index::dim + 2];
+        for (int a = 0; a < Index::dim; ++a) { row[a] = origin[a]; row[Index::dim + a] = direction[a]; }
+        row[2 * Index::dim] = range_min;
+        row[2 * Index::dim + 1] = range_max;
+        const uint32_t* rows = nullptr;
+        size_t n = 0;
+        check(bp_layer_test_ray_batch(h_, system_bounds.min, system_bounds.max, row, 1, max_depth >= 0 ? 1 : 0,
+                                      max_depth >= 0 ? (uint32_t)max_depth : 0u, &rows, &n));
+        std::vector<ID> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = (ID)rows[2 * i + 1];
+        return out;
+    }
+
+    // Layer::pick_ray (layer.rs:418-446) with the built-in ray/AABB distance over bounds_by_id (rows of 2*dim f32):
+    // true + (dist, id) of the nearest box hit within max_dist
+    bool pick_ray_aabb(const Bounds<Index::dim>& system_bounds, const float (&origin)[Index::dim],
+                       const float (&direction)[Index::dim], float max_dist, const float* bounds_by_id, size_t n_rows,
+                       float* dist, ID* id, int max_depth = -1) {
+        float row[2 * Index::dim + 1];
+        for (int a = 0; a < Index::dim; ++a) { row[a] = origin[a]; row[Index::dim + a] = direction[a]; }
+        row[2 * Index::dim] = max_dist;
+        float d = 0.f;
+        uint32_t hit = 0xFFFFFFFFu;
+        check(bp_layer_pick_ray_aabb_batch(h_, system_bounds.min, system_bounds.max, row, 1, max_depth >= 0 ? 1 : 0,
+                                           max_depth >= 0 ? (uint32_t)max_depth : 0u, bounds_by_id, n_rows, &d, &hit));
+        if (hit == 0xFFFFFFFFu) return false;
+        *dist = d;
+        *id = (ID)hit;
+        return true;
+    }
+
     // Layer::iter (layer.rs:79-81): entries in current order
     std::vector<std::pair<uint64_t, ID>> iter() {
         const uint64_t* k; const uint32_t* i; size_t m; int s;

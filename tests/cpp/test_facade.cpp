@@ -1,5 +1,6 @@
 // C++ facade test (GPU): mirrors the reference's usage snippet (src/lib.rs:24-47) and the
 // assertions of tests/test_layer.rs on the SURVEY.md 8(c) worked example.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -53,6 +54,14 @@ int main() {
     CHECK(near_origin.size() == 3 && near_origin[0] == 0 && near_origin[1] == 1 && near_origin[2] == 2);
     auto far_corner = layer.test_box(system_bounds, B3{{10.f, 10.f, 10.f}, {12.f, 12.f, 12.f}}, 2);
     CHECK(far_corner.size() == 2 && far_corner[0] == 2 && far_corner[1] == 3);
+    const float ray_o[3] = {0.5f, 8.0f, 8.0f}, ray_d[3] = {1.0f, 0.0f, 0.0f};
+    auto along = layer.test_ray(system_bounds, ray_o, ray_d, -INFINITY, INFINITY);
+    CHECK(along.size() == 2 && along[0] == 2 && along[1] == 3);   // the whole-system box and the one around (8, 8, 8)
+    const float boxes_by_id[4][6] = {{1, 1, 1, 2, 2, 2}, {1.5f, 1.5f, 1.5f, 3, 3, 3}, {0, 0, 0, 16, 16, 16}, {7, 7, 7, 9, 9, 9}};
+    float hit_dist = -1.f;
+    uint32_t hit_id = 99;
+    CHECK(layer.pick_ray_aabb(system_bounds, ray_o, ray_d, 100.f, &boxes_by_id[0][0], 4, &hit_dist, &hit_id));
+    CHECK(hit_id == 2 && hit_dist == 0.f);                          // the origin is inside the whole-system box
     CHECK(layer.par_scan().size() == 4);  // the scan is unaffected by the shared result buffers
 
     // merge: static layer into a dynamic one (layer.rs:123-138)
