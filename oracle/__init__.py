@@ -4,8 +4,9 @@ TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() an
 cpu_baseline leg of bench.py -- never by the product package (broadphase_rs_amd), which fails
 loudly when its HIP library is missing instead of falling back to this.
 
-Parity pinning status: see bp_oracle.h (end-to-end parity against reference-generated data is
-UNPINNED: no Rust toolchain, golden scenes are LFS stubs; codec/quantisation KATs are pinned).
+Parity pinning status: see bp_oracle.h -- PINNED end to end: run on the reference's own 10 000-object test
+scene (regenerated bit-exactly, authenticated by the Git-LFS sha256) it reproduces the reference's three
+validation goldens byte for byte (tests/test_reference_goldens.py); the codec/quantisation KATs are pinned too.
 """
 import ctypes as C
 import os

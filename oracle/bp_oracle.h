@@ -8,13 +8,18 @@
  * It is a plain-C restatement of the reference algorithm (zvxryb/broadphase-rs 0.1.2,
  * Rust).  Every function cites the reference file:line it follows.
  *
- * PARITY PINNING STATUS: the reference crate cannot be compiled here (no rustc/cargo)
- * and its golden scenes under tests/data are Git-LFS pointer stubs, so END-TO-END
- * PARITY IS UNPINNED against reference-generated data.  What IS pinned: the in-source
- * known-answer tests of the reference (src/index.rs:343-374 codec, src/geom.rs:696-706
- * quantisation), the structural assertions of tests/test_layer.rs:42-54 (sortedness /
- * strict uniqueness), a second independent restatement in Python (oracle/py_oracle.py)
- * and a brute-force AABB no-false-negative check.  See DESIGN.md "Oracle".
+ * PARITY PINNING STATUS: PINNED END TO END for the extend -> sort -> scan path.  The reference
+ * crate cannot be compiled here (no rustc/cargo) and its test data under tests/data are Git-LFS
+ * pointer stubs -- but the pointers carry the SHA-256 of every file.  tests/golden/ref_scene_gen.py
+ * regenerates the reference's input scenes bit-exactly (its RNG and sampling restated; hashes equal
+ * the LFS oids), and this oracle run through gen_validation_data's recipe on the 10 000-object scene
+ * reproduces the reference's three validation goldens byte for byte: 0_layer_unsorted, 1_layer_sorted,
+ * 2_layer_collisions all hash to their LFS oids (tests/test_reference_goldens.py).  Also pinned: the
+ * in-source known-answer tests of the reference (src/index.rs:343-374 codec, src/geom.rs:696-706
+ * quantisation), the structural assertions of tests/test_layer.rs:42-54, a second independent
+ * restatement in Python (oracle/py_oracle.py) and a brute-force AABB no-false-negative check.
+ * The region queries (test_box / test_ray / pick_ray) have no golden in the reference: they are
+ * pinned by the agreement of two independent restatements only.  See DESIGN.md "Oracle".
  */
 #ifndef BP_ORACLE_H
 #define BP_ORACLE_H

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Bit-exact regeneration of the reference's test scenes (tests/gen_test_scenes.py -> utils gen_boxes,
+utils/src/gen_test_data.rs:98-155) WITHOUT the Rust toolchain: rand_core 0.5 `seed_from_u64` (PCG32 seed expansion),
+rand_chacha 0.2 `ChaChaRng` (ChaCha20, 64-bit counter, stream 0, words consumed in order) and rand 0.7
+`gen_range` for f32 (`UniformFloat::sample_single`: 23 random mantissa bits -> [1, 2) - 1, then * scale + low)
+restated from their published algorithms.  The output is authenticated by the sha256 of the reference's
+Git-LFS pointers (tests/data/inputs/*.br_scene), which is all this container has of those files."""
+import hashlib
+import struct
+import sys
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+
+
+def seed_from_u64(state):
+    """rand_core 0.5 SeedableRng::seed_from_u64: PCG32 output per 4-byte chunk of the 32-byte seed"""
+    MUL, INC = 6364136223846793005, 11634580027462260723
+    out = b""
+    for _ in range(8):
+        state = (state * MUL + INC) & 0xFFFFFFFFFFFFFFFF
+        xorshifted = (((state >> 18) ^ state) >> 27) & M32
+        rot = state >> 59
+        x = ((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & M32
+        out += struct.pack("<I", x)
+    return out
+
+
+def _rotl(v, n):
+    return ((v << n) | (v >> (32 - n))) & M32
+
+
+def chacha20_block(key_words, counter):
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter & M32, (counter >> 32) & M32, 0, 0]
+    x = list(st)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M32; x[d] = _rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M32; x[b] = _rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M32; x[d] = _rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M32; x[b] = _rotl(x[b] ^ x[c], 7)
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(x[i] + st[i]) & M32 for i in range(16)]
+
+
+class ChaChaRng:
+    def __init__(self, seed_u64):
+        self.key = struct.unpack("<8I", seed_from_u64(seed_u64))
+        self.counter = 0
+        self.buf = []
+
+    def next_u32(self):
+        if not self.buf:
+            self.buf = chacha20_block(self.key, self.counter)
+            self.counter += 1
+        return self.buf.pop(0)
+
+    def gen_range_f32(self, low, high):
+        """rand 0.7 UniformFloat<f32>::sample_single"""
+        f = np.float32
+        low, high = f(low), f(high)
+        scale = f(high - low)
+        while True:
+            bits = (self.next_u32() >> 9) | 0x3F800000          # [1, 2)
+            value0_1 = f(np.frombuffer(struct.pack("<I", bits), dtype=np.float32)[0] - f(1.0))
+            res = f(f(value0_1 * scale) + low)
+            if res < high:
+                return res
+            # rounding pushed the result onto `high`: shrink the scale by one ulp and draw again
+            scale = np.nextafter(scale, f(0.0), dtype=np.float32)
+
+
+def gen_boxes(count, seed=0, density=0.001, size_range=(1.0, 10.0), cbrt_ulps=0):
+    f = np.float32
+    s0, s1 = f(size_range[0]), f(size_range[1])
+    avg = f(f(s0 + s1) / f(2.0))
+    volume = f(f(count) / f(density))
+    lin = f(np.cbrt(volume))
+    for _ in range(abs(cbrt_ulps)):                             # libm cbrtf may differ by an ulp between platforms
+        lin = np.nextafter(lin, f(np.inf if cbrt_ulps > 0 else -np.inf), dtype=np.float32)
+    linear = f(lin + avg)
+    rng = ChaChaRng(seed)
+    rows = []
+    for _ in range(count):
+        size = [rng.gen_range_f32(s0, s1) for _ in range(3)]
+        mn = [rng.gen_range_f32(f(0.0), f(linear - size[i])) for i in range(3)]
+        mx = [f(mn[i] + size[i]) for i in range(3)]
+        rows.append(mn + mx)
+    sysb = np.array([[0, 0, 0], [linear, linear, linear]], dtype=np.float32)
+    return sysb, np.array(rows, dtype=np.float32), np.arange(count, dtype=np.uint32)
+
+
+def scene_v1_0_bytes(sysb, bounds, ids):
+    """data/src/lib.rs:19-32 with bincode 1.x: header (sig, (u16, u16)), Bounds = 6 f32, Vec = u64 len + items"""
+    out = b"BR_SCENE" + struct.pack("<HH", 1, 0)
+    out += np.asarray(sysb, dtype="<f4").tobytes()
+    out += struct.pack("<Q", len(ids))
+    rec = np.zeros(len(ids), dtype=[("b", "<f4", 6), ("id", "<u4")])
+    rec["b"] = bounds
+    rec["id"] = ids
+    return out + rec.tobytes()
+
+
+LFS_INPUTS = {  # tests/data/inputs/boxes-seed_0-d_1_1000-s_1_10-n_<count>.br_scene: (sha256, size)
+    100: ("9b0c04de94bfb0f26bc7ef7b514a6a87f119cb45511dfdf17d4185a3a9124752", 2844),
+    300: ("97f21bf06961f9d9c0e31a38e7c92f77d3d07130dabeee5237876b89e67371d5", 8444),
+    1000: ("c42fffb943673b2b2b4691e87b40e5e2967ad59ce47ca7f5da73d26a6699a99a", 28044),
+    3000: ("a3b90443b3dd4a207d9144ed34e02381f75fc544555afdf2ce7b069b4e661fbb", 84044),
+    10000: ("08c4a789322c5cd8934c044cb53aaa8735bc7b5401a9fd10f22535f6cb706c92", 280044),
+    30000: ("c70e9f16eb0208f233a215415e8f320a74b7c678dc6744b381652fb827222121", 840044),
+    100000: ("738667c97d094782d4a58549272984795f5617b2484cb6f0ce9d5332f7064023", 2800044),
+}
+
+if __name__ == "__main__":
+    for count in [int(a) for a in sys.argv[1:]] or [100]:
+        want, size = LFS_INPUTS[count]
+        for ulps in (0, 1, -1, 2, -2):
+            sysb, b, ids = gen_boxes(count, cbrt_ulps=ulps)
+            blob = scene_v1_0_bytes(sysb, b, ids)
+            h = hashlib.sha256(blob).hexdigest()
+            print(count, "cbrt ulps", ulps, "size", len(blob), "(want %d)" % size, "sha", h[:16], "MATCH" if h == want else "")
+            if h == want:
+                break

@@ -1,0 +1,102 @@
+"""END-TO-END PIN against the reference's own test data.
+
+The reference keeps its input scenes and its three validation goldens (tests/data/**, consumed by tests/test_layer.rs)
+in Git LFS; this tree only has the pointer files: sha256 + size (tests/golden/reference_lfs_oids.json).  The inputs are
+regenerated bit-exactly here (tests/golden/ref_scene_gen.py restates the RNG and the sampling of
+utils/src/gen_test_data.rs:98-155) and the goldens are re-derived with gen_validation_data's recipe
+(utils/src/gen_test_data.rs:761-785: extend -> save, sort -> save, scan -> save).  Equality of the SHA-256 with the
+LFS oids proves the regenerated inputs, the unsorted tree, the sorted tree and the collision list are byte-identical to
+what the reference produced."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from broadphase_rs_amd import scene_io
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+sys.path.insert(0, GOLD)
+import ref_scene_gen  # noqa: E402
+
+OIDS = json.load(open(os.path.join(GOLD, "reference_lfs_oids.json")))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.mark.parametrize("count", [100, 300])
+def test_generator_reproduces_the_reference_input_scenes(count):
+    meta = OIDS["inputs"]["boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count]
+    sysb, bounds, ids = ref_scene_gen.gen_boxes(count, seed=0, density=0.001, size_range=(1.0, 10.0), cbrt_ulps=meta["cbrt_ulps"])
+    blob = ref_scene_gen.scene_v1_0_bytes(sysb, bounds, ids)
+    assert len(blob) == meta["size"] and sha(blob) == meta["sha256"]
+    # the same bytes through the package's own BR_SCENE writer
+    assert scene_io.Scene(system_bounds=sysb, bounds=bounds, ids=ids).assemble((1, 0)) == blob
+
+
+@pytest.mark.parametrize("count", [1000, 10000])
+def test_committed_input_fixtures_are_the_reference_files(count):
+    meta = OIDS["inputs"]["boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count]
+    blob = open(os.path.join(GOLD, "ref_input_n_%06d.br_scene" % count), "rb").read()
+    assert len(blob) == meta["size"] and sha(blob) == meta["sha256"]
+
+
+def validation_blobs(scene, layer):
+    """utils/src/gen_test_data.rs:761-785 on any object with the Layer API.  The committed goldens were written when
+    the container was at version 1.1 (files 0, 1: system bounds + layer, no object list) and 1.2 (file 2: whole scene);
+    that is what their sizes say (57 + 12 M = 385137 with M = 32090) and what the hashes confirm."""
+    sysb = (scene.system_bounds[0], scene.system_bounds[1])
+    layer.extend(sysb, scene.bounds, scene.ids)
+    out = {}
+    s = scene_io.Scene(system_bounds=scene.system_bounds)
+    s.layer_min_depth, s.layer_sorted = 0, False
+    s.layer_keys, s.layer_ids = layer_tree(layer)
+    out["0_layer_unsorted.br_scene"] = s.assemble((1, 1))
+    layer.sort()
+    s.layer_keys, s.layer_ids = layer_tree(layer)
+    s.layer_sorted = True
+    out["1_layer_sorted.br_scene"] = s.assemble((1, 1))
+    full = scene_io.Scene(system_bounds=scene.system_bounds, bounds=scene.bounds, ids=scene.ids)
+    full.layer_min_depth, full.layer_sorted, full.layer_keys, full.layer_ids = 0, True, s.layer_keys, s.layer_ids
+    full.collisions = np.asarray(layer.scan(), dtype=np.uint32).reshape(-1, 2)
+    out["2_layer_collisions.br_scene"] = full.assemble((1, 2))
+    return out
+
+
+def layer_tree(layer):
+    if hasattr(layer, "tree"):
+        k, i = layer.tree()
+        return np.array(k), np.array(i)
+    return layer.keys, layer.ids
+
+
+def test_oracle_reproduces_the_reference_validation_goldens():
+    scene = scene_io.Scene.load(os.path.join(GOLD, "ref_input_n_010000.br_scene"))
+    blobs = validation_blobs(scene, oracle.OracleLayer(oracle.INDEX64_3D, 0))
+    for name, meta in OIDS["validation"].items():
+        assert len(blobs[name]) == meta["size"], name
+        assert sha(blobs[name]) == meta["sha256"], "%s differs from the reference's golden" % name
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_reference_validation_goldens():
+    import broadphase_rs_amd as bp
+    scene = scene_io.Scene.load(os.path.join(GOLD, "ref_input_n_010000.br_scene"))
+    blobs = validation_blobs(scene, bp.Layer(bp.Index64_3D, 0))
+    for name, meta in OIDS["validation"].items():
+        assert len(blobs[name]) == meta["size"], name
+        assert sha(blobs[name]) == meta["sha256"], "%s differs from the reference's golden" % name
+    # par_sort / par_scan are the same lists (tests/test_layer.rs:74-124)
+    lay = bp.Layer(bp.Index64_3D, 0)
+    scene.extend_into(lay)
+    lay.par_sort()
+    full = scene_io.Scene(system_bounds=scene.system_bounds, bounds=scene.bounds, ids=scene.ids)
+    full.set_layer_from(lay)
+    full.collisions = np.array(lay.par_scan())
+    assert sha(full.assemble((1, 2))) == OIDS["validation"]["2_layer_collisions.br_scene"]["sha256"]
