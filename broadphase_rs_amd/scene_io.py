@@ -9,7 +9,9 @@ one tag byte for `Option`/`bool`, structs and tuples as their fields in order.
   SceneV1_2   ... + collisions: Vec<(u32, u32)> | hits: Vec<u32> | nearest: Option<(u32, f32)>   lib.rs:41-49
 
 `ID = u32`, `Index = Index64_3D` (lib.rs:16-17).  Files written here can be read by the crate's
-`Scene::load`, and its files (e.g. the Git-LFS goldens, if they ever become available) by `load`.
+`Scene::load`, and its files by `load`.  The writer is byte-exact: the reference's seven input scenes and its
+three validation goldens, rebuilt with it, hash to the SHA-256 of their Git-LFS pointers
+(tests/test_reference_goldens.py).
 """
 import io
 import struct
