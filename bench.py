@@ -108,8 +108,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    # BP_BENCH_DEVICE / BP_DIST_BACKEND=gloo: rehearse the multi-process path with every rank on ONE GPU (gloo stages
+    # the exchanges through the host); the measured configuration is one GPU per rank over nccl = RCCL
+    if os.environ.get("BP_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["BP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_backend = os.environ.get("BP_DIST_BACKEND", "nccl")
     dist = None
     sharded_path = world > 1 or args.sharded
     if sharded_path:
@@ -118,8 +123,10 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
+        elif dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(dist_backend)
 
     n = args.objects
     n_global = n * world

@@ -134,6 +134,19 @@ class HipBackend:
         self.torch.cuda.synchronize(self.device)
 
 
+class _HostAlloc:
+    """stand-in for a backend when TorchComm stages an exchange through host memory"""
+
+    def __init__(self, torch):
+        self.torch, self.device = torch, "cpu"
+
+    def empty(self, n, dtype):
+        return self.torch.empty(n, dtype=dtype)
+
+    def sync(self):
+        pass
+
+
 class TorchComm:
     """collectives of one rank over a torch.distributed process group (nccl = RCCL on ROCm, gloo on CPU)"""
 
@@ -143,19 +156,25 @@ class TorchComm:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # gloo moves host memory only: device tensors are staged through the host (rehearsals of the multi-process
+        # path on one GPU; the production backend is nccl = RCCL, which takes device tensors as they are)
+        self.host_staged = dist.get_backend(group) == "gloo"
         import os
         if os.environ.get("BP_DIST_CHUNK_BYTES"):
             self.CHUNK_BYTES = max(8, int(os.environ["BP_DIST_CHUNK_BYTES"]))
 
     def all_reduce_sum(self, arr, backend):
-        t = self.torch.from_numpy(np.asarray(arr).astype(np.int64)).to(backend.device)
+        t = self.torch.from_numpy(np.asarray(arr).astype(np.int64)).to(self._small_device(backend))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
     def all_reduce_max(self, value, backend):
-        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=backend.device)
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self._small_device(backend))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
+
+    def _small_device(self, backend):
+        return "cpu" if self.host_staged else backend.device
 
     # The RCCL build bundled with PyTorch-ROCm 2.10 silently moves only HALF of any single
     # send/recv larger than 1 GiB (measured on MI355X: tools/dbg_a2a.py), so every exchange is cut
@@ -165,7 +184,7 @@ class TorchComm:
     def all_gather_counts(self, counts, backend):
         """every rank's count vector -> matrix C[src][k] (one small collective instead of one per exchange)"""
         torch, dist = self.torch, self.dist
-        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=backend.device)
+        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=self._small_device(backend))
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         return np.stack([p.cpu().numpy() for p in parts])
@@ -175,6 +194,13 @@ class TorchComm:
         exchange in flight (the caller's next exchange or backend.sync() fences it): back-to-back exchanges overlap"""
         torch, dist = self.torch, self.dist
         send_counts = [int(c) for c in send_counts]
+        if self.host_staged and send.is_cuda:  # gloo rehearsal: exchange host copies, then put the result where it belongs
+            got = self.all_to_all_v(send.cpu(), send_counts, dtype, _HostAlloc(torch), recv_counts, None, True)
+            recv = out[: got.numel()] if out is not None else backend.empty(got.numel(), dtype)
+            recv.copy_(got)
+            if sync:
+                backend.sync()
+            return recv
         if recv_counts is None:
             sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
             rc = torch.empty_like(sc)
@@ -214,6 +240,12 @@ class TorchComm:
     def all_gather_v(self, t, dtype, backend, sizes=None):
         """all-gather of per-rank tensors of different lengths, concatenated in rank order"""
         torch, dist = self.torch, self.dist
+        if self.host_staged and t.is_cuda:
+            got = self.all_gather_v(t.cpu(), dtype, _HostAlloc(torch), sizes)
+            out = backend.empty(got.numel(), dtype)
+            out.copy_(got)
+            backend.sync()
+            return out
         if sizes is None:
             n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
             got = [torch.empty_like(n) for _ in range(self.world)]
