@@ -219,7 +219,7 @@ struct DigitCount {
     u32 cell_depth, n_cells, depth_mask;
 };
 
-template <int KIND>
+template <int KIND, bool CELLS>
 __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
                                                                  const u32* __restrict__ counts,
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     constexpr u32 DIM = KT<KIND>::DIM;
     __shared__ u32 s_ws[ENC_THREADS / 64];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
-    __shared__ u32 s_cell[ENC_CELLS_MAX + 1];
+    __shared__ u32 s_cell[CELLS ? ENC_CELLS_MAX + 1 : 1];  // CELLS: a separate instantiation, the default kernel pays nothing
     for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) s_hist[k] = 0;  // visible after the scan's barriers
-    if (dc.cell_hist)
+    if (CELLS)
         for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) s_cell[k] = 0;
     auto count_digits = [&](u64 key) {
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(key >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (dc.cell_hist) {
+        if (CELLS) {
             const u32 slot = ((u32)key & dc.depth_mask) < dc.cell_depth ? dc.n_cells : (u32)(key >> dc.cell_shift);
             __hip_atomic_fetch_add(&s_cell[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             __syncthreads();  // the stage is reused by the next round
         }
     }
-    if (dc.cell_hist) {  // workgroup-uniform
+    if (CELLS) {
         __syncthreads();
         u64* copy = dc.cell_hist + (size_t)(blockIdx.x % HIST_COPIES) * (dc.n_cells + 1);
         for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) {
@@ -1818,8 +1818,13 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
             for (int q = 0; q < hist_plan->n_passes; ++q) dc.shift[q] = hist_plan->shift[q];
         }
     }
-    BP_DISPATCH_KIND(kind, (encode_emit_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                 block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
+    if (dc.cell_hist) {
+        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
+                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
+    } else {
+        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
+                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
+    }
     return hipGetLastError();
 }
 
