@@ -73,6 +73,60 @@ class ChaChaRng:
             scale = np.nextafter(scale, f(0.0), dtype=np.float32)
 
 
+def chacha20_words(key_words, n_words):
+    """the first n_words u32 outputs of the stream, all blocks at once (numpy): same words as ChaChaRng.next_u32"""
+    nb = (n_words + 15) // 16
+    ctr = np.arange(nb, dtype=np.uint64)
+    st = np.empty((16, nb), dtype=np.uint32)
+    for i, c in enumerate((0x61707865, 0x3320646E, 0x79622D32, 0x6B206574)):
+        st[i] = c
+    for i in range(8):
+        st[4 + i] = key_words[i]
+    st[12] = (ctr & np.uint64(M32)).astype(np.uint32)
+    st[13] = (ctr >> np.uint64(32)).astype(np.uint32)
+    st[14] = 0
+    st[15] = 0
+    x = st.copy()
+
+    def rotl(v, n):
+        return (v << np.uint32(n)) | (v >> np.uint32(32 - n))
+
+    def qr(a, b, c, d):
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        x += st
+    return x.T.reshape(-1)[:n_words]
+
+
+def gen_boxes_fast(count, seed=0, density=0.001, size_range=(1.0, 10.0), cbrt_ulps=0):
+    """gen_boxes, vectorised.  Valid when no draw is rejected (res < high for all; a rejection would shift the
+    stream) -- checked, with a fall-back to the scalar generator."""
+    f = np.float32
+    s0, s1 = f(size_range[0]), f(size_range[1])
+    avg = f(f(s0 + s1) / f(2.0))
+    lin = f(np.cbrt(f(f(count) / f(density))))
+    for _ in range(abs(cbrt_ulps)):
+        lin = np.nextafter(lin, f(np.inf if cbrt_ulps > 0 else -np.inf), dtype=np.float32)
+    linear = f(lin + avg)
+    key = struct.unpack("<8I", seed_from_u64(seed))
+    w = chacha20_words(key, 6 * count).reshape(count, 6)
+    v01 = (((w >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - f(1.0)).astype(np.float32)
+    size = (v01[:, :3] * f(s1 - s0) + s0).astype(np.float32)
+    scale = (linear - size).astype(np.float32)                       # high - low with low = 0
+    mn = (v01[:, 3:] * scale + f(0.0)).astype(np.float32)
+    if not (np.all(size < s1) and np.all(mn < scale)):               # a rejected draw: replay exactly
+        return gen_boxes(count, seed, density, size_range, cbrt_ulps)
+    mx = (mn + size).astype(np.float32)
+    sysb = np.array([[0, 0, 0], [linear, linear, linear]], dtype=np.float32)
+    return sysb, np.concatenate([mn, mx], axis=1).astype(np.float32), np.arange(count, dtype=np.uint32)
+
+
 def gen_boxes(count, seed=0, density=0.001, size_range=(1.0, 10.0), cbrt_ulps=0):
     f = np.float32
     s0, s1 = f(size_range[0]), f(size_range[1])

@@ -40,6 +40,15 @@ def test_generator_reproduces_the_reference_input_scenes(count):
     assert scene_io.Scene(system_bounds=sysb, bounds=bounds, ids=ids).assemble((1, 0)) == blob
 
 
+@pytest.mark.parametrize("count", [100, 300, 1000, 3000, 10000, 30000, 100000])
+def test_all_seven_reference_input_scenes_regenerate_to_their_lfs_hash(count):
+    # vectorised generator (all ChaCha20 blocks at once); the scalar one above is the cross-check
+    meta = OIDS["inputs"]["boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count]
+    sysb, bounds, ids = ref_scene_gen.gen_boxes_fast(count, cbrt_ulps=meta["cbrt_ulps"])
+    blob = ref_scene_gen.scene_v1_0_bytes(sysb, bounds, ids)
+    assert len(blob) == meta["size"] and sha(blob) == meta["sha256"]
+
+
 @pytest.mark.parametrize("count", [1000, 10000])
 def test_committed_input_fixtures_are_the_reference_files(count):
     meta = OIDS["inputs"]["boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count]
@@ -145,3 +154,21 @@ def test_reference_test_layer_rs_mirrored_on_the_hip_path(tmp_path):
         actual = np.array(getattr(lay, method)())
         assert is_sorted(actual, True), "Layer::%s() produced unsorted output" % method
         assert np.array_equal(actual, v2.collisions), "Layer::%s() produced unexpected results" % method
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [3000, 100000])
+def test_hip_path_equals_the_pinned_oracle_on_the_reference_input_scenes(count):
+    """the reference's other input scenes (no goldens exist for them): authenticated input, oracle pinned above"""
+    import broadphase_rs_amd as bp
+    meta = OIDS["inputs"]["boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count]
+    sysb, bounds, ids = ref_scene_gen.gen_boxes_fast(count, cbrt_ulps=meta["cbrt_ulps"])
+    assert sha(ref_scene_gen.scene_v1_0_bytes(sysb, bounds, ids)) == meta["sha256"]
+    gpu, ref = bp.Layer(bp.Index64_3D, 0), oracle.OracleLayer(oracle.INDEX64_3D, 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    k, i = gpu.tree()
+    assert np.array_equal(k, ref.keys) and np.array_equal(i, ref.ids)
+    gpu.par_sort(); ref.par_sort()
+    k, i = gpu.tree()
+    assert np.array_equal(k, ref.keys) and np.array_equal(i, ref.ids)
+    assert np.array_equal(np.array(gpu.par_scan()), ref.par_scan())
