@@ -212,7 +212,10 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,
-                              const uint32_t* owner_bounds = nullptr, int owner_n = -1);
+                              const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0);
+// gen (ids that may repeat; idctx from launch_entry_ctx with box == nullptr): 1 = MARK pass (sets the skipped bit of
+// every entry whose id an ancestor carries, src/layer.rs:563-565; emits nothing), 2 = EMIT pass (all combos of two
+// unskipped entries).  Run 1 then 2; the long-range counter in sc must be zero before each.
 // owner_bounds / owner_n (instead of hist_plan): count the pairs per owner rank of the first id into hist[0..255]
 // hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
 // hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)

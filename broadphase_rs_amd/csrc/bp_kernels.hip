@@ -1178,6 +1178,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 //   bit  28      entry takes no part as the deeper side (shard scans: coarse entry)
 //   bits 29..31  BoxCtx::two
 constexpr u32 CTX_INACTIVE = 1u << 28;
+// ids that may repeat (GEN modes below): the context carries no suppression data, bit 27 marks an entry the
+// reference's skip rule drops entirely (some ancestor carries the same id, src/layer.rs:563-565)
+constexpr u32 CTX_SKIPPED = 1u << 27;
 template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 code, u32 inactive_below) {
     BoxCtx<KIND> bx;
     bx.init(key, code);
@@ -1376,7 +1379,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #else
 #define SX_OCC_ATTR
 #endif
-template <int KIND, bool FILT, bool OWNER>
+// GEN = 0: ids distinct, duplicates suppressed at the source (the default).
+// GEN = 1: ids may repeat, MARK pass: every candidate whose id equals its ancestor's gets CTX_SKIPPED (nothing is emitted).
+// GEN = 2: ids may repeat, EMIT pass: every combo of two unskipped entries (the reference's raw stream as a set).
+template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
@@ -1400,6 +1406,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
             const u32 end = range_end(p.keys, m, j, cell_upper<KIND>(key));
             c = end - j - 1u;
+            if (GEN == 2 && ((u32)wj & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
             if (c >= SX_BIG) {
                 const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
                 const u32 at = atomicAdd(&p.sc->big_count, ns);
@@ -1433,7 +1440,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             const u32 left = total - ss;
             const u32 n_steps = left >= SUPER ? 64u : (left + 63u) >> 6;
             // software pipeline: the {id, context} load of step b + 1 is in flight while step b is tested and pushed
-            struct Cand { u64 wi; u32 idj, cbdd; bool act; };
+            struct Cand { u64 wi; u32 idj, cbdd, i; bool act; };
             auto fetch = [&](u32 b) -> Cand {
                 const u64 e = uniform_u64(s_ends[w][b]);
                 const u32 k = ss + b * 64u + (u32)lane;
@@ -1443,13 +1450,20 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 if (!act) ord = n_nz - 1u;
                 const uint4 r = s_rec[w][ord];
                 const u32 i = (u32)base + r.w + 1u + ((act ? k : total - 1u) - r.x);
-                return Cand{p.idctx[i], r.y, r.z, act};
+                return Cand{p.idctx[i], r.y, r.z, i, act};
             };
             Cand cur = fetch(0);
             for (u32 b = 0; b < n_steps; ++b) {
                 Cand nxt = cur;
                 if (b + 1 < n_steps) nxt = fetch(b + 1);
+                if (GEN == 1) {  // mark: candidate index i = position of the word just fetched
+                    if (cur.act && (u32)(cur.wi >> 32) == cur.idj && !((u32)cur.wi & CTX_SKIPPED))
+                        atomicOr(const_cast<u64*>(p.idctx) + cur.i, (u64)CTX_SKIPPED);
+                    cur = nxt;
+                    continue;
+                }
                 bool keep = cur.act && ctx_keep((u32)cur.wi, cur.cbdd & 63u, cur.cbdd >> 8);
+                if (GEN == 2) keep = keep && !((u32)cur.wi & CTX_SKIPPED);
                 if (FILT && keep)
                     keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)cur.idj * (2 * FDIM));
                 st.template push<OWNER>(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
@@ -1458,12 +1472,13 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (GEN == 1) return;
     st.finish(p);
     sx_hist_flush(s_hist, p);
 }
 
 // work-list slices of the long ranges: one slice per workgroup iteration
-template <int KIND, bool FILT, bool OWNER>
+template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
@@ -1494,13 +1509,19 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
             u64 wi = 0;
             if (i < last) {
                 wi = p.idctx[i];
+                if (GEN == 1) {
+                    if ((u32)(wi >> 32) == idj && !((u32)wi & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + i, (u64)CTX_SKIPPED);
+                    continue;
+                }
                 keep = ctx_keep((u32)wi, cb, dd);
+                if (GEN == 2) keep = keep && !((u32)wi & CTX_SKIPPED);
                 if (FILT && keep)
                     keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)idj * (2 * FDIM));
             }
-            st.template push<OWNER>(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
+            if (GEN != 1) st.template push<OWNER>(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
         }
     }
+    if (GEN == 1) return;
     st.finish(p);
     sx_hist_flush(s_hist, p);
 }
@@ -2121,17 +2142,19 @@ static unsigned resident_blocks(Kern kernel, int threads) {
     return (unsigned)(cus * per_cu);
 }
 
-template <int KIND, bool FILT, bool OWNER>
+template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
-    static const unsigned resident = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER>, SX_THREADS);
+    static const unsigned resident = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS);
     const unsigned grid = (unsigned)std::min<size_t>(max_grid, resident);
     p.n_waves = grid * SX_WAVES;
-    scan_expand_kernel<KIND, FILT, OWNER><<<grid, SX_THREADS, 0, stream>>>(p);
-    scan_expand_big_kernel<KIND, FILT, OWNER><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
+    scan_expand_kernel<KIND, FILT, OWNER, GEN><<<grid, SX_THREADS, 0, stream>>>(p);
+    scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
     return hipGetLastError();
 }
 template <int KIND>
-static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream) {
+static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream, int gen) {
+    if (gen == 1) return launch_scan_expand_variant<KIND, false, false, 1>(p, max_grid, stream);
+    if (gen == 2) return launch_scan_expand_variant<KIND, false, false, 2>(p, max_grid, stream);
     const bool owner = p.owner_n >= 0;  // the owner-counting variant is a separate instantiation: the default kernel pays nothing
     if (p.filt_bounds) return owner ? launch_scan_expand_variant<KIND, true, true>(p, max_grid, stream)
                                     : launch_scan_expand_variant<KIND, true, false>(p, max_grid, stream);
@@ -2141,7 +2164,8 @@ static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipSt
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
-                              const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n) {
+                              const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n,
+                              int gen) {
     if (m == 0) return hipSuccess;
     // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
@@ -2163,9 +2187,9 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
         for (int i = 0; i < owner_n; ++i) p.owner_bounds[i] = owner_bounds[i];
     }
     switch (kind) {
-        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream);
-        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream);
-        default: return launch_scan_expand_kind<2>(p, max_grid, stream);
+        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream, gen);
+        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream, gen);
+        default: return launch_scan_expand_kind<2>(p, max_grid, stream, gen);
     }
 }
 

@@ -936,6 +936,87 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     return fail(L, BP_ERR_KERNEL, "fused scan: output size did not converge");
 }
 
+// ids that may repeat: the reference's raw stream AS A SET (every combo of two entries the skip rule keeps,
+// src/layer.rs:563-570) from two expanding passes -- MARK the skipped entries, then EMIT -- instead of the three
+// ancestor walks of the literal path.  Block-structured output in pairs[0]; *done = 0 when the work list
+// overflowed (the caller falls back to the literal kernels).
+int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, int* done) {
+    *done = 0;
+    BP_TRY(sort_tree(L));
+    L->n_raw = 0;
+    L->raw_is_unique = false;
+    L->raw_holes = false;
+    L->pair_hist_valid = false;
+    L->owner_hist_valid = false;
+    if (L->m == 0) { *done = 1; return BP_OK; }
+    if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
+    const uint32_t thr = emit_coarse ? 0u : coarse_depth;
+    BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
+    L->ctx_epoch = 0;  // the words below carry skip marks, not suppression contexts
+    {
+        ProfScope ps(L, BP_K_SCAN_COUNT);
+        HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), nullptr, L->m, thr, (uint64_t*)L->idctx.p, L->stream));
+    }
+    size_t big_cap = std::max<size_t>(65536, L->m / 16);
+    if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));
+    L->big_cap = big_cap;
+    BP_TRY(ensure_dev(L, L->big_list, big_cap * sizeof(uint64_t)));
+    const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
+    BP_TRY(ensure_dev(L, L->shards, shard_bytes));
+    BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
+    size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
+    BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->blockfill, (L->pairs[0].cap / sizeof(uint64_t) / SX_BLOCK) * sizeof(uint32_t)));
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_SCAN_COUNT);
+        HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, (uint64_t*)L->pairs[0].p, 0,
+                                      (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, (uint64_t*)L->big_list.p,
+                                      (uint32_t)std::min<size_t>(big_cap, 0xFFFFFFFFu), (DevScalars*)L->d_sc.p, L->stream,
+                                      nullptr, nullptr, nullptr, -1, /*gen=*/1));
+    }
+    {
+        DevScalars sc;
+        BP_TRY(sc_fetch(L, &sc));
+        if (sc.err & KERR_BIGLIST_OVERFLOW) return BP_OK;  // literal path instead
+    }
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
+        cap = L->pairs[0].cap / sizeof(uint64_t);
+        const size_t out_blocks = cap / SX_BLOCK;
+        BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
+        BP_TRY(sc_reset(L));
+        HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
+        HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+        {
+            ProfScope ps(L, BP_K_SCAN_EMIT);
+            HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, (uint64_t*)L->pairs[0].p,
+                                          out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, (uint64_t*)L->big_list.p,
+                                          (uint32_t)std::min<size_t>(big_cap, 0xFFFFFFFFu), (DevScalars*)L->d_sc.p, L->stream,
+                                          nullptr, nullptr, nullptr, -1, /*gen=*/2));
+        }
+        HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
+        DevScalars sc;
+        BP_TRY(sc_fetch(L, &sc));
+        if (sc.err & KERR_BIGLIST_OVERFLOW) return BP_OK;
+        const uint64_t* sh = (const uint64_t*)L->h_shards.p;
+        uint64_t kmax = 0, total = 0;
+        for (int i = 0; i < SX_SHARDS; ++i) { kmax = std::max<uint64_t>(kmax, sh[i]); total += sh[SX_SHARDS + i]; }
+        const size_t extent_blocks = (size_t)kmax * SX_SHARDS;
+        if (extent_blocks <= out_blocks) {
+            L->n_raw = (size_t)total;
+            L->stats.raw_pairs = L->n_raw;
+            L->stats.raw_candidates = L->n_raw;  // no suppression in this mode: the raw stream is the reference's
+            L->raw_holes = true;
+            L->raw_extent = extent_blocks * SX_BLOCK;
+            *done = 1;
+            return BP_OK;
+        }
+        cap = extent_blocks * SX_BLOCK + extent_blocks * SX_BLOCK / 16;
+    }
+    return fail(L, BP_ERR_KERNEL, "general scan: output size did not converge");
+}
+
 // block-structured raw stream in pairs[0] -> dense (for consumers that cannot read around the holes)
 int make_raw_dense(bp_layer* L) {
     if (!L->raw_holes) return BP_OK;
@@ -966,6 +1047,16 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
+    }
+    static const bool no_expand = getenv("BP_NO_EXPAND_SCAN") != nullptr;
+    if (!L->ids_distinct && !no_fused && !no_expand) {  // ids may repeat: mark + emit expanding passes, then sort + dedup
+        int done = 0;
+        BP_TRY(scan_general_expand_device(L, coarse_depth, emit_coarse, &done));
+        if (done) {
+            BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, false, L->raw_holes));
+            if (L->n_raw == 0) BP_TRY(sync_stream(L));
+            return BP_OK;
+        }
     }
     BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse, !no_source_dedup));
     BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
