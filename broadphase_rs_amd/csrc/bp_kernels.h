@@ -279,6 +279,9 @@ constexpr int SEGP_CHUNK = SEGP_CHUNK_DEF, SEGP_HALO = SEGP_HALO_DEF;   // segme
 constexpr int SEGT_CHUNK = SEGT_CHUNK_DEF, SEGT_HALO = SEGT_HALO_DEF;   // tree_segment_finish
 constexpr int SEG_SLOW_MAX = 4096;  // longest group the finish kernels rank straight from HBM before giving up
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
+// same for pairs that may repeat: equal pairs keep their input order, the output stays packed u64 (sorted), ready
+// for unique_count / unique_emit.  sorted_out must not alias `in`.
+hipError_t launch_segment_finish_dups(const uint64_t* in, size_t n, uint64_t* sorted_out, DevScalars* sc, hipStream_t stream);
 
 // Finishing step of the tree sort after radix passes on the high key bits only: entries are grouped
 // by (key >> seg_shift); every group is rank-sorted by (key, id, input position) in an LDS window and

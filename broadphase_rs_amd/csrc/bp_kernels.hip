@@ -1571,6 +1571,10 @@ __global__ __launch_bounds__(UQ_THREADS) void unique_emit_kernel(const u64* __re
     }
 }
 
+// DUPS = false: the pairs are distinct; output in the ABI layout (id, id_).
+// DUPS = true: pairs may repeat (no suppression at the source): equal pairs are ordered by input position and the
+// output stays packed (id << 32 | id_), sorted, for the unique_count / unique_emit pass that follows.
+template <bool DUPS>
 __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* __restrict__ in, size_t n,
                                                                       uint2* __restrict__ out, DevScalars* sc) {
     constexpr int SEG_CHUNK = SEGP_CHUNK, SEG_HALO = SEGP_HALO;
@@ -1635,15 +1639,23 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* 
             const size_t ge = lo;
             if (ge - gs > (size_t)SEG_SLOW_MAX) { too_long = true; continue; }
             u32 rank = 0;
-            for (size_t y = gs; y < ge; ++y) rank += (u32)in[y] < vb ? 1u : 0u;
-            out[gs + rank] = make_uint2(fid, vb);
+            const size_t self = win_lo + x;
+            for (size_t y = gs; y < ge; ++y) {
+                const u32 vy = (u32)in[y];
+                rank += (vy < vb || (DUPS && vy == vb && y < self)) ? 1u : 0u;
+            }
+            if (DUPS) reinterpret_cast<u64*>(out)[gs + rank] = v; else out[gs + rank] = make_uint2(fid, vb);
             continue;
         }
         u32 rank = 0;
         const u32* s_lo = reinterpret_cast<const u32*>(s_win);  // low dword = second id (first ids are equal)
 #pragma unroll 4  // segments hold ~9 pairs: the compiler's 16-wide unrolling mostly runs its remainder loops
-        for (u32 y = start; y < end; ++y) rank += s_lo[2 * y] < vb ? 1u : 0u;  // independent LDS reads
-        out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
+        for (u32 y = start; y < end; ++y) {  // independent LDS reads
+            const u32 vy = s_lo[2 * y];
+            rank += (vy < vb || (DUPS && vy == vb && y < x)) ? 1u : 0u;
+        }
+        if (DUPS) reinterpret_cast<u64*>(out)[win_lo + start + rank] = v;
+        else out[win_lo + start + rank] = make_uint2((u32)(v >> 32), (u32)v);
     }
     if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
 }
@@ -2670,10 +2682,16 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
     return hipGetLastError();
 }
 
+hipError_t launch_segment_finish_dups(const uint64_t* in, size_t n, uint64_t* sorted_out, DevScalars* sc, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)((n + SEGP_CHUNK - 1) / SEGP_CHUNK);
+    segment_finish_kernel<true><<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)sorted_out, sc);
+    return hipGetLastError();
+}
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)((n + SEGP_CHUNK - 1) / SEGP_CHUNK);
-    segment_finish_kernel<<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
+    segment_finish_kernel<false><<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
     return hipGetLastError();
 }
 

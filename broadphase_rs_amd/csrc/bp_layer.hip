@@ -743,6 +743,63 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     return BP_OK;
 }
 
+// n packed pairs that MAY REPEAT in buf0: radix sort on the first id only, rank-sort the equal-first-id segments
+// in LDS (equal pairs by position), then the adjacent-unique pass -- 3 passes + finish instead of 6 passes.
+// *done = 0: not applicable / a segment was too long (the caller runs the full-width sort).
+int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes, int* done) {
+    *done = 0;
+    const RadixPlan plan = make_radix_plan(varying & 0xFFFFFFFF00000000ull, 0, 0);
+    if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return BP_OK;
+    L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
+    DevBuf& partner = (buf0 == (uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];
+    BP_TRY(ensure_dev(L, partner, n * sizeof(uint64_t)));
+    uint64_t* bufs[2] = {buf0, (uint64_t*)partner.p};
+    int res = 0;
+    BP_TRY(sc_reset(L));
+    {
+        const size_t extent = holes ? L->raw_extent : n;
+        BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
+        HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
+                              (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
+    }
+    uint64_t* sorted = bufs[res ^ 1];  // the finish writes into the other ping-pong buffer (both hold >= n)
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_segment_finish_dups(bufs[res], n, sorted, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    const size_t nb = uq_blocks(n);
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_unique_count(sorted, n, (unsigned long long*)L->block_sums.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, nullptr, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+    BP_TRY(sync_stream(L));
+    const DevScalars sc = *(DevScalars*)L->h_sc.p;
+    if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+    if (sc.err & KERR_SEGMENT_TOO_LONG) {  // some id owns a very long segment: sort all 64 bits instead, from the grouped data
+        int rc = sort_unique_pairs_in(L, bufs[res], n, varying, false, false);
+        if (rc == BP_OK) *done = 1;
+        return rc;
+    }
+    const size_t np = (size_t)sc.total;
+    BP_TRY(ensure_dev(L, L->out_pairs, np * 2 * sizeof(uint32_t)));
+    {
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_unique_emit(sorted, n, (const unsigned long long*)L->block_sums.p, (uint32_t*)L->out_pairs.p, L->stream));
+    }
+    BP_TRY(sync_stream(L));
+    L->n_pairs = np;
+    L->stats.pairs = np;
+    *done = 1;
+    return BP_OK;
+}
+
 int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool assume_unique, bool holes) {
     L->n_pairs = 0;
     L->stats.pairs = 0;
@@ -810,6 +867,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false, bool holes = false) {
     const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
     if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes);
+    int done = 0;
+    BP_TRY(sort_dups_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, &done));
+    if (done) return BP_OK;
     return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, false, holes);
 }
 
@@ -988,12 +1048,21 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
         BP_TRY(sc_reset(L));
         HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
         HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+        // the sort that follows groups by first id first (sort_dups_pairs_in): count those digits while emitting
+        const uint32_t idv = L->id_or ^ L->id_and;
+        const RadixPlan hplan = make_radix_plan(((unsigned long long)idv << 32), 0, 0);
+        const bool count_digits = segment_finish_enabled() && hplan.n_passes > 0 && hplan.n_passes <= SX_HIST_MAX;
+        if (count_digits) {
+            BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+            HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+        }
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
             HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, (uint64_t*)L->pairs[0].p,
                                           out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, (uint64_t*)L->big_list.p,
                                           (uint32_t)std::min<size_t>(big_cap, 0xFFFFFFFFu), (DevScalars*)L->d_sc.p, L->stream,
-                                          nullptr, nullptr, nullptr, -1, /*gen=*/2));
+                                          count_digits ? &hplan : nullptr, count_digits ? (unsigned long long*)L->pair_hist.p : nullptr,
+                                          nullptr, -1, /*gen=*/2));
         }
         HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
         DevScalars sc;
@@ -1007,6 +1076,7 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
             L->n_raw = (size_t)total;
             L->stats.raw_pairs = L->n_raw;
             L->stats.raw_candidates = L->n_raw;  // no suppression in this mode: the raw stream is the reference's
+            if (count_digits) { L->pair_hist_plan = hplan; L->pair_hist_valid = true; }
             L->raw_holes = true;
             L->raw_extent = extent_blocks * SX_BLOCK;
             *done = 1;
