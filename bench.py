@@ -285,6 +285,11 @@ def main():
                                  frac_of_peak=survey_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  note="SURVEY.md 8(d) byte model of a literal 8-digit LSD pipeline on the same N/M/P; the step "
                                       "beats it by moving fewer bytes, not by exceeding HBM bandwidth (see step_model)"),
+            # SURVEY 8(d) also asks for objects/s and for the sort+scan part alone (tree sort through dedup)
+            "objects_per_s": n_global / (dt / args.steps),
+            "sort_scan": {"ms_per_step": sum(per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist",
+                                                                      "pair_sort", "dedup")),
+                          "note": "kernel time of tree sort + scan + pair sort + dedup in the per-class steps (see kernels_note)"},
             "kernels": kernels,
             "kernel_ms_per_step": per_step_ms,
             "kernels_note": "per-class times from %d extra steps after the timed region with every class bracketed by HIP "
