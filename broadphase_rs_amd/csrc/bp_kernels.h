@@ -158,6 +158,7 @@ hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint
 constexpr int SCAN_THREADS = 256;
 inline size_t scan_blocks(size_t m) { return (m + SCAN_THREADS - 1) / SCAN_THREADS; }
 
+enum : int { FILT_AABB = 0, FILT_SPHERE = 1 };  // shape of the built-in narrow-phase rows
 struct ScanParams {
     const unsigned long long* keys;
     const uint32_t* ids;
@@ -172,6 +173,7 @@ struct ScanParams {
                             // deeper object that lies in any cell of the other (exact dedup at source)
     const float* filt_bounds;  // built-in narrow-phase predicate (fused scan only): rows of 2*dim f32 indexed BY ID,
     uint32_t filt_rows;        // keep (id, id_) iff the inclusive boxes overlap (src/geom.rs:112-119); nullptr: keep all
+    int filt_shape;            // FILT_AABB, or FILT_SPHERE: rows of dim+1 f32 (centre, radius), examples/main.rs:466-474
 };
 hipError_t launch_scan_skipflags(int kind, ScanParams p, hipStream_t stream);
 hipError_t launch_scan_count(int kind, ScanParams p, uint32_t* counts, unsigned long long* block_sums,
@@ -181,7 +183,7 @@ hipError_t launch_scan_emit(int kind, ScanParams p, const uint32_t* counts, cons
 
 // keep the packed pairs whose boxes (rows of `bounds` indexed by id) overlap; arbitrary output order;
 // sc->total (zeroed by the host) = number kept
-hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, uint64_t* out, DevScalars* sc,
+hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, int shape, uint64_t* out, DevScalars* sc,
                                     hipStream_t stream);
 
 // single-pass scan for the paths that sort the raw stream afterwards: pairs in arbitrary order,
@@ -208,7 +210,7 @@ constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
-hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
+hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds, int filt_shape,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,

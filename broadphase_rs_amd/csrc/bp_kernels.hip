@@ -1085,6 +1085,23 @@ template <int DIM> __device__ __forceinline__ bool boxes_overlap(const float* __
     }
     return ov;
 }
+// The example's sphere narrow phase (examples/main.rs:466-474): rows are (centre, radius);
+// `dist > r0 + r1` rejects, so NaN keeps.  dist = sqrt(x*x + y*y [+ z*z]) summed left to right
+// (cgmath ^0.17 InnerSpace::magnitude, a dependency that is not in the tree), no contraction.
+template <int DIM> __device__ __forceinline__ bool spheres_touch(const float* __restrict__ a, const float* __restrict__ b) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int ax = 0; ax < DIM; ++ax) {
+        const float o = b[ax] - a[ax];
+        d2 = ax == 0 ? o * o : d2 + o * o;
+    }
+    return !(__fsqrt_rn(d2) > a[DIM] + b[DIM]);
+}
+// one narrow-phase row per id: FILT_AABB rows of 2*DIM floats, FILT_SPHERE rows of DIM+1
+template <int DIM> __device__ __forceinline__ u32 filt_stride(int shape) { return shape == FILT_SPHERE ? DIM + 1 : 2 * DIM; }
+template <int DIM> __device__ __forceinline__ bool narrow_keep(const float* __restrict__ a, const float* __restrict__ b, int shape) {
+    return shape == FILT_SPHERE ? spheres_touch<DIM>(a, b) : boxes_overlap<DIM>(a, b);
+}
 
 template <int KIND, bool FILT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, u64* __restrict__ out, u64 out_cap,
@@ -1110,9 +1127,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
         }
     }
     float mybox[2 * FDIM];
+    const u32 fstride = FILT ? filt_stride<FDIM>(p.filt_shape) : 0;
     if (FILT && active) {
 #pragma unroll
-        for (int q = 0; q < 2 * FDIM; ++q) mybox[q] = p.filt_bounds[(size_t)(u32)(hi_id >> 32) * (2 * FDIM) + q];
+        for (int q = 0; q < 2 * FDIM; ++q)
+            if ((u32)q < fstride) mybox[q] = p.filt_bounds[(size_t)(u32)(hi_id >> 32) * fstride + q];
     }
     u32 mine = 0;
     if (active) {
@@ -1121,7 +1140,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
             for_run_desc(lo, hi, [&](u32 j) {
                 const u32 idj = p.ids[j];
                 if (bx.earlier != 0 && bx.suppressed(cr, p.box[j])) return;
-                if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
+                if (FILT && !narrow_keep<FDIM>(mybox, p.filt_bounds + (size_t)idj * fstride, p.filt_shape)) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
                 if (slot < FUSED_STAGE) s_pairs[slot] = hi_id | (u64)idj;
                 ++mine;
@@ -1147,7 +1166,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
             for_run_desc(lo, hi, [&](u32 j) {
                 if (bx.earlier != 0 && bx.suppressed(cr, p.box[j])) return;
                 const u32 idj = p.ids[j];
-                if (FILT && !boxes_overlap<FDIM>(mybox, p.filt_bounds + (size_t)idj * (2 * FDIM))) return;
+                if (FILT && !narrow_keep<FDIM>(mybox, p.filt_bounds + (size_t)idj * fstride, p.filt_shape)) return;
                 const u32 slot = atomicAdd(&s_cursor, 1u);
                 out[base + slot] = hi_id | (u64)idj;
             });
@@ -1233,6 +1252,7 @@ struct ExpandParams {
     u32 big_cap;
     u32 n_waves;       // waves of the main kernel's grid (chunk stride)
     const float* filt_bounds;
+    int filt_shape;
     // digit histograms of the emitted pairs for the sort that follows (saves its separate read of the
     // stream): hist_passes <= SX_HIST_MAX rows of 256 u64 counters (zeroed by the host), row q counts
     // digit (pair >> hist_shift[q]) & 255
@@ -1465,7 +1485,8 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 bool keep = cur.act && ctx_keep((u32)cur.wi, cur.cbdd & 63u, cur.cbdd >> 8);
                 if (GEN == 2) keep = keep && !((u32)cur.wi & CTX_SKIPPED);
                 if (FILT && keep)
-                    keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)cur.idj * (2 * FDIM));
+                    keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * filt_stride<FDIM>(p.filt_shape),
+                                             p.filt_bounds + (size_t)cur.idj * filt_stride<FDIM>(p.filt_shape), p.filt_shape);
                 st.template push<OWNER>(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
                 cur = nxt;
             }
@@ -1516,7 +1537,8 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
                 keep = ctx_keep((u32)wi, cb, dd);
                 if (GEN == 2) keep = keep && !((u32)wi & CTX_SKIPPED);
                 if (FILT && keep)
-                    keep = boxes_overlap<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * (2 * FDIM), p.filt_bounds + (size_t)idj * (2 * FDIM));
+                    keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * filt_stride<FDIM>(p.filt_shape),
+                                             p.filt_bounds + (size_t)idj * filt_stride<FDIM>(p.filt_shape), p.filt_shape);
             }
             if (GEN != 1) st.template push<OWNER>(keep, (wi & 0xFFFFFFFF00000000ull) | (u64)idj, p);
         }
@@ -1758,7 +1780,7 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
 }
 
 template <int DIM>
-__global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds,
+__global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds, int shape,
                                                                 u64* __restrict__ out, DevScalars* sc) {
     constexpr int ITEMS = 4;
     __shared__ u64 s_keep[256 * ITEMS];
@@ -1772,9 +1794,9 @@ __global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __res
         const size_t i = base + (size_t)k * 256 + threadIdx.x;
         if (i < n) {
             const u64 v = in[i];
-            const float* a = bounds + (size_t)(u32)(v >> 32) * (2 * DIM);
-            const float* b = bounds + (size_t)(u32)v * (2 * DIM);
-            if (boxes_overlap<DIM>(a, b)) s_keep[atomicAdd(&s_cursor, 1u)] = v;
+            const float* a = bounds + (size_t)(u32)(v >> 32) * filt_stride<DIM>(shape);
+            const float* b = bounds + (size_t)(u32)v * filt_stride<DIM>(shape);
+            if (narrow_keep<DIM>(a, b, shape)) s_keep[atomicAdd(&s_cursor, 1u)] = v;
         }
     }
     __syncthreads();
@@ -2173,7 +2195,7 @@ static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipSt
     return owner ? launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream)
                  : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
 }
-hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds,
+hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds, int filt_shape,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n,
@@ -2185,7 +2207,7 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
-    p.n_waves = 0; p.filt_bounds = filt_bounds;
+    p.n_waves = 0; p.filt_bounds = filt_bounds; p.filt_shape = filt_shape;
     p.hist = (u64*)hist; p.hist_passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
@@ -2625,7 +2647,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
-    p.n_waves = 0; p.filt_bounds = nullptr; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {
@@ -2709,12 +2731,12 @@ hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* i
     return hipGetLastError();
 }
 
-hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, uint64_t* out, DevScalars* sc,
+hipError_t launch_filter_pairs_aabb(int dim, const uint64_t* in, size_t n, const float* bounds, int shape, uint64_t* out, DevScalars* sc,
                                     hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)((n + 1023) / 1024);
-    if (dim == 3) filter_pairs_aabb_kernel<3><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, (u64*)out, sc);
-    else filter_pairs_aabb_kernel<2><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, (u64*)out, sc);
+    if (dim == 3) filter_pairs_aabb_kernel<3><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, shape, (u64*)out, sc);
+    else filter_pairs_aabb_kernel<2><<<g, 256, 0, stream>>>((const u64*)in, n, bounds, shape, (u64*)out, sc);
     return hipGetLastError();
 }
 

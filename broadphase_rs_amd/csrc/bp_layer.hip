@@ -104,6 +104,7 @@ struct bp_layer {
 
     bp_stats stats{};
     bool prof_on = false;
+    int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
@@ -647,6 +648,7 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
     p.skip = nullptr;
     p.filt_bounds = nullptr;
     p.filt_rows = 0;
+    p.filt_shape = FILT_AABB;
     p.box = (source_dedup && !p.general && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
     if (p.general) {
@@ -901,6 +903,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.skip = nullptr;
     p.filt_bounds = filt_bounds;
     p.filt_rows = filt_rows;
+    p.filt_shape = L->filt_shape;
     p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = p.box != nullptr && L->box_all_known;
     static const bool no_expand = getenv("BP_NO_EXPAND_SCAN") != nullptr;  // A/B switch for measurements
@@ -942,7 +945,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             }
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
-                HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds,
+                HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds, L->filt_shape,
                                               (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p,
                                               (uint64_t*)L->big_list.p,
                                               (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
@@ -1030,7 +1033,7 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
     BP_TRY(sc_reset(L));
     {
         ProfScope ps(L, BP_K_SCAN_COUNT);
-        HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, (uint64_t*)L->pairs[0].p, 0,
+        HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, FILT_AABB, (uint64_t*)L->pairs[0].p, 0,
                                       (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, (uint64_t*)L->big_list.p,
                                       (uint32_t)std::min<size_t>(big_cap, 0xFFFFFFFFu), (DevScalars*)L->d_sc.p, L->stream,
                                       nullptr, nullptr, nullptr, -1, /*gen=*/1));
@@ -1058,7 +1061,7 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
         }
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
-            HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, (uint64_t*)L->pairs[0].p,
+            HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, nullptr, FILT_AABB, (uint64_t*)L->pairs[0].p,
                                           out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p, (uint64_t*)L->big_list.p,
                                           (uint32_t)std::min<size_t>(big_cap, 0xFFFFFFFFu), (DevScalars*)L->d_sc.p, L->stream,
                                           count_digits ? &hplan : nullptr, count_digits ? (unsigned long long*)L->pair_hist.p : nullptr,
@@ -1438,15 +1441,12 @@ int bp_layer_par_scan_filtered(bp_layer_t* L, bp_filter_fn filter, void* user, c
     return bp_layer_scan_filtered(L, filter, user, pairs, n_pairs);
 }
 
-// scan_filtered with the built-in AABB narrow-phase predicate; result in L->out_pairs
-static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_rows) {
-    if (!bounds) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: null bounds");
-    if (L->m && (!L->have_ids || L->max_id == 0xFFFFFFFFu || (size_t)L->max_id >= n_rows))
-        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: bounds need one row per id (ids must be bounded by n_rows)");
+// scan_filtered with a built-in narrow-phase predicate over per-id rows (boxes or spheres); result in L->out_pairs
+static int scan_filtered_rows(bp_layer* L, const float* bounds, size_t n_rows, int shape) {
     const KindInfo ki = kind_info(L->kind);
     const float* d_bounds = bounds;
     if (!is_device_ptr(bounds)) {
-        const size_t bytes = n_rows * 2 * ki.dim * sizeof(float);
+        const size_t bytes = n_rows * (shape == FILT_SPHERE ? ki.dim + 1 : 2 * ki.dim) * sizeof(float);
         BP_TRY(ensure_dev(L, L->in_bounds, bytes));
         HIP_TRY(L, hipMemcpyAsync(L->in_bounds.p, bounds, bytes, hipMemcpyHostToDevice, L->stream));
         d_bounds = (const float*)L->in_bounds.p;
@@ -1469,7 +1469,7 @@ static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_ro
         BP_TRY(sc_reset(L));
         {
             ProfScope ps(L, BP_K_MISC);
-            HIP_TRY(L, launch_filter_pairs_aabb((int)ki.dim, (const uint64_t*)L->pairs[0].p, n, d_bounds, (uint64_t*)L->pairs[1].p,
+            HIP_TRY(L, launch_filter_pairs_aabb((int)ki.dim, (const uint64_t*)L->pairs[0].p, n, d_bounds, shape, (uint64_t*)L->pairs[1].p,
                                                 (DevScalars*)L->d_sc.p, L->stream));
         }
         DevScalars sc;
@@ -1480,6 +1480,15 @@ static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_ro
     BP_TRY(sort_unique_pairs_in(L, (uint64_t*)L->pairs[1].p, kept, (((unsigned long long)(L->id_or ^ L->id_and)) << 32) | (L->id_or ^ L->id_and), false));
     if (kept == 0) BP_TRY(sync_stream(L));
     return BP_OK;
+}
+static int scan_filtered_aabb_impl(bp_layer* L, const float* bounds, size_t n_rows, int shape = FILT_AABB) {
+    if (!bounds) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb/sphere: null rows");
+    if (L->m && (!L->have_ids || L->max_id == 0xFFFFFFFFu || (size_t)L->max_id >= n_rows))
+        return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb/sphere: need one row per id (ids must be bounded by n_rows)");
+    L->filt_shape = shape;
+    const int rc = scan_filtered_rows(L, bounds, n_rows, shape);
+    L->filt_shape = FILT_AABB;
+    return rc;
 }
 
 int bp_layer_scan_filtered_aabb_device(bp_layer_t* L, const float* bounds_by_id, size_t n_rows, const uint32_t** d_pairs, size_t* n_pairs) {
@@ -1495,6 +1504,22 @@ int bp_layer_scan_filtered_aabb(bp_layer_t* L, const float* bounds_by_id, size_t
     if (!L || !pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_aabb: null argument");
     DeviceGuard g(L->device);
     BP_TRY(scan_filtered_aabb_impl(L, bounds_by_id, n_rows));
+    return pairs_to_host(L, pairs, n_pairs);
+}
+
+int bp_layer_scan_filtered_sphere_device(bp_layer_t* L, const float* spheres_by_id, size_t n_rows, const uint32_t** d_pairs, size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_sphere: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_filtered_aabb_impl(L, spheres_by_id, n_rows, FILT_SPHERE));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_scan_filtered_sphere(bp_layer_t* L, const float* spheres_by_id, size_t n_rows, const uint32_t** pairs, size_t* n_pairs) {
+    if (!L || !pairs || !n_pairs) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_scan_filtered_sphere: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_filtered_aabb_impl(L, spheres_by_id, n_rows, FILT_SPHERE));
     return pairs_to_host(L, pairs, n_pairs);
 }
 

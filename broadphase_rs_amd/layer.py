@@ -81,6 +81,7 @@ EXPORTS = [
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
+    "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device",
     "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
 ]
 
@@ -183,6 +184,8 @@ def load_library():
     L.bp_layer_commit_entries.argtypes = [vp, C.c_size_t, C.POINTER(_Facts)]
     L.bp_layer_scan_filtered_aabb.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_scan_filtered_aabb_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
+    L.bp_layer_scan_filtered_sphere.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
+    L.bp_layer_scan_filtered_sphere_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), szp]
     L.bp_layer_partition_pairs_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_uint32, u64p, C.POINTER(vp)]
     L.bp_layer_scan_shard_partition_device.argtypes = [vp, C.c_uint32, C.c_int, u32p, C.c_uint32, u64p, C.POINTER(vp),
                                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
@@ -377,13 +380,13 @@ class Layer:
     def par_scan_filtered(self, filt):  # src/layer.rs:493-520
         return self._filtered("bp_layer_par_scan_filtered", filt)
 
-    def _bounds_arg(self, bounds_by_id):
-        dim = self.index.dim
+    def _bounds_arg(self, bounds_by_id, width=None):
+        width = width or 2 * self.index.dim
         if _is_device_tensor(bounds_by_id):
             if bounds_by_id.element_size() != 4 or not bounds_by_id.is_contiguous():
                 raise ValueError("bounds must be contiguous f32")
-            return bounds_by_id.data_ptr(), int(bounds_by_id.numel()) // (2 * dim), bounds_by_id
-        b = np.ascontiguousarray(np.asarray(bounds_by_id, dtype=np.float32).reshape(-1, 2 * dim))
+            return bounds_by_id.data_ptr(), int(bounds_by_id.numel()) // width, bounds_by_id
+        b = np.ascontiguousarray(np.asarray(bounds_by_id, dtype=np.float32).reshape(-1, width))
         return b.ctypes.data, len(b), b
 
     def scan_filtered_aabb(self, bounds_by_id):
@@ -397,6 +400,20 @@ class Layer:
         ptr, rows, keep = self._bounds_arg(bounds_by_id)
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._L.bp_layer_scan_filtered_aabb_device(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self)
+
+    def scan_filtered_sphere(self, spheres_by_id):
+        """scan_filtered with the example's sphere test (examples/main.rs:459-474) on the device;
+        rows (centre..., radius) indexed by id"""
+        ptr, rows, keep = self._bounds_arg(spheres_by_id, self.index.dim + 1)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_filtered_sphere(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
+        return self._host_pairs(p, n)
+
+    def scan_filtered_sphere_device(self, spheres_by_id):
+        ptr, rows, keep = self._bounds_arg(spheres_by_id, self.index.dim + 1)
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_scan_filtered_sphere_device(self._h, C.c_void_p(ptr), rows, C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self)
 
     # ---- batched region queries (src/layer.rs:294-313 for many boxes at once) -----------------------

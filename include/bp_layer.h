@@ -113,6 +113,13 @@ int bp_layer_scan_filtered_aabb(bp_layer_t *layer, const float *bounds_by_id, si
                                 size_t *n_pairs);
 int bp_layer_scan_filtered_aabb_device(bp_layer_t *layer, const float *bounds_by_id, size_t n_rows,
                                        const uint32_t **d_pairs, size_t *n_pairs);
+/* the same with the example's own narrow phase (examples/main.rs:459-474): spheres_by_id = n_rows rows
+ * of dim+1 f32 (centre, radius); a pair is kept unless |c1 - c0| > r0 + r1, with the magnitude
+ * computed as the example does in f32 (sqrt of the left-to-right sum of squares); NaN keeps. */
+int bp_layer_scan_filtered_sphere(bp_layer_t *layer, const float *spheres_by_id, size_t n_rows, const uint32_t **pairs,
+                                  size_t *n_pairs);
+int bp_layer_scan_filtered_sphere_device(bp_layer_t *layer, const float *spheres_by_id, size_t n_rows,
+                                         const uint32_t **d_pairs, size_t *n_pairs);
 
 /* Raw output of scan_impl (src/layer.rs:550-573) before sort+dedup, in emission order; used by
  * parity tests and by scan_filtered.  Host-visible, interleaved (id, id_). */

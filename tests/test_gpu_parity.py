@@ -372,6 +372,47 @@ def test_builtin_aabb_predicate_equals_host_filter(kind, n):
         gpu.scan_filtered_aabb(bounds[: n // 2])          # not one row per id
 
 
+def _spheres_touch(sph, pairs, dim):
+    """the example's narrow phase (examples/main.rs:466-474) in f32, operation for operation"""
+    a, b = sph[pairs[:, 0]], sph[pairs[:, 1]]
+    d2 = None
+    for ax in range(dim):
+        o = (b[:, ax] - a[:, ax]).astype(np.float32)
+        d2 = o * o if d2 is None else (d2 + o * o).astype(np.float32)
+    return ~(np.sqrt(d2, dtype=np.float32) > (a[:, dim] + b[:, dim]).astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,n", [(2, 50000), (1, 30000), (0, 20000)])
+def test_builtin_sphere_predicate_equals_host_filter(kind, n):
+    """scan_filtered with the example's sphere test on the device == filtering the reference list"""
+    sysb, bounds, ids = make_scene(kind, n, seed=19)
+    dim = KINDS[kind].dim
+    # the example's objects: a ball and its bounding box (examples/main.rs:412-418)
+    centre = ((bounds[:, :dim] + bounds[:, dim:]) * np.float32(0.5)).astype(np.float32)
+    radius = ((bounds[:, dim:] - bounds[:, :dim]).max(axis=1) * np.float32(0.5)).astype(np.float32)
+    sph = np.ascontiguousarray(np.concatenate([centre, radius[:, None]], axis=1), dtype=np.float32)
+    sph[5, 0] = np.nan                                          # `dist > dist_min` is false for NaN: kept
+    gpu, ref = both(kind, 4 if kind == 0 else 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    full = ref.scan()
+    exp = full[_spheres_touch(sph, full, dim)]
+    assert 0 < len(exp) < len(full) // 2
+    assert_pairs_equal(gpu.scan_filtered_sphere(sph), exp, "device sphere predicate (expanding scan)")
+    assert_pairs_equal(gpu.scan_filtered_sphere_device(sph).to_numpy(), exp, "device sphere predicate (device result)")
+    # the closure form through the reference-shaped host filter gives the same list
+    keep = {(int(a), int(b)) for a, b in exp}
+    if n <= 20000:
+        assert_pairs_equal(np.array(gpu.scan_filtered(lambda a, b: (a, b) in keep)), exp, "host closure")
+    # literal path (ids not provably distinct)
+    perm = np.random.default_rng(4).permutation(n)
+    gpu2, ref2 = both(kind, 4 if kind == 0 else 0)
+    gpu2.extend(sysb, bounds[perm], ids[perm]); ref2.extend(sysb, bounds[perm], ids[perm])
+    full2 = ref2.scan()
+    assert_pairs_equal(gpu2.scan_filtered_sphere(sph), full2[_spheres_touch(sph, full2, dim)], "device sphere predicate (literal path)")
+    with pytest.raises(bp.BroadphaseError):
+        gpu.scan_filtered_sphere(sph[: n // 2])
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list
@@ -501,6 +542,10 @@ def test_long_ranges_go_through_the_work_list_and_its_overflow_falls_back(monkey
         st = gpu.stats()
         assert st["raw_pairs"] == len(exp)
         assert (st["raw_candidates"] > 0) == (cap is None)       # the fallback kernel does not count candidates
+        # both kernels (and the work-list slices of the big boxes) evaluate the sphere predicate identically
+        sph = np.concatenate([(bounds[:, :3] + bounds[:, 3:]) * np.float32(0.5),
+                              (bounds[:, 3:] - bounds[:, :3]).max(axis=1, keepdims=True) * np.float32(0.5)], axis=1).astype(np.float32)
+        assert_pairs_equal(gpu.scan_filtered_sphere(sph), exp[_spheres_touch(sph, exp, 3)], "sphere predicate, capacity %s" % cap)
 
 
 @pytest.mark.parametrize("kind", [2, 0])
