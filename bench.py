@@ -289,7 +289,17 @@ def main():
             "objects_per_s": n_global / (dt / args.steps),
             "sort_scan": {"ms_per_step": sum(per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist",
                                                                       "pair_sort", "dedup")),
-                          "note": "kernel time of tree sort + scan + pair sort + dedup in the per-class steps (see kernels_note)"},
+                          "pairs_per_s": n_pairs / max(1e-12, 1e-3 * sum(per_step_ms[k] for k in (
+                              "tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist", "pair_sort", "dedup"))),
+                          # north_star's target: >= 50 % of the HBM roofline on sort+scan, where SURVEY 8(d) defines
+                          # B_sort+scan = B_treesort + B_scan (tree sort and scan proper, before the pair sort)
+                          "tree_sort_and_scan_ms": sum(per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit")),
+                          "survey_B_sort_scan": survey["B_treesort"] + survey["B_scan"],
+                          "survey_frac_of_peak": (survey["B_treesort"] + survey["B_scan"]) / max(1e-12, 1e-3 * sum(
+                              per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit"))) / 1e9 / HBM_PEAK_GBS,
+                          "note": "kernel time of tree sort + scan + pair sort + dedup in the per-class steps (see kernels_note); "
+                                  "survey_frac_of_peak prices SURVEY's model bytes, which this pipeline does not all move "
+                                  "(see step_model for the bytes it does)"},
             "kernels": kernels,
             "kernel_ms_per_step": per_step_ms,
             "kernels_note": "per-class times from %d extra steps after the timed region with every class bracketed by HIP "
