@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--cpu-objects", type=int, default=10_000_000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
+    ap.add_argument("--pair-order", choices=["global", "local"], default="global",
+                    help="VARIANT: 'local' leaves every rank's pairs where they were found (set-equal, not the sorted partition)")
     ap.add_argument("--aabb-filter", action="store_true",
                     help="variant (not the headline metric): par_scan_filtered with the built-in device AABB narrow phase")
     return ap.parse_args()
@@ -151,7 +153,7 @@ def main():
         engine = layer
     else:
         from broadphase_rs_amd import dist as bpd
-        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global)
+        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
 
         def step():
             sharded.clear()
@@ -259,7 +261,8 @@ def main():
                   "B_pairsort": (8.0 + 16.0 * 8) * P_lit, "B_dedup": 8.0 * P_lit + 8.0 * P}
         survey_total = sum(survey.values())
         line = {
-            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if not args.aabb_filter else
+            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if not (args.aabb_filter or args.pair_order != "global") else
+                      "VARIANT (not the headline metric): pairs left on the rank that found them (set-equal, unsorted across ranks)" if not args.aabb_filter else
                       "VARIANT (not the headline metric): box-overlapping pairs/sec with the device AABB narrow phase fused into the scan",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

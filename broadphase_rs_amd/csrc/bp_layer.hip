@@ -1923,6 +1923,17 @@ int bp_layer_scan_shard_pairs_device(bp_layer_t* L, uint32_t coarse_depth, int e
     return BP_OK;
 }
 
+int bp_layer_par_scan_shard_device(bp_layer_t* L, uint32_t coarse_depth, int emit_coarse, const uint32_t** d_pairs, size_t* n_pairs,
+                                   int* unique) {
+    if (!L || !d_pairs || !n_pairs || !unique) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_par_scan_shard: null argument");
+    DeviceGuard g(L->device);
+    BP_TRY(scan_device(L, coarse_depth, emit_coarse));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    *unique = L->raw_is_unique ? 1 : 0;
+    return BP_OK;
+}
+
 int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask, const uint32_t** d_pairs,
                                 size_t* n_pairs) {
     if (!L || !d_pairs || !n_pairs || (n && !d_packed)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_packed: null argument");

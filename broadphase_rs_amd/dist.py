@@ -112,6 +112,9 @@ class HipBackend:
         raw, unique = self.shard.scan_shard_pairs_device(coarse_depth, emit_coarse)
         return raw.as_torch(), unique
 
+    def shard_par_scan(self, coarse_depth, emit_coarse):
+        return self.shard.par_scan_shard_device(coarse_depth, emit_coarse)
+
     def partition_pairs(self, packed, bounds):
         counts, out = self.shard.partition_pairs_device(packed.data_ptr(), int(packed.numel()), bounds)
         return counts, out.as_torch()
@@ -272,9 +275,17 @@ class ShardedLayer:
     rank's slice (a contiguous first-id range) of the global sorted, duplicate-free pair list."""
 
     def __init__(self, index=Index64_3D, min_depth=0, device=0, n_global=None, split_depth=None, group=None,
-                 backend=None, comm=None):
+                 backend=None, comm=None, pair_order="global"):
         import torch
         self.torch = torch
+        # "global": rank r returns the r-th first-id range of the reference's sorted list (concatenation in rank
+        # order == Layer::par_scan, bit for bit).  "local": every rank returns, sorted and duplicate-free, the
+        # pairs found in its own Morton range -- the ranks' lists are disjoint and their union is the reference's
+        # set, but no pair crosses the wire.  Only possible while every rank suppresses duplicates at the source
+        # (box codes known everywhere); otherwise the call silently takes the "global" route.
+        if pair_order not in ("global", "local"):
+            raise ValueError("pair_order must be 'global' or 'local'")
+        self.pair_order = pair_order
         self.comm = comm if comm is not None else TorchComm(group)
         self.rank, self.world = self.comm.rank, self.comm.world
         self.index = index
@@ -375,6 +386,17 @@ class ShardedLayer:
         else:
             max_id = max(comm.all_reduce_max(self.max_id_local, be), 0)
         bounds = id_range_bounds(max_id, G)
+        if self.pair_order == "local" and pack and all_known and hasattr(be, "shard_par_scan"):
+            # every rank knows all its box codes, so every pair is emitted exactly once, on one rank
+            out, unique = be.shard_par_scan(d_s, self.rank == 0)
+            lap("sort_scan_sort_pairs")
+            if bool(np.all(comm.all_gather_counts([0 if unique else 1], be)[:, 0] == 0)):
+                self.last = {"entries_local": int(counts.sum()), "entries_shard": n_recv + n_coarse, "coarse": n_coarse,
+                             "raw_pairs": len(out), "raw_pairs_recv": 0, "pairs": len(out), "id_range": (0, max_id),
+                             "box_codes": True, "unique_at_source": True, "pair_order": "local",
+                             "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+                return out
+            # a shard could not vouch for uniqueness after all: take the exchange route (re-scans)
         if hasattr(be, "shard_scan_partition"):
             pcounts, grouped, unique = be.shard_scan_partition(d_s, self.rank == 0, bounds)
             lap("sort_scan_partition")
@@ -402,7 +424,7 @@ class ShardedLayer:
         self.last = {"entries_local": int(counts.sum()), "entries_shard": n_recv + n_coarse,
                      "coarse": n_coarse, "raw_pairs": n_raw, "raw_pairs_recv": int(rp.numel()),
                      "pairs": len(out), "id_range": (lo, hi), "box_codes": bool(pack), "unique_at_source": bool(unique),
-                     "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+                     "pair_order": "global", "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
         return out
 
     # reference names

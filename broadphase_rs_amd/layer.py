@@ -81,7 +81,7 @@ EXPORTS = [
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
-    "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device",
+    "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device", "bp_layer_par_scan_shard_device",
     "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
 ]
 
@@ -178,6 +178,7 @@ def load_library():
     L.bp_layer_partition_entries_packed_device.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32,
                                                            C.c_int, u64p, C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_scan_shard_pairs_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
+    L.bp_layer_par_scan_shard_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
     L.bp_layer_sort_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
     L.bp_layer_get_facts.argtypes = [vp, C.POINTER(_Facts)]
     L.bp_layer_begin_entries.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
@@ -611,6 +612,13 @@ class Layer:
         self._check(self._L.bp_layer_scan_shard_pairs_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
                                                              C.byref(n), C.byref(u)))
         return DeviceArray(p.value, (n.value,), np.uint64, self), bool(u.value)
+
+    def par_scan_shard_device(self, coarse_depth, emit_coarse):
+        """(this shard's sorted duplicate-free pairs, no-other-shard-holds-them flag)"""
+        p, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._check(self._L.bp_layer_par_scan_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+                                                           C.byref(n), C.byref(u)))
+        return DeviceArray(p.value, (n.value, 2), np.uint32, self), bool(u.value)
 
     def scan_shard_partition_device(self, coarse_depth, emit_coarse, bounds):
         """scan + bucketing of the raw pairs by owner of the first id -> (counts, grouped packed pairs, unique flag)"""

@@ -207,6 +207,11 @@ int bp_layer_scan_raw_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int
  * the source for every entry of this layer (all box codes known) */
 int bp_layer_scan_shard_pairs_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
                                      const uint64_t **d_packed, size_t *n_raw, int *unique);
+/* the shard scan followed by this shard's own sort + dedup (par_scan restricted to the shard's Morton
+ * range): sorted duplicate-free (id, id_) rows in HBM.  *unique = 1 if no other shard can hold any of these
+ * pairs as well (duplicates suppressed at the source for every entry) */
+int bp_layer_par_scan_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse, const uint32_t **d_pairs,
+                                   size_t *n_pairs, int *unique);
 /* stable bucketing of n packed pairs by the owner of the first id: bounds[i] = first id owned by
  * rank i + 1 (n_bounds <= 15); counts[n_bounds + 1] (host) */
 int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed, size_t n, const uint32_t *bounds,

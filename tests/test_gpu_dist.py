@@ -118,6 +118,57 @@ def test_rank_threads_on_one_gpu_match_the_oracle(world, n_per_rank, giants):
     assert max(loads) < 1.5 * (sum(loads) / world) + 1000
 
 
+@pytest.mark.parametrize("world,n_per_rank,giants", [(3, 30000, False), (2, 40000, True)])
+def test_local_pair_order_is_a_disjoint_cover_of_the_reference_list(world, n_per_rank, giants):
+    """pair_order="local": no pair crosses the wire; the ranks' sorted lists are disjoint and their union is
+    exactly the reference's list (falls back to the exchange when a rank cannot vouch for uniqueness)"""
+    import torch
+    torch.cuda.init()
+    parts = [scenes.gen_boxes_shard(world * n_per_rank, r, world, seed=5) for r in range(world)]
+    if giants:
+        _giants(parts, world)
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lay = ShardedLayer(bp.Index64_3D, 0, device=0, backend=HipBackend(bp.Index64_3D, 0, 0), comm=ThreadComm(shared, rank),
+                               pair_order="local")
+            sysb, bounds, ids = parts[rank]
+            lay.extend(sysb, torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda())
+            results[rank] = (lay.par_scan(), lay.last)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    ref = oracle.OracleLayer(2, 0)
+    for sysb, b, ids in parts:
+        ref.extend(sysb, b, ids)
+    expect = ref.scan()
+    orders = {results[r][1]["pair_order"] for r in range(world)}
+    assert len(orders) == 1                                     # every rank took the same route
+    packed = []
+    for r in range(world):
+        out = results[r][0]
+        pk = (out[:, 0].astype(np.uint64) << np.uint64(32)) | out[:, 1].astype(np.uint64)
+        assert np.all(pk[1:] > pk[:-1])                         # sorted, duplicate-free
+        packed.append(pk)
+    allp = np.concatenate(packed)
+    assert len(allp) == len(expect)                             # disjoint ...
+    allp.sort()
+    exp = (expect[:, 0].astype(np.uint64) << np.uint64(32)) | expect[:, 1].astype(np.uint64)
+    assert np.array_equal(allp, exp)                            # ... and a cover
+    if not giants:
+        assert orders == {"local"} and all(results[r][1]["raw_pairs_recv"] == 0 for r in range(world))
+        assert min(len(pk) for pk in packed) > 0
+
+
 def test_single_rank_nccl_group_runs_the_production_path():
     import torch
     import torch.distributed as dist
