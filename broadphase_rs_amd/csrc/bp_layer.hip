@@ -251,6 +251,7 @@ struct ProfScope {
 };
 
 int sync_stream(bp_layer* L) {
+    ++L->stats.host_syncs;
     HIP_TRY(L, hipStreamSynchronize(L->stream));
     prof_collect(L);
     return BP_OK;

@@ -56,7 +56,8 @@ class _Stats(C.Structure):
     _fields_ = [("objects_valid", C.c_uint64), ("objects_invalid", C.c_uint64), ("entries", C.c_uint64),
                 ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("raw_candidates", C.c_uint64),
                 ("tree_sort_passes", C.c_uint32),
-                ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32)]
+                ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32),
+                ("host_syncs", C.c_uint64)]
 
 
 FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)

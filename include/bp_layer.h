@@ -243,6 +243,7 @@ typedef struct bp_stats {
     uint32_t pair_sort_passes;
     uint32_t depth_mask;      /* bit d set <=> some entry has depth d                   */
     uint32_t flags;           /* bit0: key-only stable sort valid, bit1: ids distinct   */
+    uint64_t host_syncs;      /* stream synchronisations since create (each is a host round trip) */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 
