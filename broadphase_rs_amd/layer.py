@@ -277,7 +277,7 @@ class LayerBuilder:
         self._collision_capacity = int(capacity)
         return self
 
-    def with_test_capacity(self, capacity):  # query path (Layer::test/pick) is out of scope; accepted, unused
+    def with_test_capacity(self, capacity):  # accepted, unused: the batched queries size their own scratch
         self._test_capacity = int(capacity)
         return self
 

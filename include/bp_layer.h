@@ -56,7 +56,7 @@ const char *bp_layer_last_error(const bp_layer_t *layer);
 /* LayerBuilder::new().with_min_depth(min_depth).with_index_capacity(index_capacity)
  *   .with_collision_capacity(collision_capacity).build::<Index, u32>()
  * `device` is the HIP device ordinal the layer lives on (-1: the current device).
- * with_test_capacity (src/layer.rs:665) has no counterpart: the query path is out of scope. */
+ * with_test_capacity (src/layer.rs:665) has no counterpart: the batched queries size their own scratch. */
 int bp_layer_create(bp_layer_t **out, int index_kind, uint32_t min_depth, size_t index_capacity,
                     size_t collision_capacity, int device);
 int bp_layer_destroy(bp_layer_t *layer);
