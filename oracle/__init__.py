@@ -15,7 +15,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+# BP_ORACLE_ASAN=1 (with LD_PRELOAD=libasan.so): the sanitizer build of the same source, for `make -C oracle _build/liboracle_asan.so`
+_ASAN = os.environ.get("BP_ORACLE_ASAN") == "1"
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle_asan.so" if _ASAN else "liboracle.so")
 
 INDEX32_2D, INDEX64_2D, INDEX64_3D = 0, 1, 2
 KINDS = {  # src/index.rs:293-295: (dim, bits, depth_bits, axis_bits)
@@ -30,7 +32,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    subprocess.check_call(["make", "-C", _HERE, "-s", "_build/liboracle_asan.so" if _ASAN else "all"])
     return _LIB_PATH
 
 
