@@ -1394,6 +1394,9 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #ifndef SX_WAVES_PER_EU
 #define SX_WAVES_PER_EU 0
 #endif
+#ifndef SX_LDS_WINDOW
+#define SX_LDS_WINDOW 1
+#endif
 #if SX_WAVES_PER_EU
 #define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SX_WAVES_PER_EU, SX_WAVES_PER_EU)))
 #else
@@ -1407,11 +1410,15 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     constexpr int FDIM = (int)KT<KIND>::DIM;
     constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
     __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
-    __shared__ uint4 s_rec[SX_WAVES][64];  // owners with a non-empty range, compacted: {first candidate, id, code | depth << 8, lane}
+    // owners with a non-empty range, compacted: {first candidate, id, code | depth << 8, lane}; the same storage holds
+    // the wave's key window while the range ends are searched (a union, so the compiler knows the two views alias)
+    union RecWin { uint4 rec[64]; u64 win[128]; };
+    __shared__ RecWin s_recwin[SX_WAVES];
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
     sx_hist_clear(s_hist, p);
     const int w = (int)(threadIdx.x >> 6), lane = lane_id();
+    uint4* const s_rec_w = s_recwin[w].rec;
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
     WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
@@ -1419,6 +1426,37 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
         const u32 j = (u32)base + (u32)lane;
         u32 c = 0, idj = 0, cbdd = 0;
+#if SX_LDS_WINDOW
+        // Most ranges end within the next few dozen entries: the wave puts its 64 keys and the 64 after them in LDS
+        // (aliasing s_rec, which is filled only afterwards) and every lane bisects there -- 7 LDS reads instead of a
+        // chain of dependent global loads.  Only a range that leaves the window continues in HBM.
+        u64* const win = s_recwin[w].win;
+        const u64 key = j < m ? p.keys[j] : ~0ull;
+        {
+            const u64 j2 = (u64)j + 64u;
+            win[lane] = key;
+            win[64 + lane] = j2 < p.m ? p.keys[j2] : ~0ull;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (j < m) {
+            const u64 wj = p.idctx[j];
+            idj = (u32)(wj >> 32);
+            cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
+            const u64 upper = cell_upper<KIND>(key);
+            u32 lo = (u32)lane, hi = 128u;  // win[lo] < upper <= win[hi] (hi == 128: not in the window)
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const u32 mid = (lo + hi) >> 1;
+                const bool ge = mid > lo && win[mid] >= upper;
+                hi = ge ? mid : hi;
+                lo = (ge || mid == lo) ? lo : mid;
+            }
+            u32 end;
+            if (hi < 128u) end = (u32)base + hi;
+            else if ((u64)base + 128u >= p.m) end = m;
+            else end = range_end(p.keys, m, (u32)base + 127u, upper);
+            c = end - j - 1u;
+#else
         if (j < m) {
             const u64 key = p.keys[j];
             const u64 wj = p.idctx[j];
@@ -1426,6 +1464,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
             const u32 end = range_end(p.keys, m, j, cell_upper<KIND>(key));
             c = end - j - 1u;
+#endif
             if (GEN == 2 && ((u32)wj & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
             if (c >= SX_BIG) {
                 const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
@@ -1438,6 +1477,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 c = 0;
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the key window is dead from here on (s_rec is written below)
         const u64 nz = __ballot(c > 0);
         if (nz == 0) continue;  // wave-uniform
         const u32 n_nz = (u32)__popcll(nz);
@@ -1448,7 +1488,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
         // popcount and one 16-byte LDS read per lane -- no per-candidate search.
         st.examined += total;
-        if (c > 0) s_rec[w][__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, cbdd, (u32)lane);
+        if (c > 0) s_rec_w[__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, cbdd, (u32)lane);
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
             s_ends[w][lane] = 0ull;
@@ -1468,7 +1508,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 u32 ord = owners_done + (u32)__popcll(e & le_lane);
                 owners_done += (u32)__popcll(e);
                 if (!act) ord = n_nz - 1u;
-                const uint4 r = s_rec[w][ord];
+                const uint4 r = s_rec_w[ord];
                 const u32 i = (u32)base + r.w + 1u + ((act ? k : total - 1u) - r.x);
                 return Cand{p.idctx[i], r.y, r.z, i, act};
             };
@@ -1507,7 +1547,9 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     __shared__ u32 s_end;
     const int w = (int)(threadIdx.x >> 6);
     const u32 m = (u32)p.m;
-    const u32 n_items = min(p.sc->big_count, p.big_cap);
+    // an overflowed list has unwritten slots (a lane that did not fit reserved its slices anyway) and the host
+    // discards this scan's output: do nothing
+    const u32 n_items = p.sc->big_count <= p.big_cap ? p.sc->big_count : 0u;
     if (blockIdx.x >= n_items) return;  // workgroup-uniform: nothing on the list for this workgroup
     sx_hist_clear(s_hist, p);
     WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
