@@ -1446,10 +1446,11 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             u32 lo = (u32)lane, hi = 128u;  // win[lo] < upper <= win[hi] (hi == 128: not in the window)
 #pragma unroll
             for (int it = 0; it < 7; ++it) {
-                const u32 mid = (lo + hi) >> 1;
-                const bool ge = mid > lo && win[mid] >= upper;
+                const u32 mid = (lo + hi) >> 1;  // <= 127: the read is unconditional (no branch per step)
+                const u64 v = win[mid];
+                const bool ge = (mid > lo) & (v >= upper);
                 hi = ge ? mid : hi;
-                lo = (ge || mid == lo) ? lo : mid;
+                lo = ge ? lo : mid;  // mid == lo leaves lo unchanged as well
             }
             u32 end;
             if (hi < 128u) end = (u32)base + hi;
