@@ -145,7 +145,7 @@ def _scene(world, n_per_rank, seed, with_giants):
     return parts
 
 
-def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q):
+def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q, pair_order="global"):
     if split_depth == 2:
         os.environ["BP_DIST_CHUNK_BYTES"] = "4096"   # force the multi-round (chunked) exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -154,7 +154,7 @@ def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q):
     try:
         parts = _scene(world, n_per_rank, seed, with_giants)
         sysb, bounds, ids = parts[rank]
-        lay = ShardedLayer(Index64_3D, 0, n_global=None, split_depth=split_depth, backend=OracleBackend(2, 0))
+        lay = ShardedLayer(Index64_3D, 0, n_global=None, split_depth=split_depth, backend=OracleBackend(2, 0), pair_order=pair_order)
         for _round in range(2):  # reuse across "frames"
             lay.clear()
             lay.extend(sysb, bounds[: len(ids) // 2], ids[: len(ids) // 2])
@@ -173,12 +173,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_per_rank,with_giants,split_depth", [(2, 1500, True, 3), (2, 2500, False, 2), (3, 800, True, 3)])
-def test_sharded_pipeline_equals_single_process(world, n_per_rank, with_giants, split_depth):
+# the last case asks for pair_order="local": this backend cannot vouch for uniqueness at the source, so every rank
+# must take the exchange route and the result is still the sorted partition
+@pytest.mark.parametrize("world,n_per_rank,with_giants,split_depth,pair_order",
+                         [(2, 1500, True, 3, "global"), (2, 2500, False, 2, "global"), (3, 800, True, 3, "global"),
+                          (2, 1200, False, 3, "local")])
+def test_sharded_pipeline_equals_single_process(world, n_per_rank, with_giants, split_depth, pair_order):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_per_rank, 7, with_giants, split_depth, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_per_rank, 7, with_giants, split_depth, q, pair_order)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -197,6 +201,7 @@ def test_sharded_pipeline_equals_single_process(world, n_per_rank, with_giants, 
     assert got.shape == expect.shape and np.array_equal(got, expect)
     if with_giants:
         assert all(results[r][1]["coarse"] >= 3 * world for r in range(world))  # boundary keys replicated everywhere
+    assert all(results[r][1]["pair_order"] == "global" for r in range(world))
     for r in range(world):                                                   # every rank holds its own id range only
         lo, hi = results[r][1]["id_range"]
         o = results[r][0]
