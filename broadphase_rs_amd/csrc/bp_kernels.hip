@@ -2408,36 +2408,51 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
                 const u32 c = child[l];
                 const u32 shift = TOP - DIM * ((u32)l + 1u);
                 const u64 base_key = (cell[l] & ~(u64)((1u << DB) - 1u)) | (u64)((u32)l + 1u);
-                const u32 a0 = cur[l];
-                const u64 next_key = base_key | ((u64)(c + 1u) << shift);
-                const u32 b0 = c + 1u == NSUB ? hi[l]
-                               : ((u32)l + 1u <= qtab_levels ? qtab[qtab_offset<KIND>((u32)l + 1u) + (u32)(next_key >> shift)]
-                                                              : lower_bound(a0, hi[l], next_key));
-                cur[l] = b0;
-                child[l] = c + 1u;
-                if (a0 < b0) {
-                    float r0 = RAY ? rmin[RAY ? l : 0] : 0.f, r1 = RAY ? rmax[RAY ? l : 0] : 0.f;
+                // the child's geometry first (subdivide + should_test need no tree access): a child the query misses
+                // is never entered, so its slice is not located at all -- only the children that are visited pay
+                // for their bisections (the slices are the same lower bounds either way)
+                float cmn[DIM], cmx[DIM];
+                float r0 = RAY ? rmin[RAY ? l : 0] : 0.f, r1 = RAY ? rmax[RAY ? l : 0] : 0.f;
+                bool ovc = true;
 #pragma unroll
-                    for (u32 a = 0; a < DIM; ++a) {
-                        const float ctr = mn[l][a] + (mx[l][a] - mn[l][a]) / 2.0f;
-                        const bool upper = (c >> a) & 1u;
-                        if (RAY) {
-                            const float distance = (ctr - qa[a]) / qb[a];
-                            if (isfinite(distance)) {
-                                const bool is_towards = (qb[a] > 0.0f) != upper;
-                                if (is_towards) r1 = fminf(r1, distance); else r0 = fmaxf(r0, distance);
-                            } else if ((qa[a] > ctr) != upper) {
-                                r0 = INFINITY; r1 = -INFINITY;
-                            }
+                for (u32 a = 0; a < DIM; ++a) {
+                    const float ctr = mn[l][a] + (mx[l][a] - mn[l][a]) / 2.0f;
+                    const bool upper = (c >> a) & 1u;
+                    if (RAY) {
+                        const float distance = (ctr - qa[a]) / qb[a];
+                        if (isfinite(distance)) {
+                            const bool is_towards = (qb[a] > 0.0f) != upper;
+                            if (is_towards) r1 = fminf(r1, distance); else r0 = fmaxf(r0, distance);
+                        } else if ((qa[a] > ctr) != upper) {
+                            r0 = INFINITY; r1 = -INFINITY;
                         }
-                        mn[l + 1][a] = upper ? ctr : mn[l][a];
-                        mx[l + 1][a] = upper ? mx[l][a] : ctr;
                     }
-                    if (RAY) { rmin[RAY ? l + 1 : 0] = r0; rmax[RAY ? l + 1 : 0] = r1; }
-                    lo[l + 1] = a0; hi[l + 1] = b0;
-                    cell[l + 1] = base_key | ((u64)c << shift);
-                    child[l + 1] = NSUB + 1u;
-                    level = l + 1;
+                    cmn[a] = upper ? ctr : mn[l][a];
+                    cmx[a] = upper ? mx[l][a] : ctr;
+                    if (!RAY) ovc = ovc && !(cmn[a] > qb[a] || cmx[a] < qa[a]);
+                }
+                if (RAY) ovc = r0 < r1 && r0 < INFINITY;
+                child[l] = c + 1u;
+                if (!ovc) {
+                    cur[l] = 0xFFFFFFFFu;  // the next visited child locates its own start
+                } else {
+                    const u64 this_key = base_key | ((u64)c << shift);
+                    const bool tab = (u32)l + 1u <= qtab_levels;
+                    const u32 a0 = cur[l] != 0xFFFFFFFFu ? cur[l]
+                                   : (tab ? qtab[qtab_offset<KIND>((u32)l + 1u) + (u32)(this_key >> shift)] : lower_bound(lo[l], hi[l], this_key));
+                    const u64 next_key = base_key | ((u64)(c + 1u) << shift);
+                    const u32 b0 = c + 1u == NSUB ? hi[l]
+                                   : (tab ? qtab[qtab_offset<KIND>((u32)l + 1u) + (u32)(next_key >> shift)] : lower_bound(a0, hi[l], next_key));
+                    cur[l] = b0;
+                    if (a0 < b0) {
+#pragma unroll
+                        for (u32 a = 0; a < DIM; ++a) { mn[l + 1][a] = cmn[a]; mx[l + 1][a] = cmx[a]; }
+                        if (RAY) { rmin[RAY ? l + 1 : 0] = r0; rmax[RAY ? l + 1 : 0] = r1; }
+                        lo[l + 1] = a0; hi[l + 1] = b0;
+                        cell[l + 1] = this_key;
+                        child[l + 1] = NSUB + 1u;
+                        level = l + 1;
+                    }
                 }
             }
         }
