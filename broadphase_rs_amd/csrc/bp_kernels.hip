@@ -568,8 +568,11 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 //   5 tile-local scatter of the keys into LDS (needs no global information)
 //   6 look-back for the global digit bases (predecessors have had phase 5 to publish), PREFIX publish
 //   7 coalesced global stores (+ payload round trip through LDS)
+#ifndef RS_MIN_WAVES_PER_EU
+#define RS_MIN_WAVES_PER_EU 1
+#endif
 template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
-__global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
+__global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
                                                                     u64* status, u32* tile_counter, DevScalars* sc,
@@ -580,7 +583,12 @@ __global__ __launch_bounds__(THREADS) void radix_onesweep_kernel(const K* __rest
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
     constexpr size_t STAGE = RS_TILE * (sizeof(K) > StageBytes<V>::value ? sizeof(K) : StageBytes<V>::value);
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE];
+#if defined(RS_CNT16) && RS_CNT16
+    __shared__ unsigned short s_cnt[RS_WAVES][RS_BINS];  // per-wave counts <= 64 * ITEMS, tile offsets < RS_TILE <= 65535
+    static_assert(RS_TILE <= 65535, "16-bit tile offsets");
+#else
     __shared__ u32 s_cnt[RS_WAVES][RS_BINS];
+#endif
     __shared__ u64 s_glob[RS_BINS];
     __shared__ u32 s_ws[RS_WAVES];
     __shared__ u32 s_tile;
