@@ -210,6 +210,9 @@ constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
+// scalars := init, blockfill[0..n_blocks) := 0, shards[0..n_shard_words) := 0, hist[0..n_hist_words) := 0 (hist may be null)
+hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t* blockfill, size_t n_blocks, uint64_t* shards,
+                               uint32_t n_shard_words, unsigned long long* hist, uint32_t n_hist_words, hipStream_t stream);
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds, int filt_shape,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,

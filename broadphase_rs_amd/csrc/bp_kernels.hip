@@ -2227,6 +2227,25 @@ static unsigned resident_blocks(Kern kernel, int threads) {
     return (unsigned)(cus * per_cu);
 }
 
+// one launch instead of a scalar upload and three memsets in front of every scan: neutral reduction scalars,
+// zeroed per-block fill counts, shard cursors / counters and (optionally) digit histograms
+__global__ __launch_bounds__(256) void scan_prepare_kernel(DevScalars* sc, DevScalars init, u32* __restrict__ blockfill, size_t n_blocks,
+                                                           u64* __restrict__ shards, u32 n_shard_words, u64* __restrict__ hist,
+                                                           u32 n_hist_words) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (t == 0) *sc = init;
+    for (size_t i = t; i < n_blocks; i += stride) blockfill[i] = 0u;
+    for (size_t i = t; i < n_shard_words; i += stride) shards[i] = 0ull;
+    for (size_t i = t; i < n_hist_words; i += stride) hist[i] = 0ull;
+}
+hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t* blockfill, size_t n_blocks, uint64_t* shards,
+                               uint32_t n_shard_words, unsigned long long* hist, uint32_t n_hist_words, hipStream_t stream) {
+    const unsigned grid = (unsigned)std::min<size_t>(2048, (std::max<size_t>(n_blocks, 1024) + 255) / 256);
+    scan_prepare_kernel<<<grid, 256, 0, stream>>>(sc, init, blockfill, n_blocks, (u64*)shards, n_shard_words, (u64*)hist,
+                                                  hist ? n_hist_words : 0u);
+    return hipGetLastError();
+}
+
 template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
     static const unsigned resident = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS);

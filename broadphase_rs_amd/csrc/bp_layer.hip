@@ -258,12 +258,17 @@ int sync_stream(bp_layer* L) {
 }
 
 // ---- device scalars ---------------------------------------------------------------------------------
-int sc_reset(bp_layer* L) {  // neutral elements for every reduction
+DevScalars neutral_scalars() {  // neutral elements for every reduction
+    DevScalars n;
+    std::memset(&n, 0, sizeof n);
+    n.key_and = ~0ull;
+    n.id_and = 0xFFFFFFFFu;
+    n.id_min = 0xFFFFFFFFu;
+    return n;
+}
+int sc_reset(bp_layer* L) {
     DevScalars* h = (DevScalars*)L->h_sc.p;
-    std::memset(h, 0, sizeof(DevScalars));
-    h->key_and = ~0ull;
-    h->id_and = 0xFFFFFFFFu;
-    h->id_min = 0xFFFFFFFFu;
+    *h = neutral_scalars();
     HIP_TRY(L, hipMemcpyAsync(L->d_sc.p, h, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
     return BP_OK;
 }
@@ -928,22 +933,30 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     for (int attempt = 0; attempt < 4; ++attempt) {
         BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
         cap = L->pairs[0].cap / sizeof(uint64_t);
-        BP_TRY(sc_reset(L));
+        if (!expand) BP_TRY(sc_reset(L));
         if (expand) {
             const size_t out_blocks = cap / SX_BLOCK;
             const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
             BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->shards, shard_bytes));
             BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
-            HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
-            HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
             const bool count_digits = allow_holes && hist_plan && hist_plan->n_passes > 0 && hist_plan->n_passes <= SX_HIST_MAX;
             const bool count_owners = allow_holes && !count_digits && owner_n >= 0 && owner_n <= 15;
             L->owner_hist_valid = false;
-            if (count_digits || count_owners) {
-                BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
-                HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
-            }
+            if (count_digits || count_owners) BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+            // scalars, fill counts, cursors and histograms are all reset by one small kernel
+            static const bool no_prepare = getenv("BP_NO_SCAN_PREPARE") != nullptr;  // A/B switch for measurements
+            if (no_prepare) {
+                BP_TRY(sc_reset(L));
+                HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
+                HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+                if (count_digits || count_owners)
+                    HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+            } else
+            HIP_TRY(L, launch_scan_prepare((DevScalars*)L->d_sc.p, neutral_scalars(), (uint32_t*)L->blockfill.p, out_blocks,
+                                           (uint64_t*)L->shards.p, 3 * SX_SHARDS,
+                                           (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
+                                           SX_HIST_MAX * RS_BINS, L->stream));
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds, L->filt_shape,
