@@ -190,7 +190,7 @@ class TorchComm:
         mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=self._small_device(backend))
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
-        return np.stack([p.cpu().numpy() for p in parts])
+        return torch.stack(parts).cpu().numpy()      # ONE device-to-host copy (a copy per part is a sync per rank)
 
     def all_to_all_v(self, send, send_counts, dtype, backend, recv_counts=None, out=None, sync=True):
         """variable-size all-to-all of a tensor that is already grouped by destination.  sync=False leaves the
@@ -329,17 +329,18 @@ class ShardedLayer:
         # 2. balanced contiguous Morton ranges from the all-reduced cell histogram
         hist = be.local_cell_histogram(d_s).astype(np.int64)
         lap("cell_hist")
-        hist_all = comm.all_reduce_sum(hist, be)
-        lap("allreduce_hist")
-        lut = choose_owner_lut(hist_all[:-1], G)
-        # every rank's facts travel with its counts (one all-gather): who can pack box codes into the
-        # ids, id ranges, OR/AND of keys and ids -- the receiving shard layers need no re-reduction
+        # every rank's facts travel with its histogram (ONE small all-gather, summed locally): who can pack box
+        # codes into the ids, id ranges, OR/AND of keys and ids -- the receiving shard layers need no re-reduction
         lf = be.local_facts()
         can_pack = bool(lf["flags"] & 4)
         fvec = [lf["key_or"], lf["key_and"], lf["id_or"], lf["id_and"], lf["id_min"], lf["id_max"], lf["depth_mask"], lf["flags"]]
+        both = comm.all_gather_counts(list(hist) + fvec, be)
+        hist_all = both[:, :len(hist)].sum(axis=0)
+        lap("allgather_hist_facts")
+        lut = choose_owner_lut(hist_all[:-1], G)
         # 3. entries -> owners (fine), boundary keys -> everyone (coarse).  Packing must be decided
-        #    before the partition, by every rank alike: a first tiny all-gather of the flags
-        fm = comm.all_gather_counts(fvec, be)
+        #    before the partition, by every rank alike (from the gathered flags)
+        fm = both[:, len(hist):]
         nonempty = fm[:, 4] <= fm[:, 5]                                  # id_min <= id_max: the rank has entries
         flags_all = fm[:, 7]
         pack = bool(np.all((flags_all[nonempty] & 4) != 0)) if nonempty.any() else False
