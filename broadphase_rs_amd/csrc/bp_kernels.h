@@ -283,6 +283,12 @@ constexpr int SEG_THREADS = 256;
 constexpr int SEGP_CHUNK = SEGP_CHUNK_DEF, SEGP_HALO = SEGP_HALO_DEF;   // segment_finish
 constexpr int SEGT_CHUNK = SEGT_CHUNK_DEF, SEGT_HALO = SEGT_HALO_DEF;   // tree_segment_finish
 constexpr int SEG_SLOW_MAX = 4096;  // longest group the finish kernels rank straight from HBM before giving up
+// n DISTINCT packed pairs sorted by (first id >> gbits): groups g0 .. g0 + n_groups - 1 of 2^gbits first ids each
+// (bounds: n_groups + 1 words of scratch).  Every group is put in final order in LDS and written in the ABI layout;
+// a group of more than group_finish_capacity() pairs (or an id with very many) sets KERR_SEGMENT_TOO_LONG
+hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
+int group_finish_capacity();
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
 // same for pairs that may repeat: equal pairs keep their input order, the output stays packed u64 (sorted), ready
 // for unique_count / unique_emit.  sorted_out must not alias `in`.

@@ -2789,6 +2789,161 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
     return hipGetLastError();
 }
 
+// =================================================================================================
+// Grouped finish: the pair sort stops one digit early.  The stream is sorted by (first id >> G) only;
+// the pairs of one group of 2^G consecutive first ids (GRP_CAP at most) are contiguous, and one
+// workgroup puts a group in final order in LDS: counting sort by the low G bits of the first id
+// (= the id within the group), then each element is ranked by second id inside its id's segment
+// (the pairs are distinct), and the group leaves in the ABI layout with coalesced stores.  Replaces
+// the last radix pass + segment_finish by two small kernels.
+// =================================================================================================
+constexpr int GRP_THREADS = 256, GRP_CAP = 4096, GRP_ITEMS = GRP_CAP / GRP_THREADS, GRP_MAX_BITS = 8;
+constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
+constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;  // larger groups than this are not attempted
+// bounds[t] = first index whose (pair >> gshift) is >= g0 + t, for t = 0 .. n_groups
+__global__ __launch_bounds__(256) void group_bounds_kernel(const u64* __restrict__ in, u32 n, u32 n_groups, u32 g0, int gshift,
+                                                           u32* __restrict__ bounds) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t > n_groups) return;
+    const u64 key = (u64)g0 + (u64)t;
+    u32 a = 0, b = n;
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        if ((in[mid] >> gshift) < key) a = mid + 1; else b = mid;
+    }
+    bounds[t] = a;
+}
+__global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
+                                                                   int gbits, uint2* __restrict__ out, DevScalars* sc) {
+    __shared__ u32 s_second[GRP_CAP];
+    __shared__ u32 s_sorted[GRP_CAP];
+    __shared__ uint8_t s_binof[GRP_CAP];
+    __shared__ u32 s_cnt[256], s_off[257], s_cur[256];
+    __shared__ u32 s_ws[GRP_THREADS / 64];
+    const u32 g = blockIdx.x, tid = threadIdx.x;
+    const u32 lo = bounds[g], hi = bounds[g + 1];
+    const u32 ng = hi - lo;
+    if (ng == 0) return;  // workgroup-uniform
+    const u32 bmask = (1u << gbits) - 1u;
+    if (ng > (u32)GRP_CAP) {
+        // A group that does not fit the LDS buffers (rare: the host only picks this kernel when the average group is
+        // well below the capacity) is finished in several rounds over ranges of ids that do fit, re-reading the group
+        // (L2-resident) in every round.  Only an id with more than GRP_CAP pairs of its own cannot be handled.
+        if (ng > GRP_SLOW_MAX) {
+            if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+            return;
+        }
+        s_cnt[tid] = 0;
+        __syncthreads();
+        for (u32 x = tid; x < ng; x += GRP_THREADS)
+            __hip_atomic_fetch_add(&s_cnt[(u32)(in[(size_t)lo + x] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        const u32 mine_s = s_cnt[tid];
+        u32 total_s;
+        const u32 excl_s = block_excl_scan_u32<GRP_THREADS>(mine_s, s_ws, total_s);
+        s_off[tid] = excl_s;
+        if (tid == 0) s_off[256] = ng;
+        if (mine_s > (u32)GRP_CAP) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);  // the host discards this output
+        __syncthreads();
+        const u32 first_base_s = (g0 + g) << gbits;
+        u32 b0 = 0;
+        while (b0 < 256u) {  // workgroup-uniform: every thread walks the same offsets
+            u32 b1 = b0 + 1u;
+            while (b1 < 256u && s_off[b1 + 1u] - s_off[b0] <= (u32)GRP_CAP) ++b1;
+            const u32 base = s_off[b0];
+            const u32 cnt = min(s_off[b1] - base, (u32)GRP_CAP);  // > GRP_CAP only for an over-long id (flagged above)
+            if (tid >= b0 && tid < b1) s_cur[tid] = s_off[tid] - base;
+            __syncthreads();
+            for (u32 x = tid; x < ng; x += GRP_THREADS) {
+                const u64 vv = in[(size_t)lo + x];
+                const u32 b = (u32)(vv >> 32) & bmask;
+                if (b >= b0 && b < b1) {
+                    const u32 pos = __hip_atomic_fetch_add(&s_cur[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pos < (u32)GRP_CAP) s_second[pos] = (u32)vv;
+                }
+            }
+            __syncthreads();
+            for (u32 x = tid; x < ng; x += GRP_THREADS) {
+                const u64 vv = in[(size_t)lo + x];
+                const u32 b = (u32)(vv >> 32) & bmask, vb = (u32)vv;
+                if (b >= b0 && b < b1) {
+                    const u32 start = s_off[b] - base, end = min(s_off[b + 1u] - base, (u32)GRP_CAP);
+                    u32 rank = 0;
+                    for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
+                    if (start + rank < (u32)GRP_CAP) {
+                        s_sorted[start + rank] = vb;
+                        s_binof[start + rank] = (uint8_t)b;
+                    }
+                }
+            }
+            __syncthreads();
+            for (u32 y = tid; y < cnt; y += GRP_THREADS) out[(size_t)lo + base + y] = make_uint2(first_base_s | (u32)s_binof[y], s_sorted[y]);
+            __syncthreads();
+            b0 = b1;
+        }
+        return;
+    }
+    s_cnt[tid] = 0;  // GRP_THREADS == 256 bins
+    u64 v[GRP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; ++k) {
+        const u32 x = (u32)k * GRP_THREADS + tid;
+        v[k] = x < ng ? in[(size_t)lo + x] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; ++k) {
+        const u32 x = (u32)k * GRP_THREADS + tid;
+        if (x < ng) __hip_atomic_fetch_add(&s_cnt[(u32)(v[k] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const u32 mine = s_cnt[tid];
+    u32 total;
+    const u32 excl = block_excl_scan_u32<GRP_THREADS>(mine, s_ws, total);
+    s_off[tid] = excl;
+    s_cur[tid] = excl;
+    if (tid == 0) s_off[256] = ng;
+    const bool heavy = mine > GRP_SEG_MAX;
+    if (__any(heavy) && lane_id() == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; ++k) {
+        const u32 x = (u32)k * GRP_THREADS + tid;
+        if (x < ng) {
+            const u32 pos = __hip_atomic_fetch_add(&s_cur[(u32)(v[k] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            s_second[pos] = (u32)v[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; ++k) {
+        const u32 x = (u32)k * GRP_THREADS + tid;
+        if (x < ng) {
+            const u32 b = (u32)(v[k] >> 32) & bmask, vb = (u32)v[k];
+            const u32 start = s_off[b], end = s_off[b + 1];
+            u32 rank = 0;
+            if (end - start <= GRP_SEG_MAX) {  // longer: the host discards this output
+#pragma unroll 4
+                for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
+            }
+            s_sorted[start + rank] = vb;
+            s_binof[start + rank] = (uint8_t)b;
+        }
+    }
+    __syncthreads();
+    const u32 first_base = (g0 + g) << gbits;
+    for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_sorted[x]);
+}
+hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream) {
+    if (n == 0 || n_groups == 0) return hipSuccess;
+    if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
+    group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
+    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, (uint2*)pairs_out, sc);
+    return hipGetLastError();
+}
+int group_finish_capacity() { return GRP_CAP; }
+
 hipError_t launch_segment_finish_dups(const uint64_t* in, size_t n, uint64_t* sorted_out, DevScalars* sc, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)((n + SEGP_CHUNK - 1) / SEGP_CHUNK);

@@ -104,6 +104,8 @@ struct bp_layer {
 
     bp_stats stats{};
     bool prof_on = false;
+    bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
+    DevBuf grp_bounds;                  // group start offsets of the grouped finish
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
     std::vector<ProfRec> prof_pending;
@@ -695,12 +697,29 @@ bool segment_finish_enabled() {
     return !disabled;
 }
 // the plan the sort of a pair stream will use (distinct pairs: first id only, then segment finish)
-RadixPlan pair_sort_plan(unsigned long long varying, bool distinct) {
+RadixPlan pair_sort_plan(unsigned long long varying, bool distinct, bool grouped = false) {
     if (distinct && segment_finish_enabled()) {
+        if (grouped) {  // the grouped finish takes the lowest 8 bits of the first id as well
+            const RadixPlan plan = make_radix_plan(varying & 0xFFFFFF0000000000ull, 0, 0);
+            if (plan.n_passes > 0) return plan;
+        }
         const RadixPlan plan = make_radix_plan(varying & 0xFFFFFFFF00000000ull, 0, 0);
         if (plan.n_passes > 0) return plan;
     }
     return make_radix_plan(varying, 0, 0);
+}
+// Grouped finish (launch_group_finish) instead of the last first-id pass + segment_finish: worth it when a group of
+// 256 consecutive first ids holds a few hundred to ~2400 pairs on average (the kernel takes 4096).  id_lo / id_hi bound the first ids (AND / OR of the
+// layer's ids).  Returns the number of groups, 0 = use the classic path.
+uint32_t group_finish_groups(size_t n, unsigned long long varying, uint32_t id_lo, uint32_t id_hi) {
+    static const bool disabled = getenv("BP_NO_GROUP_FINISH") != nullptr;  // A/B switch
+    if (disabled || !segment_finish_enabled() || n < 4096 || n >= 0xFFFFFFFFull || id_hi < id_lo) return 0;
+    const uint32_t idv = (uint32_t)(varying >> 32);
+    if ((idv >> 8) == 0 || (idv & 0xFFu) != 0xFFu) return 0;  // needs varying bits above the group digit and a full low digit
+    const unsigned long long span = (unsigned long long)id_hi - id_lo + 1ull;
+    const double per_group = (double)n * 256.0 / (double)span;
+    if (per_group < 320.0 || per_group > 0.6 * group_finish_capacity()) return 0;
+    return (id_hi >> 8) - (id_lo >> 8) + 1u;
 }
 // digit counts the scan left behind for exactly this plan (consumed by the first sort that asks)
 const unsigned long long* take_ready_hist(bp_layer* L, const RadixPlan& plan, bool holes) {
@@ -718,9 +737,13 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 // n DISTINCT packed pairs in buf0: radix sort on the first id only, then rank-sort the small
 // equal-first-id segments in LDS while writing the ABI layout (3 passes + 1 kernel instead of
 // 6 passes + 1 kernel).  Falls back to the full-width sort when a segment is too long.
-int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes = false) {
+int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes = false,
+                           bool own_ids = false) {
     const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
-    const RadixPlan plan = make_radix_plan(hi_var, 0, 0);
+    // own_ids: the first ids are ids of this layer, so its AND / OR bound them (grouped finish needs the range)
+    const uint32_t n_groups = own_ids ? group_finish_groups(n, varying, L->id_and, L->id_or) : 0u;
+    L->grp_next = n_groups != 0;  // the next scan counts its digit histograms for the plan this frame used
+    const RadixPlan plan = n_groups ? make_radix_plan(hi_var & 0xFFFFFF0000000000ull, 0, 0) : make_radix_plan(hi_var, 0, 0);
     if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
@@ -736,7 +759,12 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
                               holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
     }
     BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
-    {
+    if (n_groups) {
+        BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
+        ProfScope ps(L, BP_K_DEDUP);
+        HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, L->id_and >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
+                                       (DevScalars*)L->d_sc.p, L->stream));
+    } else {
         ProfScope ps(L, BP_K_DEDUP);
         HIP_TRY(L, launch_segment_finish(bufs[res], n, (uint32_t*)L->out_pairs.p, (DevScalars*)L->d_sc.p, L->stream));
     }
@@ -744,8 +772,10 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     BP_TRY(sync_stream(L));
     const DevScalars sc = *(DevScalars*)L->h_sc.p;
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
-    if (sc.err & KERR_SEGMENT_TOO_LONG)  // some id owns > SEG_HALO pairs: sort all 64 bits instead
+    if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group / segment did not fit its window: sort all 64 bits instead
+        L->grp_next = false;
         return sort_unique_pairs_in(L, bufs[res], n, varying, true);
+    }
     L->n_pairs = n;
     L->stats.pairs = n;
     return BP_OK;
@@ -872,9 +902,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
     return BP_OK;
 }
 
-int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false, bool holes = false) {
+int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false, bool holes = false, bool own_ids = false) {
     const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
-    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes);
+    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, own_ids);
     int done = 0;
     BP_TRY(sort_dups_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, &done));
     if (done) return BP_OK;
@@ -1129,9 +1159,9 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         BP_TRY(sort_tree(L));  // settles box_valid, which decides whether the raw stream will be duplicate-free
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv,
-                                              !no_source_dedup && L->box_valid && L->box_all_known);
+                                              !no_source_dedup && L->box_valid && L->box_all_known, L->grp_next);
         BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true, &plan));
-        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes, true));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
     }
@@ -1146,7 +1176,7 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         }
     }
     BP_TRY(scan_raw_device(L, coarse_depth, emit_coarse, !no_source_dedup));
-    BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique));
+    BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, false, true));
     if (L->n_raw == 0) BP_TRY(sync_stream(L));
     return BP_OK;
 }
@@ -1238,7 +1268,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
     free_host(L->h_shards);
     if (L->stream) (void)hipStreamDestroy(L->stream);
@@ -1470,7 +1500,7 @@ static int scan_filtered_rows(bp_layer* L, const float* bounds, size_t n_rows, i
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv, L->box_valid && L->box_all_known);
         BP_TRY(scan_fused_device(L, 0, 1, true, d_bounds, (uint32_t)n_rows, true, &plan));
-        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes));
+        BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes, true));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
     }

@@ -413,6 +413,32 @@ def test_builtin_sphere_predicate_equals_host_filter(kind, n):
         gpu.scan_filtered_sphere(sph[: n // 2])
 
 
+def test_grouped_pair_finish_handles_oversize_and_empty_groups():
+    """the pair sort stops one digit early and finishes groups of 256 first ids in LDS: a group far above the LDS
+    capacity (a tight cluster of consecutively numbered objects) takes the multi-round path, id ranges without any
+    pair give empty groups, and a second frame reuses the scan-side digit counts of the shortened plan"""
+    n = 60000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=31)
+    L = float(sysb[1][0])
+    c = np.float32(0.37) * L
+    rng = np.random.default_rng(5)
+    k = 300                                                       # ids 2048..2347: every pair of them overlaps
+    lo = c - rng.uniform(0.5, 3.0, size=(k, 3)).astype(np.float32)
+    hi = c + rng.uniform(0.5, 3.0, size=(k, 3)).astype(np.float32)
+    bounds[2048:2048 + k] = np.concatenate([lo, hi], axis=1)
+    bounds[30000:31024] += np.float32(1e6)                        # four groups of ids outside the system bounds: no pairs at all
+    gpu, ref = both(2, 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    exp = ref.scan()
+    per_group = np.bincount(exp[:, 0] >> 8, minlength=(n >> 8) + 1)
+    assert per_group.max() > 4096 * 4 and per_group.min() == 0 and 320 < len(exp) * 256 / n < 2400
+    for frame in range(3):
+        got = np.array(gpu.par_scan())
+        assert_pairs_equal(got, exp, "grouped finish, frame %d" % frame)
+        assert gpu.stats()["pair_sort_passes"] == 1                # ids < 2^16: one first-id pass instead of two
+        gpu.clear(); gpu.extend(sysb, bounds, ids)
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list
