@@ -2797,7 +2797,10 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
 // (the pairs are distinct), and the group leaves in the ABI layout with coalesced stores.  Replaces
 // the last radix pass + segment_finish by two small kernels.
 // =================================================================================================
-constexpr int GRP_THREADS = 256, GRP_CAP = 4096, GRP_ITEMS = GRP_CAP / GRP_THREADS, GRP_MAX_BITS = 8;
+#ifndef GRP_THREADS_MACRO
+#define GRP_THREADS_MACRO 512
+#endif
+constexpr int GRP_THREADS = GRP_THREADS_MACRO, GRP_CAP = 4096, GRP_ITEMS = GRP_CAP / GRP_THREADS, GRP_MAX_BITS = 8;
 constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
 constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;  // larger groups than this are not attempted
 // bounds[t] = first index whose (pair >> gshift) is >= g0 + t, for t = 0 .. n_groups
@@ -2833,15 +2836,15 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
             if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
             return;
         }
-        s_cnt[tid] = 0;
+        if (tid < 256u) s_cnt[tid] = 0;
         __syncthreads();
         for (u32 x = tid; x < ng; x += GRP_THREADS)
             __hip_atomic_fetch_add(&s_cnt[(u32)(in[(size_t)lo + x] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
-        const u32 mine_s = s_cnt[tid];
+        const u32 mine_s = tid < 256u ? s_cnt[tid] : 0u;
         u32 total_s;
         const u32 excl_s = block_excl_scan_u32<GRP_THREADS>(mine_s, s_ws, total_s);
-        s_off[tid] = excl_s;
+        if (tid < 256u) s_off[tid] = excl_s;
         if (tid == 0) s_off[256] = ng;
         if (mine_s > (u32)GRP_CAP) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);  // the host discards this output
         __syncthreads();
@@ -2883,7 +2886,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         }
         return;
     }
-    s_cnt[tid] = 0;  // GRP_THREADS == 256 bins
+    if (tid < 256u) s_cnt[tid] = 0;
     u64 v[GRP_ITEMS];
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
@@ -2897,11 +2900,10 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         if (x < ng) __hip_atomic_fetch_add(&s_cnt[(u32)(v[k] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    const u32 mine = s_cnt[tid];
+    const u32 mine = tid < 256u ? s_cnt[tid] : 0u;
     u32 total;
     const u32 excl = block_excl_scan_u32<GRP_THREADS>(mine, s_ws, total);
-    s_off[tid] = excl;
-    s_cur[tid] = excl;
+    if (tid < 256u) { s_off[tid] = excl; s_cur[tid] = excl; }
     if (tid == 0) s_off[256] = ng;
     const bool heavy = mine > GRP_SEG_MAX;
     if (__any(heavy) && lane_id() == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
