@@ -738,10 +738,10 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 // equal-first-id segments in LDS while writing the ABI layout (3 passes + 1 kernel instead of
 // 6 passes + 1 kernel).  Falls back to the full-width sort when a segment is too long.
 int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes = false,
-                           bool own_ids = false) {
+                           const uint32_t* first_range = nullptr) {
     const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
-    // own_ids: the first ids are ids of this layer, so its AND / OR bound them (grouped finish needs the range)
-    const uint32_t n_groups = own_ids ? group_finish_groups(n, varying, L->id_and, L->id_or) : 0u;
+    // first_range: inclusive bounds of the first ids (the grouped finish needs them), nullptr when unknown
+    const uint32_t n_groups = first_range ? group_finish_groups(n, varying, first_range[0], first_range[1]) : 0u;
     L->grp_next = n_groups != 0;  // the next scan counts its digit histograms for the plan this frame used
     const RadixPlan plan = n_groups ? make_radix_plan(hi_var & 0xFFFFFF0000000000ull, 0, 0) : make_radix_plan(hi_var, 0, 0);
     if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
@@ -762,7 +762,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     if (n_groups) {
         BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
         ProfScope ps(L, BP_K_DEDUP);
-        HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, L->id_and >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
+        HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, first_range[0] >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
                                        (DevScalars*)L->d_sc.p, L->stream));
     } else {
         ProfScope ps(L, BP_K_DEDUP);
@@ -904,7 +904,9 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
 
 int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_unique = false, bool holes = false, bool own_ids = false) {
     const unsigned long long varying = ((unsigned long long)id_varying << 32) | id_varying;
-    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, own_ids);
+    // own_ids: the first ids are ids of this layer, so its AND / OR bound them
+    const uint32_t own_range[2] = {L->id_and, L->id_or};
+    if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, own_ids ? own_range : nullptr);
     int done = 0;
     BP_TRY(sort_dups_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, &done));
     if (done) return BP_OK;
@@ -1984,6 +1986,20 @@ int bp_layer_sort_packed_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uin
     DeviceGuard g(L->device);
     L->n_raw = n;
     BP_TRY(sort_distinct_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull));
+    if (n == 0) BP_TRY(sync_stream(L));
+    *d_pairs = (const uint32_t*)L->out_pairs.p;
+    *n_pairs = L->n_pairs;
+    return BP_OK;
+}
+
+int bp_layer_sort_packed_range_device(bp_layer_t* L, uint64_t* d_packed, size_t n, uint64_t varying_mask, uint32_t first_lo,
+                                      uint32_t first_hi, const uint32_t** d_pairs, size_t* n_pairs) {
+    if (!L || !d_pairs || !n_pairs || (n && !d_packed)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_packed_range: null argument");
+    if (first_hi < first_lo) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_sort_packed_range: empty first-id range");
+    DeviceGuard g(L->device);
+    L->n_raw = n;
+    const uint32_t range[2] = {first_lo, first_hi};
+    BP_TRY(sort_distinct_pairs_in(L, d_packed, n, varying_mask ? varying_mask : ~0ull, false, range));
     if (n == 0) BP_TRY(sync_stream(L));
     *d_pairs = (const uint32_t*)L->out_pairs.p;
     *n_pairs = L->n_pairs;

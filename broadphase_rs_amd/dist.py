@@ -124,7 +124,9 @@ class HipBackend:
         counts, out, unique = self.shard.scan_shard_partition_device(coarse_depth, emit_coarse, bounds)
         return counts, out.as_torch(), unique
 
-    def sort_unique_packed(self, packed, varying_mask, already_unique=False):
+    def sort_unique_packed(self, packed, varying_mask, already_unique=False, first_range=None):
+        if already_unique and first_range is not None:
+            return self.shard.sort_packed_range_device(packed.data_ptr(), int(packed.numel()), varying_mask, *first_range)
         if already_unique:
             return self.shard.sort_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
         return self.shard.sort_unique_packed_device(packed.data_ptr(), int(packed.numel()), varying_mask)
@@ -420,7 +422,7 @@ class ShardedLayer:
         lo = 0 if self.rank == 0 else int(bounds[self.rank - 1])
         hi = max_id if self.rank == G - 1 else int(bounds[self.rank]) - 1
         varying = (_varying_bits(lo, max(hi, lo)) << 32) | _varying_bits(0, max_id)
-        out = be.sort_unique_packed(rp, varying, unique)
+        out = be.sort_unique_packed(rp, varying, unique, (lo, max(hi, lo)))         # this rank's first-id range
         lap("sort_pairs")
         self.last = {"entries_local": int(counts.sum()), "entries_shard": n_recv + n_coarse,
                      "coarse": n_coarse, "raw_pairs": n_raw, "raw_pairs_recv": int(rp.numel()),

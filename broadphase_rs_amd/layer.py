@@ -82,7 +82,7 @@ EXPORTS = [
     "bp_layer_sort_unique_packed_device",
     "bp_layer_can_pack_box", "bp_layer_partition_entries_packed_device", "bp_layer_scan_shard_pairs_device",
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
-    "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device", "bp_layer_par_scan_shard_device",
+    "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device", "bp_layer_par_scan_shard_device", "bp_layer_sort_packed_range_device",
     "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
 ]
 
@@ -181,6 +181,7 @@ def load_library():
     L.bp_layer_scan_shard_pairs_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
     L.bp_layer_par_scan_shard_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp, ip]
     L.bp_layer_sort_packed_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.POINTER(vp), szp]
+    L.bp_layer_sort_packed_range_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp), szp]
     L.bp_layer_get_facts.argtypes = [vp, C.POINTER(_Facts)]
     L.bp_layer_begin_entries.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_commit_entries.argtypes = [vp, C.c_size_t, C.POINTER(_Facts)]
@@ -634,6 +635,12 @@ class Layer:
     def sort_packed_device(self, packed_ptr, n, varying_mask=0):
         p, m = C.c_void_p(), C.c_size_t()
         self._check(self._L.bp_layer_sort_packed_device(self._h, C.c_void_p(packed_ptr), n, varying_mask, C.byref(p), C.byref(m)))
+        return DeviceArray(p.value, (m.value, 2), np.uint32, self)
+
+    def sort_packed_range_device(self, packed_ptr, n, varying_mask, first_lo, first_hi):
+        p, m = C.c_void_p(), C.c_size_t()
+        self._check(self._L.bp_layer_sort_packed_range_device(self._h, C.c_void_p(packed_ptr), n, varying_mask, int(first_lo),
+                                                              int(first_hi), C.byref(p), C.byref(m)))
         return DeviceArray(p.value, (m.value, 2), np.uint32, self)
 
     def partition_pairs_device(self, packed_ptr, n, bounds):

@@ -212,6 +212,10 @@ int bp_layer_scan_shard_pairs_device(bp_layer_t *layer, uint32_t coarse_depth, i
  * pairs as well (duplicates suppressed at the source for every entry) */
 int bp_layer_par_scan_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse, const uint32_t **d_pairs,
                                    size_t *n_pairs, int *unique);
+/* sort n DISTINCT packed pairs (no dedup needed); with the inclusive range of their first ids known the sort can stop
+ * one digit early and finish 256-id groups in LDS (bp_layer_sort_packed_device: the same without the range) */
+int bp_layer_sort_packed_range_device(bp_layer_t *layer, uint64_t *d_packed, size_t n, uint64_t varying_mask,
+                                      uint32_t first_lo, uint32_t first_hi, const uint32_t **d_pairs, size_t *n_pairs);
 /* stable bucketing of n packed pairs by the owner of the first id: bounds[i] = first id owned by
  * rank i + 1 (n_bounds <= 15); counts[n_bounds + 1] (host) */
 int bp_layer_partition_pairs_device(bp_layer_t *layer, const uint64_t *d_packed, size_t n, const uint32_t *bounds,

@@ -120,9 +120,11 @@ class OracleBackend:
         counts = np.bincount(owner, minlength=len(bounds) + 1).astype(np.uint64)
         return counts, torch.from_numpy(p[order].view(np.int64).copy())
 
-    def sort_unique_packed(self, packed, varying_mask, already_unique=False):
+    def sort_unique_packed(self, packed, varying_mask, already_unique=False, first_range=None):
         assert not already_unique
         p = np.unique(packed.numpy().view(np.uint64))
+        if first_range is not None and len(p):   # the range the caller promises must hold
+            assert first_range[0] <= int(p[0] >> np.uint64(32)) and int(p[-1] >> np.uint64(32)) <= first_range[1]
         if varying_mask:  # the mask must cover every bit that differs between the pairs
             assert len(p) == 0 or int(np.bitwise_or.reduce(p ^ p[0])) & ~int(varying_mask) == 0
         return _Result(np.stack([(p >> np.uint64(32)).astype(np.uint32), (p & np.uint64(0xFFFFFFFF)).astype(np.uint32)], axis=1))
