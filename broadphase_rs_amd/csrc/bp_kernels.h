@@ -283,6 +283,16 @@ constexpr int SEG_THREADS = 256;
 constexpr int SEGP_CHUNK = SEGP_CHUNK_DEF, SEGP_HALO = SEGP_HALO_DEF;   // segment_finish
 constexpr int SEGT_CHUNK = SEGT_CHUNK_DEF, SEGT_HALO = SEGT_HALO_DEF;   // tree_segment_finish
 constexpr int SEG_SLOW_MAX = 4096;  // longest group the finish kernels rank straight from HBM before giving up
+// Grouped finish of the tree sort (entries sorted by key >> gshift only, gshift >= 8):
+// bounds[t] = first index whose key >> gshift is >= g0 + t (t = 0..n_groups); stats (optional, 2 words): largest group,
+// entries in groups above tgroup_capacity().  launch_tgroup_finish orders every group by (key, id, position) in LDS.
+hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_groups, uint64_t g0, int gshift, uint32_t* bounds,
+                                uint32_t* stats, hipStream_t stream);
+hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
+                                int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
+                                hipStream_t stream);
+int tgroup_capacity();
+int tgroup_bin_bits();  // key bits below gshift the finish uses for its counting sort (gshift must be >= this)
 // n DISTINCT packed pairs sorted by (first id >> gbits): groups g0 .. g0 + n_groups - 1 of 2^gbits first ids each
 // (bounds: n_groups + 1 words of scratch).  Every group is put in final order in LDS and written in the ABI layout;
 // a group of more than group_finish_capacity() pairs (or an id with very many) sets KERR_SEGMENT_TOO_LONG

@@ -1830,6 +1830,184 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
     if (__any(too_long) && lane == 0) atomicOr(&sc->err, KERR_SEGMENT_TOO_LONG);
 }
 
+// =================================================================================================
+// Grouped finish of the TREE sort: the radix passes sort the top bits only (key >> gshift); the entries of one
+// group (equal key >> gshift; TGRP_CAP fit) are contiguous and one workgroup orders them in LDS: counting sort
+// by the next 8 key bits, rank by (key, id, input position) inside the bin, coalesced write-out with the box
+// code split off the id payload.  A larger group takes several rounds over bin ranges that fit (re-reading the
+// group, which is L2-resident).  tgroup_stats reduces the group sizes so that the host can choose between this
+// path and the classic one (one more pass + tree_segment_finish) for the NEXT sort.
+// =================================================================================================
+#ifndef TGRP_THREADS_MACRO
+#define TGRP_THREADS_MACRO 256
+#endif
+#ifndef TGRP_CAP_MACRO
+#define TGRP_CAP_MACRO 2048
+#endif
+constexpr int TGRP_THREADS = TGRP_THREADS_MACRO, TGRP_CAP = TGRP_CAP_MACRO, TGRP_ITEMS = TGRP_CAP / TGRP_THREADS;
+// one bin per thread, at most 256: many small workgroups in flight hide the per-group latency chain (bounds, load,
+// three barriers) better than few large ones
+constexpr int TGRP_BIN_BITS = TGRP_THREADS >= 256 ? 8 : (TGRP_THREADS == 128 ? 7 : 6), TGRP_BINS = 1 << TGRP_BIN_BITS;
+static_assert(TGRP_THREADS >= TGRP_BINS && TGRP_CAP % TGRP_THREADS == 0, "tree group geometry");
+constexpr u32 TGRP_SLOW_MAX = 32768;  // input positions travel as u16 + rounds stay few; longer groups: classic sort
+__global__ __launch_bounds__(256) void tgroup_bounds_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
+                                                            u32* __restrict__ bounds) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t > n_groups) return;
+    const u64 key = g0 + (u64)t;
+    u32 a = 0, b = n;
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        if ((keys[mid] >> gshift) < key) a = mid + 1; else b = mid;
+    }
+    bounds[t] = a;
+}
+// stats[0] = largest group, stats[1] = entries in groups larger than TGRP_CAP (zeroed by the caller)
+__global__ __launch_bounds__(256) void tgroup_stats_kernel(const u32* __restrict__ bounds, u32 n_groups, u32* __restrict__ stats) {
+    u32 mx = 0, over = 0;
+    for (u32 g = blockIdx.x * 256 + threadIdx.x; g < n_groups; g += gridDim.x * 256) {
+        const u32 c = bounds[g + 1] - bounds[g];
+        mx = max(mx, c);
+        over += c > (u32)TGRP_CAP ? c : 0u;
+    }
+    for (int o = 32; o; o >>= 1) { mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); }
+    if (lane_id() == 0) { atomicMax(&stats[0], mx); if (over) atomicAdd(&stats[1], over); }
+}
+template <bool PACKED>
+__global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ ids_in,
+                                                                     const u32* __restrict__ bounds, int gshift,
+                                                                     u64* __restrict__ keys_out, u32* __restrict__ ids_out,
+                                                                     uint8_t* __restrict__ box_out, DevScalars* sc) {
+    __shared__ u64 s_key[TGRP_CAP];
+    __shared__ u32 s_id[TGRP_CAP];             // payload as it travels (box code packed in when PACKED)
+    __shared__ unsigned short s_pos[TGRP_CAP]; // input position inside the group: last tie-break (exact duplicates)
+    __shared__ u32 s_cnt[TGRP_BINS], s_off[TGRP_BINS + 1], s_cur[TGRP_BINS];
+    __shared__ u32 s_ws[TGRP_THREADS / 64];
+    const u32 g = blockIdx.x, tid = threadIdx.x;
+    const u32 lo = bounds[g], hi = bounds[g + 1];
+    const u32 ng = hi - lo;
+    if (ng == 0) return;  // workgroup-uniform
+    constexpr u32 NB = (u32)TGRP_BINS, BM = NB - 1u;
+    const int bshift = gshift - TGRP_BIN_BITS;  // the host guarantees gshift >= TGRP_BIN_BITS
+    auto idof = [](u32 p) { return PACKED ? (p & BOX_ID_MASK) : p; };
+    auto less3 = [&](u64 ky, u32 iy, u32 py, u64 kx, u32 ix, u32 px) { return ky < kx || (ky == kx && (iy < ix || (iy == ix && py < px))); };
+    if (tid < NB) s_cnt[tid] = 0;
+    __syncthreads();
+    if (ng <= (u32)TGRP_CAP) {
+        u64 k[TGRP_ITEMS];
+        u32 p[TGRP_ITEMS];
+#pragma unroll
+        for (int i = 0; i < TGRP_ITEMS; ++i) {
+            const u32 x = (u32)i * TGRP_THREADS + tid;
+            k[i] = x < ng ? keys_in[(size_t)lo + x] : 0ull;
+            p[i] = x < ng ? ids_in[(size_t)lo + x] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < TGRP_ITEMS; ++i) {
+            const u32 x = (u32)i * TGRP_THREADS + tid;
+            if (x < ng) __hip_atomic_fetch_add(&s_cnt[(u32)(k[i] >> bshift) & BM], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        const u32 mine = tid < NB ? s_cnt[tid] : 0u;
+        u32 total;
+        const u32 excl = block_excl_scan_u32<TGRP_THREADS>(mine, s_ws, total);
+        if (tid < NB) { s_off[tid] = excl; s_cur[tid] = excl; }
+        if (tid == 0) s_off[NB] = ng;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TGRP_ITEMS; ++i) {
+            const u32 x = (u32)i * TGRP_THREADS + tid;
+            if (x < ng) {
+                const u32 pos = __hip_atomic_fetch_add(&s_cur[(u32)(k[i] >> bshift) & BM], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                s_key[pos] = k[i];
+                s_id[pos] = p[i];
+                s_pos[pos] = (unsigned short)x;
+            }
+        }
+        __syncthreads();
+        u32 dst[TGRP_ITEMS];
+#pragma unroll
+        for (int i = 0; i < TGRP_ITEMS; ++i) {
+            const u32 x = (u32)i * TGRP_THREADS + tid;
+            dst[i] = 0;
+            if (x < ng) {
+                const u32 b = (u32)(k[i] >> bshift) & BM;
+                const u32 start = s_off[b], end = s_off[b + 1];
+                const u32 ix = idof(p[i]);
+                u32 rank = 0;
+                for (u32 y = start; y < end; ++y) rank += less3(s_key[y], idof(s_id[y]), (u32)s_pos[y], k[i], ix, x) ? 1u : 0u;
+                dst[i] = start + rank;
+            }
+        }
+        __syncthreads();  // every rank is known: the buffers now take the group in final order
+#pragma unroll
+        for (int i = 0; i < TGRP_ITEMS; ++i) {
+            const u32 x = (u32)i * TGRP_THREADS + tid;
+            if (x < ng) { s_key[dst[i]] = k[i]; s_id[dst[i]] = p[i]; }
+        }
+        __syncthreads();
+        for (u32 y = tid; y < ng; y += TGRP_THREADS) {
+            const u32 px = s_id[y];
+            keys_out[(size_t)lo + y] = s_key[y];
+            ids_out[(size_t)lo + y] = idof(px);
+            if (PACKED) box_out[(size_t)lo + y] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
+        }
+        return;
+    }
+    // ---- a group that does not fit: rounds over bin ranges that do ------------------------------------------
+    if (ng > TGRP_SLOW_MAX) {
+        if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
+    for (u32 x = tid; x < ng; x += TGRP_THREADS)
+        __hip_atomic_fetch_add(&s_cnt[(u32)(keys_in[(size_t)lo + x] >> bshift) & BM], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const u32 mine_s = tid < NB ? s_cnt[tid] : 0u;
+    u32 total_s;
+    const u32 excl_s = block_excl_scan_u32<TGRP_THREADS>(mine_s, s_ws, total_s);
+    if (tid < NB) s_off[tid] = excl_s;
+    if (tid == 0) s_off[NB] = ng;
+    if (mine_s > (u32)TGRP_CAP) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);  // one bin alone does not fit: the host re-sorts
+    __syncthreads();
+    u32 b0 = 0;
+    while (b0 < NB) {  // workgroup-uniform
+        u32 b1 = b0 + 1u;
+        while (b1 < NB && s_off[b1 + 1u] - s_off[b0] <= (u32)TGRP_CAP) ++b1;
+        const u32 base = s_off[b0];
+        const u32 cnt = min(s_off[b1] - base, (u32)TGRP_CAP);
+        if (tid >= b0 && tid < b1) s_cur[tid] = s_off[tid] - base;
+        __syncthreads();
+        for (u32 x = tid; x < ng; x += TGRP_THREADS) {
+            const u64 kk = keys_in[(size_t)lo + x];
+            const u32 b = (u32)(kk >> bshift) & BM;
+            if (b >= b0 && b < b1) {
+                const u32 pos = __hip_atomic_fetch_add(&s_cur[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pos < (u32)TGRP_CAP) { s_key[pos] = kk; s_id[pos] = ids_in[(size_t)lo + x]; s_pos[pos] = (unsigned short)x; }
+            }
+        }
+        __syncthreads();
+        // ranks go straight to the output (this path is rare; its stores are scattered inside the round's range)
+        for (u32 x = tid; x < ng; x += TGRP_THREADS) {
+            const u64 kk = keys_in[(size_t)lo + x];
+            const u32 b = (u32)(kk >> bshift) & BM;
+            if (b >= b0 && b < b1) {
+                const u32 px = ids_in[(size_t)lo + x], ix = idof(px);
+                const u32 start = s_off[b] - base, end = min(s_off[b + 1u] - base, (u32)TGRP_CAP);
+                u32 rank = 0;
+                for (u32 y = start; y < end; ++y) rank += less3(s_key[y], idof(s_id[y]), (u32)s_pos[y], kk, ix, x) ? 1u : 0u;
+                const size_t d = (size_t)lo + base + start + rank;
+                if (start + rank < cnt) {
+                    keys_out[d] = kk;
+                    ids_out[d] = ix;
+                    if (PACKED) box_out[d] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
+                }
+            }
+        }
+        __syncthreads();
+        b0 = b1;
+    }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds, int shape,
                                                                 u64* __restrict__ out, DevScalars* sc) {
@@ -2958,6 +3136,34 @@ hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_o
     segment_finish_kernel<false><<<g, SEG_THREADS, 0, stream>>>((const u64*)in, n, (uint2*)pairs_out, sc);
     return hipGetLastError();
 }
+
+hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_groups, uint64_t g0, int gshift, uint32_t* bounds,
+                                uint32_t* stats, hipStream_t stream) {
+    if (m == 0 || n_groups == 0) return hipSuccess;
+    if (m >= 0xFFFFFFFFull) return hipErrorInvalidValue;
+    tgroup_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)keys, (u32)m, n_groups, (u64)g0, gshift, bounds);
+    if (stats) {
+        hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, stats);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
+                                int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
+                                hipStream_t stream) {
+    if (n_groups == 0) return hipSuccess;
+    if (gshift < TGRP_BIN_BITS) return hipErrorInvalidValue;
+    if (payload_packed)
+        tgroup_finish_kernel<true><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out,
+                                                                          ids_out, box_out, sc);
+    else
+        tgroup_finish_kernel<false><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out,
+                                                                           ids_out, box_out, sc);
+    return hipGetLastError();
+}
+int tgroup_capacity() { return TGRP_CAP; }
+int tgroup_bin_bits() { return TGRP_BIN_BITS; }
 
 hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* ids_in, size_t m, int seg_shift,
                                       int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out,

@@ -105,6 +105,11 @@ struct bp_layer {
     bp_stats stats{};
     bool prof_on = false;
     bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
+    // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (tgrp_stats) allow it
+    bool tgrp_ok = false, tgrp_known = false;
+    uint32_t tgrp_probe = 0;
+    DevBuf tgrp_bounds, tgrp_stats;
+    HostBuf h_tstats;
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
@@ -333,6 +338,8 @@ int ensure_unpacked(bp_layer* L) {
 }
 
 bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, int* seg_shift_out);
+struct TreeGroupPlan { RadixPlan plan; int gshift; uint32_t n_groups; unsigned long long g0; };
+bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out);
 
 // ---- extend -------------------------------------------------------------------------------------------
 int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const float* d_bounds,
@@ -380,8 +387,15 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     // already known, so encode counts its digit histograms while the keys are in registers
     RadixPlan hist_plan;
     int seg_shift_unused = 0;
-    const bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
-                              hist_plan.n_passes <= SX_HIST_MAX;
+    bool count_digits = L->m == 0 && tree_partial_plan(add, sc.key_or ^ sc.key_and, &hist_plan, &seg_shift_unused) &&
+                        hist_plan.n_passes <= SX_HIST_MAX;
+    {   // the coming sort takes the grouped plan when the previous sort's group sizes allowed it: count THOSE digits
+        TreeGroupPlan gp;
+        if (L->m == 0 && L->tgrp_ok && tree_group_plan(add, sc.key_and, sc.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
+            hist_plan = gp.plan;
+            count_digits = true;
+        }
+    }
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     // same situation: the codes can ride in the ids from the start (ids distinct and < 2^27), so the tree
     // sort's first pass has no box bytes to gather and none are written here
@@ -505,6 +519,32 @@ bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, in
     *seg_shift_out = seg_shift;
     return true;
 }
+// Grouped tree sort: radix-sort only the top G key bits, and let launch_tgroup_finish order the groups in LDS -- one pass fewer than the classic partial sort.
+bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out) {
+    static const bool disabled = getenv("BP_NO_TREE_GROUPS") != nullptr;  // A/B switch
+    const unsigned long long varying = key_or ^ key_and;
+    if (disabled || m < 65536 || m >= 0xFFFFFFFFull || varying == 0) return false;
+    RadixPlan classic;
+    int seg_shift = 0;
+    if (!tree_partial_plan(m, varying, &classic, &seg_shift)) return false;
+    const int top = 64 - __builtin_clzll(varying);
+    // the fewest top bits G whose groups of equal prefix average at most 60 % of the LDS capacity (the largest groups
+    // that still leave room for the scene's unevenness); worth it only if that needs fewer passes than the classic plan
+    int G = 1;
+    while (G < 56 && (double)m / (double)(1ull << G) > 0.6 * tgroup_capacity()) ++G;
+    const int gshift = top - G;
+    const int passes = (G + 7) / 8;
+    if (G < 1 || gshift < tgroup_bin_bits() || passes >= classic.n_passes) return false;
+    const unsigned long long g0 = key_and >> gshift, g1 = key_or >> gshift;  // key_and <= every key <= key_or
+    if (g1 - g0 + 1 > (unsigned long long)m / 16 + 1) return false;
+    out->plan.n_passes = passes;
+    for (int i = 0; i < RS_MAX_PASSES; ++i) { out->plan.shift[i] = 0; out->plan.from_val[i] = 0; }
+    for (int i = 0; i < passes; ++i) out->plan.shift[i] = gshift + 8 * i;
+    out->gshift = gshift;
+    out->g0 = g0;
+    out->n_groups = (uint32_t)(g1 - g0 + 1);
+    return true;
+}
 bool same_plan(const RadixPlan& a, const RadixPlan& b) {
     if (a.n_passes != b.n_passes) return false;
     for (int i = 0; i < a.n_passes; ++i)
@@ -576,7 +616,58 @@ int sort_tree(bp_layer* L) {
         int seg_shift = 0;
         const bool partial = tree_partial_plan(L->m, varying, &plan, &seg_shift);
         bool done = false;
-        if (partial) {
+        TreeGroupPlan gp;
+        const bool group_able = tree_group_plan(L->m, L->key_and, L->key_or, &gp);
+        if (group_able && L->tgrp_ok) {  // one pass fewer; the groups of equal prefix are ordered in LDS
+            L->stats.tree_sort_passes = (uint32_t)gp.plan.n_passes;
+            const int other = L->cur ^ 1;
+            BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
+            BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
+            const bool packed_in = L->ids_packed;
+            const bool ride = packed_in || (L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0);
+            BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, gp.plan.n_passes)));
+            BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
+            BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
+            BP_TRY(sc_reset(L));
+            int res = 0;
+            uint64_t* kb[2] = {(uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p};
+            uint32_t* vb[2] = {(uint32_t*)L->ids[L->cur].p, (uint32_t*)L->ids[other].p};
+            const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(gp.plan, L->tree_hist_plan);
+            L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
+            HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
+                                  &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
+                                  (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
+                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES));
+            const int src = res ? other : L->cur, dst = src ^ 1;
+            if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
+            {
+                ProfScope ps(L, BP_K_TREE_SORT);
+                HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
+                                                (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
+                HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
+                                                (const uint32_t*)L->tgrp_bounds.p, gp.gshift, ride ? 1 : 0, (uint64_t*)L->keys[dst].p,
+                                                (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
+                                                (DevScalars*)L->d_sc.p, L->stream));
+            }
+            HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+            HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+            BP_TRY(sync_stream(L));
+            const DevScalars sc = *(DevScalars*)L->h_sc.p;
+            if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+            L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
+            if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group beyond the multi-round path: full-width sort of the partially sorted data
+                L->tgrp_ok = false;
+                L->cur = src;
+                BP_TRY(sort_tree_full(L, ride));
+            } else {
+                L->cur = dst;
+                L->box_valid = ride;
+            }
+            L->ids_packed = false;
+            done = true;
+        }
+        if (!done && partial) {
             const int n_part = plan.n_passes;
             L->stats.tree_sort_passes = (uint32_t)n_part;
             const int other = L->cur ^ 1;
@@ -606,10 +697,28 @@ int sort_tree(bp_layer* L) {
                                                       ride ? 1 : 0, (uint64_t*)L->keys[dst].p, (uint32_t*)L->ids[dst].p,
                                                       ride ? (uint8_t*)L->box[dst].p : nullptr, (DevScalars*)L->d_sc.p, L->stream));
             }
+            // would the grouped finish suit this tree?  group sizes of the (now sorted) keys decide for the NEXT sort;
+            // a scene that did not qualify is looked at again every 16th sort only
+            const bool probe = group_able && (!L->tgrp_known || (++L->tgrp_probe & 15u) == 0);
+            if (probe) {
+                BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
+                BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
+                BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
+                ProfScope ps(L, BP_K_TREE_SORT);
+                HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[dst].p, L->m, gp.n_groups, gp.g0, gp.gshift,
+                                                (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
+                HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+            }
             HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             BP_TRY(sync_stream(L));
             const DevScalars sc = *(DevScalars*)L->h_sc.p;
             if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+            if (probe && !(sc.err & KERR_SEGMENT_TOO_LONG)) {
+                L->tgrp_known = true;
+                // switched on only with a margin (80 % of the capacity): a scene hovering at the limit must not flip the
+                // plan every frame -- each flip costs the digit counts encode_emit made for the other plan
+                L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)(tgroup_capacity() * 4 / 5);
+            }
             if (sc.err & KERR_SEGMENT_TOO_LONG) {
                 // a group of equal key prefix is longer than the LDS window (heavily clustered input):
                 // finish with the full-width sort, starting from the partially sorted (still packed) data
@@ -1270,9 +1379,9 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
-    free_host(L->h_shards);
+    free_host(L->h_shards); free_host(L->h_tstats);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
     return BP_OK;

@@ -439,6 +439,48 @@ def test_grouped_pair_finish_handles_oversize_and_empty_groups():
         gpu.clear(); gpu.extend(sysb, bounds, ids)
 
 
+def _clustered_scene(n, n_cluster, seed, frac):
+    """uniform scene whose first n_cluster objects are squeezed into a cube of `frac` of the system side"""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
+    L = float(sysb[1][0])
+    rng = np.random.default_rng(seed)
+    size = (bounds[:n_cluster, 3:] - bounds[:n_cluster, :3]) * np.float32(0.02)
+    lo = (np.float32(0.61) * L + rng.uniform(0, frac * L, size=(n_cluster, 3))).astype(np.float32)
+    bounds[:n_cluster] = np.concatenate([lo, lo + size], axis=1).astype(np.float32)
+    return sysb, bounds, ids
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+def test_grouped_tree_sort_over_frames(kind):
+    """the tree sort drops a radix pass once a sort has shown that prefix groups fit LDS: same tree as the oracle's in
+    every frame -- uniform frames (grouped finish), then clustered frames whose groups need several rounds or exceed
+    the path altogether (full-width fallback), then uniform again"""
+    n = 90000
+    uniform = make_scene(kind, n, seed=41)
+    dim = KINDS[kind].dim
+
+    def cut(scene):
+        sysb, b, ids = scene
+        if dim == 2:
+            return np.ascontiguousarray(sysb[:, :2]), np.ascontiguousarray(b[:, [0, 1, 3, 4]]), ids
+        return scene
+    mild = cut(_clustered_scene(n, 6000, 43, 0.004))            # a group of several thousand entries: multi-round path
+    heavy = cut(_clustered_scene(n, 60000, 44, 0.0005))         # tens of thousands in one group: falls back
+    frames = [uniform, uniform, uniform, mild, mild, uniform, heavy, heavy, uniform, uniform]
+    gpu, ref = both(kind, 0)
+    passes = []
+    for f, (sysb, bounds, ids) in enumerate(frames):
+        gpu.clear(); ref.clear()
+        gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+        gpu.par_sort(); ref.sort()
+        assert_tree_equal(gpu, ref, "grouped tree sort, frame %d" % f)
+        passes.append(gpu.stats()["tree_sort_passes"])
+        if f in (2, 5, 9):
+            assert_pairs_equal(np.array(gpu.par_scan()), ref.scan(), "scan after grouped tree sort, frame %d" % f)
+    if kind == 2:      # the uniform cube qualifies: frame 0 probes, frames 1-2 run one pass fewer (the 2-D scene leaves
+        assert passes[1] < passes[0] and passes[2] == passes[1], passes     # part of its square empty: groups too uneven)
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list
