@@ -1873,11 +1873,14 @@ __global__ __launch_bounds__(256) void tgroup_stats_kernel(const u32* __restrict
     for (int o = 32; o; o >>= 1) { mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); }
     if (lane_id() == 0) { atomicMax(&stats[0], mx); if (over) atomicAdd(&stats[1], over); }
 }
-template <bool PACKED>
+// CTX_KIND >= 0 (with PACKED): also write the scan's per-entry {id, suppression context} word (entry_ctx_kernel's output
+// for inactive_below = 0) while key and box code are at hand -- the separate streaming kernel is then not needed
+template <bool PACKED, int CTX_KIND>
 __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ ids_in,
                                                                      const u32* __restrict__ bounds, int gshift,
                                                                      u64* __restrict__ keys_out, u32* __restrict__ ids_out,
-                                                                     uint8_t* __restrict__ box_out, DevScalars* sc) {
+                                                                     uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
+                                                                     DevScalars* sc) {
     __shared__ u64 s_key[TGRP_CAP];
     __shared__ u32 s_id[TGRP_CAP];             // payload as it travels (box code packed in when PACKED)
     __shared__ unsigned short s_pos[TGRP_CAP]; // input position inside the group: last tie-break (exact duplicates)
@@ -1948,9 +1951,14 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* 
         __syncthreads();
         for (u32 y = tid; y < ng; y += TGRP_THREADS) {
             const u32 px = s_id[y];
-            keys_out[(size_t)lo + y] = s_key[y];
+            const u64 ky = s_key[y];
+            keys_out[(size_t)lo + y] = ky;
             ids_out[(size_t)lo + y] = idof(px);
-            if (PACKED) box_out[(size_t)lo + y] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
+            if (PACKED) {
+                const u32 code = box_from_packed(px >> BOX_ID_BITS);
+                box_out[(size_t)lo + y] = (uint8_t)code;
+                if constexpr (CTX_KIND >= 0) idctx_out[(size_t)lo + y] = ((u64)idof(px) << 32) | (u64)make_entry_ctx<CTX_KIND>(ky, code, 0u);
+            }
         }
         return;
     }
@@ -1999,7 +2007,11 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* 
                 if (start + rank < cnt) {
                     keys_out[d] = kk;
                     ids_out[d] = ix;
-                    if (PACKED) box_out[d] = (uint8_t)box_from_packed(px >> BOX_ID_BITS);
+                    if (PACKED) {
+                        const u32 code = box_from_packed(px >> BOX_ID_BITS);
+                        box_out[d] = (uint8_t)code;
+                        if constexpr (CTX_KIND >= 0) idctx_out[d] = ((u64)ix << 32) | (u64)make_entry_ctx<CTX_KIND>(kk, code, 0u);
+                    }
                 }
             }
         }
@@ -3151,15 +3163,18 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
 }
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
-                                hipStream_t stream) {
+                                hipStream_t stream, int ctx_kind, uint64_t* idctx_out) {
     if (n_groups == 0) return hipSuccess;
     if (gshift < TGRP_BIN_BITS) return hipErrorInvalidValue;
-    if (payload_packed)
-        tgroup_finish_kernel<true><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out,
-                                                                          ids_out, box_out, sc);
-    else
-        tgroup_finish_kernel<false><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out,
-                                                                           ids_out, box_out, sc);
+#define BP_TGRP_LAUNCH(P, K)                                                                                                     \
+    tgroup_finish_kernel<P, K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out, \
+                                                                      ids_out, box_out, (u64*)idctx_out, sc)
+    if (!payload_packed) BP_TGRP_LAUNCH(false, -1);
+    else if (!idctx_out || ctx_kind < 0) BP_TGRP_LAUNCH(true, -1);
+    else if (ctx_kind == 0) BP_TGRP_LAUNCH(true, 0);
+    else if (ctx_kind == 1) BP_TGRP_LAUNCH(true, 1);
+    else BP_TGRP_LAUNCH(true, 2);
+#undef BP_TGRP_LAUNCH
     return hipGetLastError();
 }
 int tgroup_capacity() { return TGRP_CAP; }

@@ -641,6 +641,10 @@ int sort_tree(bp_layer* L) {
                                   hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES));
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
+            // the finish has key and box code at hand: it also writes the scan's per-entry context words
+            static const bool no_ctx_fuse = getenv("BP_NO_CTX_FUSE") != nullptr;  // A/B switch
+            const bool with_ctx = ride && !no_ctx_fuse;
+            if (with_ctx) BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             {
                 ProfScope ps(L, BP_K_TREE_SORT);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
@@ -648,7 +652,8 @@ int sort_tree(bp_layer* L) {
                 HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
                                                 (const uint32_t*)L->tgrp_bounds.p, gp.gshift, ride ? 1 : 0, (uint64_t*)L->keys[dst].p,
                                                 (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
-                                                (DevScalars*)L->d_sc.p, L->stream));
+                                                (DevScalars*)L->d_sc.p, L->stream, with_ctx ? L->kind : -1,
+                                                with_ctx ? (uint64_t*)L->idctx.p : nullptr));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
             HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
@@ -663,6 +668,7 @@ int sort_tree(bp_layer* L) {
             } else {
                 L->cur = dst;
                 L->box_valid = ride;
+                if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; }
             }
             L->ids_packed = false;
             done = true;
