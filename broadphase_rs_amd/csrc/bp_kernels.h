@@ -290,7 +290,10 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
                                 uint32_t* stats, hipStream_t stream);
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
-                                hipStream_t stream, int ctx_kind = -1, uint64_t* idctx_out = nullptr);
+                                hipStream_t stream, int ctx_kind = -1, uint64_t* idctx_out = nullptr,
+                                const uint32_t* stats = nullptr, uint32_t abort_over = 0xFFFFFFFFu);
+// stats / abort_over: launch_tgroup_bounds' statistics; more than abort_over entries in oversize groups -> nothing is
+// done and KERR_SEGMENT_TOO_LONG is set (the caller sorts full-width instead)
 // ctx_kind (index kind) + idctx_out with payload_packed: also writes launch_entry_ctx's output for inactive_below = 0
 int tgroup_capacity();
 int tgroup_bin_bits();  // key bits below gshift the finish uses for its counting sort (gshift must be >= this)

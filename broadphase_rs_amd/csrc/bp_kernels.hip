@@ -1880,13 +1880,19 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* 
                                                                      const u32* __restrict__ bounds, int gshift,
                                                                      u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                      uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
-                                                                     DevScalars* sc) {
+                                                                     DevScalars* sc, const u32* __restrict__ stats, u32 abort_over) {
     __shared__ u64 s_key[TGRP_CAP];
     __shared__ u32 s_id[TGRP_CAP];             // payload as it travels (box code packed in when PACKED)
     __shared__ unsigned short s_pos[TGRP_CAP]; // input position inside the group: last tie-break (exact duplicates)
     __shared__ u32 s_cnt[TGRP_BINS], s_off[TGRP_BINS + 1], s_cur[TGRP_BINS];
     __shared__ u32 s_ws[TGRP_THREADS / 64];
     const u32 g = blockIdx.x, tid = threadIdx.x;
+    // the scene changed under the plan (most entries now sit in oversize groups): rounds over every such group would cost
+    // far more than the full-width sort the host runs when it sees this flag
+    if (stats && stats[1] > abort_over) {
+        if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
     const u32 lo = bounds[g], hi = bounds[g + 1];
     const u32 ng = hi - lo;
     if (ng == 0) return;  // workgroup-uniform
@@ -3163,12 +3169,12 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
 }
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
-                                hipStream_t stream, int ctx_kind, uint64_t* idctx_out) {
+                                hipStream_t stream, int ctx_kind, uint64_t* idctx_out, const uint32_t* stats, uint32_t abort_over) {
     if (n_groups == 0) return hipSuccess;
     if (gshift < TGRP_BIN_BITS) return hipErrorInvalidValue;
 #define BP_TGRP_LAUNCH(P, K)                                                                                                     \
     tgroup_finish_kernel<P, K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out, \
-                                                                      ids_out, box_out, (u64*)idctx_out, sc)
+                                                                      ids_out, box_out, (u64*)idctx_out, sc, stats, abort_over)
     if (!payload_packed) BP_TGRP_LAUNCH(false, -1);
     else if (!idctx_out || ctx_kind < 0) BP_TGRP_LAUNCH(true, -1);
     else if (ctx_kind == 0) BP_TGRP_LAUNCH(true, 0);
