@@ -1862,13 +1862,13 @@ __global__ __launch_bounds__(256) void tgroup_bounds_kernel(const u64* __restric
     }
     bounds[t] = a;
 }
-// stats[0] = largest group, stats[1] = entries in groups larger than TGRP_CAP (zeroed by the caller)
-__global__ __launch_bounds__(256) void tgroup_stats_kernel(const u32* __restrict__ bounds, u32 n_groups, u32* __restrict__ stats) {
+// stats[0] = largest group, stats[1] = entries in groups larger than cap (zeroed by the caller)
+__global__ __launch_bounds__(256) void tgroup_stats_kernel(const u32* __restrict__ bounds, u32 n_groups, u32 cap, u32* __restrict__ stats) {
     u32 mx = 0, over = 0;
     for (u32 g = blockIdx.x * 256 + threadIdx.x; g < n_groups; g += gridDim.x * 256) {
         const u32 c = bounds[g + 1] - bounds[g];
         mx = max(mx, c);
-        over += c > (u32)TGRP_CAP ? c : 0u;
+        over += c > cap ? c : 0u;
     }
     for (int o = 32; o; o >>= 1) { mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); }
     if (lane_id() == 0) { atomicMax(&stats[0], mx); if (over) atomicAdd(&stats[1], over); }
@@ -3013,13 +3013,20 @@ __global__ __launch_bounds__(256) void group_bounds_kernel(const u64* __restrict
     bounds[t] = a;
 }
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
-                                                                   int gbits, uint2* __restrict__ out, DevScalars* sc) {
+                                                                   int gbits, uint2* __restrict__ out, DevScalars* sc,
+                                                                   const u32* __restrict__ stats, u32 abort_over) {
     __shared__ u32 s_second[GRP_CAP];
     __shared__ u32 s_sorted[GRP_CAP];
     __shared__ uint8_t s_binof[GRP_CAP];
     __shared__ u32 s_cnt[256], s_off[257], s_cur[256];
     __shared__ u32 s_ws[GRP_THREADS / 64];
     const u32 g = blockIdx.x, tid = threadIdx.x;
+    // most pairs sit in oversize groups (ids that follow the scene's clusters): rounds over every such group would cost far
+    // more than the full-width sort the host runs when it sees this flag
+    if (stats && stats[1] > abort_over) {
+        if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
     const u32 lo = bounds[g], hi = bounds[g + 1];
     const u32 ng = hi - lo;
     if (ng == 0) return;  // workgroup-uniform
@@ -3133,11 +3140,17 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
     for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_sorted[x]);
 }
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
-                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream) {
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats) {
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
     group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
-    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, (uint2*)pairs_out, sc);
+    if (stats) {  // stats[0] = largest group, stats[1] = pairs in groups above the capacity; a quarter of all pairs there: bail out
+        hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRP_CAP, stats);
+    }
+    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, (uint2*)pairs_out, sc, stats,
+                                                              (u32)(n / 4));
     return hipGetLastError();
 }
 int group_finish_capacity() { return GRP_CAP; }
@@ -3163,7 +3176,7 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
     if (stats) {
         hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, stats);
+        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)TGRP_CAP, stats);
     }
     return hipGetLastError();
 }

@@ -104,6 +104,7 @@ struct bp_layer {
 
     bp_stats stats{};
     bool prof_on = false;
+    uint32_t grp_off = 0;               // sorts left for which the grouped pair finish stays off (after a refusal)
     bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
     // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (tgrp_stats) allow it
     bool tgrp_ok = false, tgrp_known = false;
@@ -857,7 +858,9 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
                            const uint32_t* first_range = nullptr) {
     const unsigned long long hi_var = varying & 0xFFFFFFFF00000000ull;
     // first_range: inclusive bounds of the first ids (the grouped finish needs them), nullptr when unknown
-    const uint32_t n_groups = first_range ? group_finish_groups(n, varying, first_range[0], first_range[1]) : 0u;
+    // after a refusal (uneven groups) the grouped finish stays off for the next 16 distinct-pair sorts of this layer
+    if (L->grp_off) --L->grp_off;
+    const uint32_t n_groups = (first_range && !L->grp_off) ? group_finish_groups(n, varying, first_range[0], first_range[1]) : 0u;
     L->grp_next = n_groups != 0;  // the next scan counts its digit histograms for the plan this frame used
     const RadixPlan plan = n_groups ? make_radix_plan(hi_var & 0xFFFFFF0000000000ull, 0, 0) : make_radix_plan(hi_var, 0, 0);
     if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
@@ -878,8 +881,9 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     if (n_groups) {
         BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
         ProfScope ps(L, BP_K_DEDUP);
+        BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
         HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, first_range[0] >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
-                                       (DevScalars*)L->d_sc.p, L->stream));
+                                       (DevScalars*)L->d_sc.p, L->stream, (uint32_t*)L->tgrp_stats.p));
     } else {
         ProfScope ps(L, BP_K_DEDUP);
         HIP_TRY(L, launch_segment_finish(bufs[res], n, (uint32_t*)L->out_pairs.p, (DevScalars*)L->d_sc.p, L->stream));
@@ -890,6 +894,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group / segment did not fit its window: sort all 64 bits instead
         L->grp_next = false;
+        if (n_groups) L->grp_off = 16;
         return sort_unique_pairs_in(L, bufs[res], n, varying, true);
     }
     L->n_pairs = n;

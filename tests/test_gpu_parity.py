@@ -413,7 +413,8 @@ def test_builtin_sphere_predicate_equals_host_filter(kind, n):
         gpu.scan_filtered_sphere(sph[: n // 2])
 
 
-def test_grouped_pair_finish_handles_oversize_and_empty_groups():
+@pytest.mark.parametrize("k", [300, 2500])
+def test_grouped_pair_finish_handles_oversize_and_empty_groups(k):
     """the pair sort stops one digit early and finishes groups of 256 first ids in LDS: a group far above the LDS
     capacity (a tight cluster of consecutively numbered objects) takes the multi-round path, id ranges without any
     pair give empty groups, and a second frame reuses the scan-side digit counts of the shortened plan"""
@@ -422,7 +423,8 @@ def test_grouped_pair_finish_handles_oversize_and_empty_groups():
     L = float(sysb[1][0])
     c = np.float32(0.37) * L
     rng = np.random.default_rng(5)
-    k = 300                                                       # ids 2048..2347: every pair of them overlaps
+    # ids 2048..2048+k-1: every pair of them overlaps.  k = 300: one group of ~40 k pairs (rounds).  k = 2500: most of the
+    # pairs sit in ten such groups of hundreds of thousands -- the finish refuses and the full-width sort runs
     lo = c - rng.uniform(0.5, 3.0, size=(k, 3)).astype(np.float32)
     hi = c + rng.uniform(0.5, 3.0, size=(k, 3)).astype(np.float32)
     bounds[2048:2048 + k] = np.concatenate([lo, hi], axis=1)
@@ -431,11 +433,14 @@ def test_grouped_pair_finish_handles_oversize_and_empty_groups():
     gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
     exp = ref.scan()
     per_group = np.bincount(exp[:, 0] >> 8, minlength=(n >> 8) + 1)
-    assert per_group.max() > 4096 * 4 and per_group.min() == 0 and 320 < len(exp) * 256 / n < 2400
+    assert per_group.max() > 4096 * 4 and per_group.min() == 0
+    if k == 300:
+        assert 320 < len(exp) * 256 / n < 2400
     for frame in range(3):
         got = np.array(gpu.par_scan())
         assert_pairs_equal(got, exp, "grouped finish, frame %d" % frame)
-        assert gpu.stats()["pair_sort_passes"] == 1                # ids < 2^16: one first-id pass instead of two
+        if k == 300:
+            assert gpu.stats()["pair_sort_passes"] == 1            # ids < 2^16: one first-id pass instead of two
         gpu.clear(); gpu.extend(sysb, bounds, ids)
 
 
