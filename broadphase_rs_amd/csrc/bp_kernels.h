@@ -301,7 +301,8 @@ int tgroup_bin_bits();  // key bits below gshift the finish uses for its countin
 // (bounds: n_groups + 1 words of scratch).  Every group is put in final order in LDS and written in the ABI layout;
 // a group of more than group_finish_capacity() pairs (or an id with very many) sets KERR_SEGMENT_TOO_LONG
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
-                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats = nullptr);
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats = nullptr,
+                               uint32_t second_max = 0xFFFFFFFFu);  // an upper bound of the second ids (only speed depends on it)
 // stats (2 words of scratch): group-size statistics; with more than a quarter of the pairs in oversize groups the finish
 // does nothing and sets KERR_SEGMENT_TOO_LONG
 int group_finish_capacity();

@@ -2998,7 +2998,8 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
 #endif
 constexpr int GRP_THREADS = GRP_THREADS_MACRO, GRP_CAP = 4096, GRP_ITEMS = GRP_CAP / GRP_THREADS, GRP_MAX_BITS = 8;
 constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
-constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;  // larger groups than this are not attempted
+constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;
+constexpr u32 GRP_SUB = 4;  // sub-bins per id by the top bits of the second id (fast path)  // larger groups than this are not attempted
 // bounds[t] = first index whose (pair >> gshift) is >= g0 + t, for t = 0 .. n_groups
 __global__ __launch_bounds__(256) void group_bounds_kernel(const u64* __restrict__ in, u32 n, u32 n_groups, u32 g0, int gshift,
                                                            u32* __restrict__ bounds) {
@@ -3013,12 +3014,15 @@ __global__ __launch_bounds__(256) void group_bounds_kernel(const u64* __restrict
     bounds[t] = a;
 }
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
-                                                                   int gbits, uint2* __restrict__ out, DevScalars* sc,
+                                                                   int gbits, int sshift, uint2* __restrict__ out, DevScalars* sc,
                                                                    const u32* __restrict__ stats, u32 abort_over) {
-    __shared__ u32 s_second[GRP_CAP];
-    __shared__ u32 s_sorted[GRP_CAP];
+    // bins of the fast path: id within the group x GRP_SUB ranges of the second id (second >> sshift, clamped): shorter
+    // bins, shorter rank loops (their cost is quadratic in the bin length)
+    constexpr u32 NBINS = 256u * GRP_SUB;
+    static_assert(NBINS == 2u * GRP_THREADS, "two bins per thread in the prefix scan");
+    __shared__ u32 s_second[GRP_CAP];  // second ids grouped by bin for the rank loops, then the group in final order
     __shared__ uint8_t s_binof[GRP_CAP];
-    __shared__ u32 s_cnt[256], s_off[257], s_cur[256];
+    __shared__ u32 s_cnt[NBINS], s_off[NBINS + 1], s_cur[NBINS];
     __shared__ u32 s_ws[GRP_THREADS / 64];
     const u32 g = blockIdx.x, tid = threadIdx.x;
     // most pairs sit in oversize groups (ids that follow the scene's clusters): rounds over every such group would cost far
@@ -3076,20 +3080,21 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
                     const u32 start = s_off[b] - base, end = min(s_off[b + 1u] - base, (u32)GRP_CAP);
                     u32 rank = 0;
                     for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
-                    if (start + rank < (u32)GRP_CAP) {
-                        s_sorted[start + rank] = vb;
-                        s_binof[start + rank] = (uint8_t)b;
-                    }
+                    // rare path: ranks go straight to the output (stores scattered inside the round's range)
+                    if (start + rank < cnt) out[(size_t)lo + base + start + rank] = make_uint2(first_base_s | b, vb);
                 }
             }
-            __syncthreads();
-            for (u32 y = tid; y < cnt; y += GRP_THREADS) out[(size_t)lo + base + y] = make_uint2(first_base_s | (u32)s_binof[y], s_sorted[y]);
             __syncthreads();
             b0 = b1;
         }
         return;
     }
-    if (tid < 256u) s_cnt[tid] = 0;
+    auto bin_of = [&](u64 v) {
+        const u32 sub = min((u32)v >> sshift, GRP_SUB - 1u);
+        return (((u32)(v >> 32) & bmask) * GRP_SUB) | sub;
+    };
+    s_cnt[2u * tid] = 0;
+    s_cnt[2u * tid + 1u] = 0;
     u64 v[GRP_ITEMS];
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
@@ -3100,47 +3105,60 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
-        if (x < ng) __hip_atomic_fetch_add(&s_cnt[(u32)(v[k] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (x < ng) __hip_atomic_fetch_add(&s_cnt[bin_of(v[k])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    const u32 mine = tid < 256u ? s_cnt[tid] : 0u;
+    const u32 c0 = s_cnt[2u * tid], c1 = s_cnt[2u * tid + 1u];
     u32 total;
-    const u32 excl = block_excl_scan_u32<GRP_THREADS>(mine, s_ws, total);
-    if (tid < 256u) { s_off[tid] = excl; s_cur[tid] = excl; }
-    if (tid == 0) s_off[256] = ng;
-    const bool heavy = mine > GRP_SEG_MAX;
+    const u32 excl = block_excl_scan_u32<GRP_THREADS>(c0 + c1, s_ws, total);
+    s_off[2u * tid] = excl;
+    s_cur[2u * tid] = excl;
+    s_off[2u * tid + 1u] = excl + c0;
+    s_cur[2u * tid + 1u] = excl + c0;
+    if (tid == 0) s_off[NBINS] = ng;
+    const bool heavy = max(c0, c1) > GRP_SEG_MAX;
     if (__any(heavy) && lane_id() == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
         if (x < ng) {
-            const u32 pos = __hip_atomic_fetch_add(&s_cur[(u32)(v[k] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 pos = __hip_atomic_fetch_add(&s_cur[bin_of(v[k])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             s_second[pos] = (u32)v[k];
         }
     }
     __syncthreads();
+    u32 dst[GRP_ITEMS];
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
+        dst[k] = 0;
         if (x < ng) {
-            const u32 b = (u32)(v[k] >> 32) & bmask, vb = (u32)v[k];
+            const u32 b = bin_of(v[k]), vb = (u32)v[k];
             const u32 start = s_off[b], end = s_off[b + 1];
             u32 rank = 0;
             if (end - start <= GRP_SEG_MAX) {  // longer: the host discards this output
 #pragma unroll 4
                 for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
             }
-            s_sorted[start + rank] = vb;
-            s_binof[start + rank] = (uint8_t)b;
+            dst[k] = start + rank;
+        }
+    }
+    __syncthreads();  // every rank is known: the buffer now takes the group in final order
+#pragma unroll
+    for (int k = 0; k < GRP_ITEMS; ++k) {
+        const u32 x = (u32)k * GRP_THREADS + tid;
+        if (x < ng) {
+            s_second[dst[k]] = (u32)v[k];
+            s_binof[dst[k]] = (uint8_t)((u32)(v[k] >> 32) & bmask);
         }
     }
     __syncthreads();
     const u32 first_base = (g0 + g) << gbits;
-    for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_sorted[x]);
+    for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_second[x]);
 }
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
-                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats) {
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max) {
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
     group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
@@ -3149,7 +3167,11 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
         if (e != hipSuccess) return e;
         tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRP_CAP, stats);
     }
-    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, (uint2*)pairs_out, sc, stats,
+    // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
+    int bits = 0;
+    while (bits < 32 && (second_max >> bits) != 0) ++bits;
+    const int sshift = bits > 2 ? bits - 2 : 0;
+    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
                                                               (u32)(n / 4));
     return hipGetLastError();
 }

@@ -883,7 +883,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
         ProfScope ps(L, BP_K_DEDUP);
         BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
         HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, first_range[0] >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
-                                       (DevScalars*)L->d_sc.p, L->stream, (uint32_t*)L->tgrp_stats.p));
+                                       (DevScalars*)L->d_sc.p, L->stream, (uint32_t*)L->tgrp_stats.p, (uint32_t)(varying & 0xFFFFFFFFull)));
     } else {
         ProfScope ps(L, BP_K_DEDUP);
         HIP_TRY(L, launch_segment_finish(bufs[res], n, (uint32_t*)L->out_pairs.p, (DevScalars*)L->d_sc.p, L->stream));
