@@ -243,8 +243,8 @@ typedef struct bp_stats {
     uint64_t pairs;           /* P of the last scan                                     */
     uint64_t raw_candidates;  /* containment combos the last scan examined = the reference's raw pair count
                                  before dedup (src/layer.rs:566-570); 0 when the scan path does not count them */
-    uint32_t tree_sort_passes;
-    uint32_t pair_sort_passes;
+    uint32_t tree_sort_passes; /* radix passes of the last tree sort (the LDS finish kernels are not counted)  */
+    uint32_t pair_sort_passes; /* radix passes of the last pair sort                                            */
     uint32_t depth_mask;      /* bit d set <=> some entry has depth d                   */
     uint32_t flags;           /* bit0: key-only stable sort valid, bit1: ids distinct   */
     uint64_t host_syncs;      /* stream synchronisations since create (each is a host round trip) */
