@@ -594,6 +594,7 @@ int sort_tree_by_merge(bp_layer* L, int* handled) {
     }
     BP_TRY(sync_stream(L));
     L->cur = dst;
+    ++L->epoch;  // the head's own sort may have left per-entry context words for ITS order: the merged tree is a new one
     L->sorted = true;
     L->order_ok = true;
     ++L->stats.tree_sort_passes;

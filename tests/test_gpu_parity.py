@@ -685,7 +685,9 @@ def test_destroy_releases_every_device_buffer():
     assert free0 - free1 < (32 << 20), "destroy leaks %d MB per layer" % ((free0 - free1) >> 20 // 12)
 
 
-@pytest.mark.parametrize("kind,n_static,n_dyn", [(2, 60000, 3000), (2, 5000, 1), (0, 20000, 2500), (2, 3000, 9000)])
+# (2, 150000, 40000): a head large enough for the grouped tree finish from the second frame on -- its per-entry context
+# words describe the head alone and must not survive the merge
+@pytest.mark.parametrize("kind,n_static,n_dyn", [(2, 60000, 3000), (2, 5000, 1), (0, 20000, 2500), (2, 3000, 9000), (2, 150000, 40000)])
 def test_static_layer_merge_sorts_by_merging_runs(kind, n_static, n_dyn):
     # the crate's per-frame pattern (src/layer.rs:123-138): dynamic.clear(); dynamic.extend(..); dynamic.merge(&static)
     # -- the static entries arrive as one sorted run, so the sort is "sort the dynamic run + one merge pass"
@@ -701,7 +703,7 @@ def test_static_layer_merge_sorts_by_merging_runs(kind, n_static, n_dyn):
     st_g.extend(sysb, sb, sid); st_r.extend(sysb, sb, sid)
     st_g.par_sort(); st_r.sort()
     dyn_g, dyn_r = both(kind, 0)
-    for frame in range(2):
+    for frame in range(4 if n_dyn >= 40000 else 2):
         dyn_g.clear(); dyn_r.clear()
         shift = np.float32(0.01 * frame)
         dyn_g.extend(sysb, db + shift, did); dyn_r.extend(sysb, db + shift, did)
