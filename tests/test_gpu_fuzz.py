@@ -133,3 +133,55 @@ def test_random_operation_sequences(seed):
     for which in range(2):
         g, r = layers[which]
         _scan(g, r, "final scan[%d] after %s" % (which, " | ".join(log[-8:])), rng)
+
+
+def _frame_scene(rng, n, style):
+    """one frame's objects: uniform, shifted, clustered (dense consecutive ids), sparse ids, ids shuffled or repeated"""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=int(rng.integers(0, 1 << 30)))
+    L = float(sysb[1][0])
+    if style == "clustered":
+        k = int(rng.integers(n // 20, n // 2))
+        size = (bounds[:k, 3:] - bounds[:k, :3]) * np.float32(rng.choice([0.02, 0.2]))
+        lo = (np.float32(rng.uniform(0.1, 0.8)) * L + rng.uniform(0, float(rng.choice([0.0005, 0.004, 0.03])) * L, size=(k, 3))).astype(np.float32)
+        bounds[:k] = np.concatenate([lo, lo + size], axis=1).astype(np.float32)
+    elif style == "sparse_ids":
+        ids = (ids.astype(np.uint64) * np.uint64(rng.choice([3, 17, 300]))).astype(np.uint32)
+    elif style == "shuffled_ids":
+        ids = rng.permutation(ids)
+    elif style == "repeated_ids":
+        ids = (ids // np.uint32(2)).astype(np.uint32)
+    elif style == "dense_pairs":
+        bounds[:, 3:] = bounds[:, :3] + (bounds[:, 3:] - bounds[:, :3]) * np.float32(2.2)
+    return sysb, bounds, ids
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BP_FRAME_SEEDS", "3")))   # BP_FRAME_SEEDS=24 for a soak (~25 s per seed, mostly the oracle))
+def test_random_frame_sequences_on_one_layer(seed):
+    """the sort plans adapt from frame to frame (grouped tree / pair finishes chosen from the previous frame's statistics,
+    digit counts made by the producers for the predicted plan, context words written by the sort): whatever the order of
+    scene kinds, every frame's tree and pair list must equal the oracle's"""
+    rng = np.random.default_rng(7000 + seed)
+    gpu, ref = bp.Layer(bp.Index64_3D, 0), oracle.OracleLayer(2, 0)
+    styles = ["uniform", "uniform", "clustered", "sparse_ids", "shuffled_ids", "repeated_ids", "dense_pairs"]
+    log = []
+    for frame in range(9):
+        style = str(rng.choice(styles)) if frame > 1 else "uniform"     # two uniform frames first: the grouped paths switch on
+        n = 30000 if style == "dense_pairs" else int(rng.choice([30000, 60000, 110000]))   # the oracle pays for the pairs
+        sysb, bounds, ids = _frame_scene(rng, n, style)
+        log.append("%s/%d" % (style, n))
+        gpu.clear(); ref.clear()
+        if rng.random() < 0.3:                                          # the frame arrives in two extends
+            h = n // 3
+            gpu.extend(sysb, bounds[:h], ids[:h]); ref.extend(sysb, bounds[:h], ids[:h])
+            gpu.extend(sysb, bounds[h:], ids[h:]); ref.extend(sysb, bounds[h:], ids[h:])
+        else:
+            gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+        if rng.random() < 0.5:
+            gpu.par_sort(); ref.sort()
+            _tree(gpu, ref, "frames " + " ".join(log))
+        exp = ref.scan()
+        got = gpu.scan_device().to_numpy() if rng.random() < 0.5 else np.array(gpu.par_scan())
+        assert got.shape == exp.shape and np.array_equal(got, exp), "frames " + " ".join(log)
+        if rng.random() < 0.3:                                          # a second scan of the same tree (cached context words)
+            got = np.array(gpu.scan())
+            assert got.shape == exp.shape and np.array_equal(got, exp), "rescan, frames " + " ".join(log)
