@@ -155,7 +155,8 @@ def _frame_scene(rng, n, style):
     return sysb, bounds, ids
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BP_FRAME_SEEDS", "3")))   # BP_FRAME_SEEDS=24 for a soak (~25 s per seed, mostly the oracle))
+# BP_FRAME_SEEDS=24 for a soak (~25 s per seed, mostly the oracle)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BP_FRAME_SEEDS", "3"))))
 def test_random_frame_sequences_on_one_layer(seed):
     """the sort plans adapt from frame to frame (grouped tree / pair finishes chosen from the previous frame's statistics,
     digit counts made by the producers for the predicted plan, context words written by the sort): whatever the order of
