@@ -140,7 +140,7 @@ def _frame_scene(rng, n, style):
     sysb, bounds, ids = scenes.gen_boxes(n, seed=int(rng.integers(0, 1 << 30)))
     L = float(sysb[1][0])
     if style == "clustered":
-        k = int(rng.integers(n // 20, n // 2))
+        k = int(rng.integers(n // 20, n // 4))
         size = (bounds[:k, 3:] - bounds[:k, :3]) * np.float32(rng.choice([0.02, 0.2]))
         lo = (np.float32(rng.uniform(0.1, 0.8)) * L + rng.uniform(0, float(rng.choice([0.0005, 0.004, 0.03])) * L, size=(k, 3))).astype(np.float32)
         bounds[:k] = np.concatenate([lo, lo + size], axis=1).astype(np.float32)
@@ -156,7 +156,7 @@ def _frame_scene(rng, n, style):
 
 
 # BP_FRAME_SEEDS=24 for a soak (~25 s per seed, mostly the oracle)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BP_FRAME_SEEDS", "3"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BP_FRAME_SEEDS", "1"))))
 def test_random_frame_sequences_on_one_layer(seed):
     """the sort plans adapt from frame to frame (grouped tree / pair finishes chosen from the previous frame's statistics,
     digit counts made by the producers for the predicted plan, context words written by the sort): whatever the order of
@@ -165,9 +165,9 @@ def test_random_frame_sequences_on_one_layer(seed):
     gpu, ref = bp.Layer(bp.Index64_3D, 0), oracle.OracleLayer(2, 0)
     styles = ["uniform", "uniform", "clustered", "sparse_ids", "shuffled_ids", "repeated_ids", "dense_pairs"]
     log = []
-    for frame in range(9):
+    for frame in range(7):
         style = str(rng.choice(styles)) if frame > 1 else "uniform"     # two uniform frames first: the grouped paths switch on
-        n = 30000 if style == "dense_pairs" else int(rng.choice([30000, 60000, 110000]))   # the oracle pays for the pairs
+        n = 30000 if style == "dense_pairs" else int(rng.choice([30000, 70000]))   # the oracle pays for the pairs
         sysb, bounds, ids = _frame_scene(rng, n, style)
         log.append("%s/%d" % (style, n))
         gpu.clear(); ref.clear()
