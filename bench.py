@@ -6,11 +6,12 @@ A "step" is one pass of the hot path over one batch of synthetic AABBs that are 
 in HBM: clear + extend + par_sort + par_scan, result (sorted, duplicate-free pair list) left in HBM.
 value = unique pairs produced by all ranks / max-over-ranks time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--objects M]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--objects M] [--scaling strong|weak]
 
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`
-(one rank per GPU, RCCL); scaling is weak: every rank contributes `--objects` objects of one
-global scene, entries and pairs are exchanged by Morton / id range (broadphase_rs_amd/dist.py).
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU,
+RCCL).  Default for N > 1 is BASELINE.json configs[3] as stated: `--objects` (10 M) objects IN TOTAL, sharded by
+object index over the N ranks ("scaling": "strong"); `--scaling weak` gives every rank `--objects` objects of one
+N-times larger scene.  Entries and pairs are exchanged by Morton / id range (broadphase_rs_amd/dist.py).
 """
 import argparse
 import json
@@ -22,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+M64 = (1 << 64) - 1
 
 
 def parse():
@@ -29,10 +31,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--objects", type=int, default=10_000_000, help="objects per GPU")
+    ap.add_argument("--objects", type=int, default=10_000_000,
+                    help="objects of the scene (per GPU with --scaling weak, in total with --scaling strong)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1 only: strong = configs[3] (--objects in total), weak = --objects per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-objects", type=int, default=10_000_000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-1m", action="store_true", help="skip the configs[1] (1 M objects) sub-record")
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
     ap.add_argument("--pair-order", choices=["global", "local"], default="global",
                     help="VARIANT: 'local' leaves every rank's pairs where they were found (set-equal, not the sorted partition)")
@@ -64,6 +70,25 @@ def usable_cpus(hw):
     return max(1, n)
 
 
+def list_hash_numpy(pairs):
+    """order-sensitive 64-bit fingerprint of a pair list: (count, sum p, sum p * (2 i + 1)) mod 2^64, p = id << 32 | id_"""
+    import numpy as np
+    p = (pairs[:, 0].astype(np.uint64) << np.uint64(32)) | pairs[:, 1].astype(np.uint64)
+    w = np.arange(len(p), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        return [int(len(p)), int(p.sum(dtype=np.uint64)), int((p * w).sum(dtype=np.uint64))]
+
+
+def list_hash_torch(t):
+    """the same fingerprint of a device-resident (n, 2) int32 view, with torch ops (int64 arithmetic wraps mod 2^64)"""
+    import torch
+    a = t[:, 0].to(torch.int64) & 0xFFFFFFFF
+    b = t[:, 1].to(torch.int64) & 0xFFFFFFFF
+    p = (a << 32) | b
+    w = torch.arange(p.numel(), dtype=torch.int64, device=p.device) * 2 + 1
+    return [int(p.numel()), int(p.sum().item()) & M64, int((p * w).sum().item()) & M64]
+
+
 def cpu_baseline(n_objects, seed):
     """The oracle (C restatement of the reference's algorithm and structure) timed on this host.
     kind = "port": the Rust crate itself cannot be built here (no rustc/cargo).  Bounded sample:
@@ -73,6 +98,7 @@ def cpu_baseline(n_objects, seed):
     sysb, bounds, ids = scenes.gen_boxes(n_objects, seed=seed)
     threads = usable_cpus(oracle.lib().orc_hw_threads())
     rows = {}
+    list_hash = None
     # "tuned": min_depth = smallest natural depth of the scene, so indices/results are unchanged
     # but par_scan_impl can actually split (src/layer.rs:533-546); "default": min_depth = 0, where
     # level_mask(0) == 0 makes the reference's scan one serial sweep (only the sorts are parallel).
@@ -88,13 +114,86 @@ def cpu_baseline(n_objects, seed):
         pairs = lay.par_scan(threads)
         dt = time.perf_counter() - t0
         rows[name] = {"pairs": int(len(pairs)), "seconds": dt, "pairs_per_s": len(pairs) / dt}
+        if md == 0:
+            list_hash = list_hash_numpy(pairs)
         del lay, pairs
     best = max(rows.values(), key=lambda r: r["pairs_per_s"])
     return {"value": best["pairs_per_s"] / 1e6, "unit": "Mpairs/s", "cores": threads, "kind": "port",
             "sample": "gen_boxes(%d objects, density 0.001, seed %d): clear+extend+par_sort+par_scan, OpenMP "
                       "C restatement with the reference's structure; rows: %s" % (
                           n_objects, seed, json.dumps({k: round(v["pairs_per_s"] / 1e6, 3) for k, v in rows.items()})),
-            "rows": rows}
+            "rows": rows, "list_hash": list_hash}
+
+
+# one kernel per class on the default path (bp_kernel_class of include/bp_layer.h) -> (kernel name, SURVEY 8(d) bytes per launch)
+def kernel_table(n, M, P_raw, P):
+    return {
+        "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)", 28.0 * n + 12.0 * M),
+        "tree_sort": ("radix_onesweep_kernel<u64,u32> (tree-sort pass)", 24.0 * M),
+        "tree_finish": ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
+        "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
+        "pair_sort": ("radix_onesweep_kernel<u64,NoVal> (pair-sort pass)", 16.0 * P_raw),
+        "dedup": ("group_finish_kernel (LDS finish of the pair sort + dedup)", 8.0 * P_raw + 8.0 * P),
+    }
+
+
+def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, aabb_filter=False, detail=True):
+    """steady-state frames of one layer on one GPU -> dict of measurements (all times in ms)"""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
+    d_bounds = torch.from_numpy(bounds).to(dev)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
+
+    def step():
+        layer.clear()
+        layer.extend(sysb, d_bounds, d_ids)
+        layer.par_sort()
+        if aabb_filter:
+            return layer.scan_filtered_aabb_device(d_bounds)
+        return layer.scan_device()
+
+    def timed(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3, out
+
+    res = {}
+    res["first_frame_ms"], _ = timed(1)            # fresh layer: includes every hipMalloc
+    layer.reset_plan_hints()
+    res["cold_frame_ms"], _ = timed(1)             # buffers allocated, no plan hints: what a layer's first frame runs
+    st = layer.stats()
+    res["cold_plan"] = {"tree_sort_passes": st["tree_sort_passes"], "pair_sort_passes": st["pair_sort_passes"]}
+    # warm-up with every class timed: finds the dominant kernel = largest TOTAL time per step over all classes
+    layer.profile_reset(); layer.profile_select(None); layer.profile_enable(True)
+    for _ in range(max(warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    layer.profile_enable(False)
+    wprof = layer.profile()
+    st = layer.stats()
+    table = kernel_table(n, st["entries"], st["raw_pairs"], st["pairs"])
+    dom_cls = max(table, key=lambda c: wprof[c][0])
+    # timed region: events only around the dominant class (every event pair costs a few us of stream bubble)
+    layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(True)
+    syncs0 = layer.stats()["host_syncs"]
+    res["ms_per_step"], out = timed(steps)
+    res["host_syncs_per_step"] = (layer.stats()["host_syncs"] - syncs0) / steps
+    layer.profile_enable(False)
+    res["dom_cls"], res["dom_prof"] = dom_cls, layer.profile()[dom_cls]
+    if detail:
+        k = max(1, min(steps, 3))
+        layer.profile_reset(); layer.profile_select(None); layer.profile_enable(True)
+        for _ in range(k):
+            out = step()
+        torch.cuda.synchronize()
+        layer.profile_enable(False)
+        res["detail_steps"], res["prof"] = k, layer.profile()
+    res["stats"], res["n_pairs"], res["out"], res["layer"] = layer.stats(), len(out), out, layer
+    return res
 
 
 def main():
@@ -116,21 +215,51 @@ def main():
         local_rank = int(os.environ["BP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_backend = os.environ.get("BP_DIST_BACKEND", "nccl")
-    dist = None
     sharded_path = world > 1 or args.sharded
-    if sharded_path:
-        import torch.distributed as dist
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        elif dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(dist_backend)
 
-    n = args.objects
+    if not sharded_path:
+        r = run_single(bp, scenes, torch, np, dev, local_rank, args.objects, args.seed, args.warmup, args.steps, args.aabb_filter)
+        line = single_gpu_line(args, r, np)
+        # in-run parity: the device list's fingerprint against the CPU row's (same scene, same seed)
+        gpu_hash = list_hash_torch(r["out"].as_torch()) if r["n_pairs"] else [0, 0, 0]
+        line["list_hash"] = gpu_hash
+        del r["out"]
+        if not args.no_1m and args.objects != 1_000_000 and not args.aabb_filter:
+            r1 = run_single(bp, scenes, torch, np, dev, local_rank, 1_000_000, args.seed, 5, 50, detail=False)
+            line["config_1m"] = {"workload": "configs[1]: 1M Index64_3D uniform-random AABBs, single MI355X, clear+extend+par_sort+par_scan",
+                                 "ms_per_step": r1["ms_per_step"], "pairs": r1["n_pairs"],
+                                 "value": r1["n_pairs"] / (r1["ms_per_step"] * 1e-3), "unit": "pairs/s",
+                                 "cold_frame_ms": r1["cold_frame_ms"], "host_syncs_per_step": r1["host_syncs_per_step"],
+                                 "tree_sort_passes": r1["stats"]["tree_sort_passes"], "pair_sort_passes": r1["stats"]["pair_sort_passes"]}
+            del r1
+        if not args.no_cpu_baseline and not args.aabb_filter:
+            cb = cpu_baseline(args.cpu_objects, args.seed)
+            line["cpu_baseline"] = cb
+            same_scene = args.cpu_objects == args.objects
+            line["parity_in_run"] = (cb["list_hash"] == gpu_hash) if same_scene else None
+            line["parity_note"] = ("fingerprint (count, sum p, sum p*(2i+1) mod 2^64, p = id<<32|id_) of the device pair list vs "
+                                   "the CPU row's list on the same scene" if same_scene else
+                                   "CPU sample is a different scene size: lists not comparable")
+        else:
+            line["cpu_baseline"] = None
+            line["parity_in_run"] = None
+        print(json.dumps(line))
+        return
+
+    # ---- N > 1 (or --sharded rehearsal): Morton-range shards over torch.distributed ---------------------------
+    import torch.distributed as dist
+    dist_backend = os.environ.get("BP_DIST_BACKEND", "nccl")
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif dist_backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(dist_backend)
+    strong = args.scaling == "strong"
+    n_global = args.objects if strong else args.objects * world
+    n = n_global // world
     n_global = n * world
     # one global scene, sharded by object index: rank r owns ids [r*n, (r+1)*n); same density as
     # the reference's recipe, so the global side is cbrt(n_global / 0.001) + 5.5
@@ -139,198 +268,166 @@ def main():
     d_bounds = torch.from_numpy(bounds).to(dev)
     d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
     torch.cuda.synchronize()
+    from broadphase_rs_amd import dist as bpd
+    sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
 
-    if not sharded_path:
-        layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
-
-        def step():
-            layer.clear()
-            layer.extend(sysb, d_bounds, d_ids)
-            layer.par_sort()
-            if args.aabb_filter:
-                return layer.scan_filtered_aabb_device(d_bounds)
-            return layer.scan_device()
-        engine = layer
-    else:
-        from broadphase_rs_amd import dist as bpd
-        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
-
-        def step():
-            sharded.clear()
-            sharded.extend(sysb, d_bounds, d_ids)
-            return sharded.par_scan_device()
-        engine = sharded.shard_layer
+    def step():
+        sharded.clear()
+        sharded.extend(sysb, d_bounds, d_ids)
+        return sharded.par_scan_device()
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up (untimed) with every kernel class timed: finds the dominant kernel.  Each HIP event pair
-    # costs a few microseconds of stream bubble (all classes: ~0.2 ms per step), so the TIMED region
-    # carries events only around the dominant kernel -- the one `roofline` reports.
-    DOM_CAND = {"scan_emit": 1.0, "dedup": 1.0, "pair_sort": None}   # class -> launches per step (None: measured)
-    engine.profile_reset()
-    engine.profile_select(None)
-    engine.profile_enable(True)
     for _ in range(args.warmup):
         out = step()
-    engine.profile_enable(False)
-    wprof = engine.profile()
-    per_launch = {c: (wprof[c][0] / max(wprof[c][1], 1)) for c in DOM_CAND}
-    dom_cls = max(per_launch, key=per_launch.get) if args.warmup > 0 and any(per_launch.values()) else "scan_emit"
-    engine.profile_reset()
-    engine.profile_select([dom_cls])
-    engine.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    engine.profile_enable(False)
-    dom_prof = engine.profile()[dom_cls]          # (ms, launches) of the dominant class inside the timed region
-    # per-kernel breakdown: extra steps after the timed region, every class timed
-    detail_steps = max(1, min(args.steps, 3))
-    engine.profile_reset()
-    engine.profile_select(None)
-    engine.profile_enable(True)
-    for _ in range(detail_steps):
-        out = step()
-    torch.cuda.synchronize()
-    engine.profile_enable(False)
     n_pairs_local = len(out)
-
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([n_pairs_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_pairs = int(c.item())
-    else:
-        n_pairs = n_pairs_local
-
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    c = torch.tensor([n_pairs_local], dtype=torch.int64, device=dev)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    n_pairs = int(c.item())
+    # fingerprint of the global list = per-rank fingerprints combined with the ranks' list offsets (rank order = list order)
+    h = list_hash_torch(out.as_torch()) if n_pairs_local else [0, 0, 0]
+    hv = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in h], dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(hv) for _ in range(world)]
+    dist.all_gather(parts, hv)
     if rank == 0:
-        st = engine.stats()
-        prof = engine.profile()
+        cnt = s1 = s2 = 0
+        for pr in parts:
+            k, a, b = [int(v) & M64 for v in pr.tolist()]
+            s2 = (s2 + b + 2 * cnt * a) & M64      # sum p (2 (i + cnt) + 1) = local + 2 cnt sum p
+            s1 = (s1 + a) & M64
+            cnt += k
+        st = sharded.shard_layer.stats()
         ms_per_step = dt / args.steps * 1e3
-        value = n_pairs / (dt / args.steps)
-        M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
-        pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
-        # ALGORITHMIC bytes per step and per kernel class (SURVEY.md 8(d) per-unit figures x measured
-        # N / M / P_raw / P).  P_raw is what the scan actually emitted: with
-        # duplicate suppression at the source it equals P.
-        model = {
-            "encode": 64.0 * n + 13.0 * M,                    # bounds+ids read twice, counts w+r, entries + box written
-            "tree_hist": 0.0,                                 # digits are counted inside encode_emit
-            "tree_sort": 24.0 * M * pk + 25.0 * M,            # key+id per pass (r+w) + finish (12 r + 13 w)
-            "scan_count": 21.0 * M,                           # entry_ctx: key, id, box read; {id, context} word written
-            "scan_emit": 16.0 * M + 8.0 * P_raw,              # scan_expand: keys + {id, context} words read; packed pairs written
-            "pair_hist": 0.0,                                 # digits are counted inside the scan
-            "pair_sort": 16.0 * P_raw * pp,
-            "dedup": 16.0 * P_raw,                            # finish / unique: pairs read, ABI layout written
-            "misc": 0.0,
-        }
-        launches = {k: v[1] / detail_steps for k, v in prof.items()}
-        per_step_ms = {k: v[0] / detail_steps for k, v in prof.items()}
-        kernels = {k: {"ms_per_step": per_step_ms[k], "timed_regions_per_step": launches[k], "model_bytes_per_step": model[k],
-                       "GBps": (model[k] / (per_step_ms[k] * 1e-3) / 1e9) if per_step_ms[k] > 0 else 0.0}
-                   for k in prof}
-        # dominant kernel = the kernel (by name) with the largest time per step.  Radix passes are
-        # timed per launch, so a class total is launches x one kernel; the scan is a single launch.
-        cand = {
-            "scan_expand_kernel (overlap scan, single pass)": ("scan_emit", 1.0, model["scan_emit"]),
-            "segment_finish_kernel (pair segments -> final list)": ("dedup", 1.0, model["dedup"]),
-            "radix_onesweep_kernel<u64,NoVal> (pair-sort pass)": ("pair_sort", max(launches["pair_sort"], 1.0), 16.0 * P_raw),
-        }
-        dom_name = [k for k in cand if cand[k][0] == dom_cls][0]
-        _, _, bytes_per_launch = cand[dom_name]
-        dom_launches = dom_prof[1] / args.steps if dom_prof[1] else 1.0
-        per_launch_ms = dom_prof[0] / dom_prof[1] if dom_prof[1] else 0.0   # HIP events inside the timed region
-        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        # the radix pass is the HBM-bound kernel of the path: always reported as well
-        rp_ms = per_step_ms["pair_sort"] / max(launches["pair_sort"], 1.0)
-        rp_achieved = 16.0 * P_raw / (rp_ms * 1e-3) / 1e9 if rp_ms > 0 else 0.0
-        b_total = sum(model.values())
-        # SURVEY.md 8(d)'s own byte model (what a literal 8-digit LSD pipeline moves: p_k = p_p = 8 passes,
-        # the reference's raw pair stream before dedup), evaluated on this run's N / M / P_raw / P
-        P_lit = st.get("raw_candidates", 0) or P_raw
-        survey = {"B_encode": 28.0 * n + 12.0 * M, "B_treesort": (8.0 + 24.0 * 8) * M, "B_scan": 12.0 * M + 8.0 * P_lit,
-                  "B_pairsort": (8.0 + 16.0 * 8) * P_lit, "B_dedup": 8.0 * P_lit + 8.0 * P}
-        survey_total = sum(survey.values())
         line = {
-            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if not (args.aabb_filter or args.pair_order != "global") else
-                      "VARIANT (not the headline metric): pairs left on the rank that found them (set-equal, unsorted across ranks)" if not args.aabb_filter else
-                      "VARIANT (not the headline metric): box-overlapping pairs/sec with the device AABB narrow phase fused into the scan",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if args.pair_order == "global" else
+                      "VARIANT (not the headline metric): pairs left on the rank that found them (set-equal, unsorted across ranks)",
+            "value": n_pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dM Index64_3D uniform-random AABBs per GPU (gen_boxes recipe, density 0.001, "
-                                   "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
-                                   % (n // 1_000_000) if n % 1_000_000 == 0 else "%d Index64_3D AABBs per GPU" % n,
-                       "objects_per_gpu": n, "objects_total": n_global, "entries": M, "raw_pairs": P_raw,
-                       "pairs_rank0": P, "pairs_total": n_pairs, "tree_sort_passes": pk, "pair_sort_passes": pp,
-                       "parallelism": "1 GPU" if world == 1 else "morton-range shards x%d, RCCL all-to-all" % world},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": per_launch_ms, "launches_per_step": dom_launches},
-            "roofline_radix_pass": {"bound": "hbm", "kernel": "radix_onesweep_kernel<u64,NoVal> (pair-sort pass)",
-                                    "achieved": rp_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": rp_achieved / HBM_PEAK_GBS, "bytes_per_launch": 16.0 * P_raw, "avg_launch_ms": rp_ms},
-            "step_model": {"bytes": b_total, "GBps": b_total / (ms_per_step * 1e-3) / 1e9,
-                           "frac_of_peak": b_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "bytes the kernels of THIS pipeline must move (digit skipping, partial sorts, duplicates "
-                                   "suppressed at the source already taken out)"},
-            "survey_model": dict(survey, raw_pairs_reference=P_lit, B_total=survey_total,
-                                 ms_at_peak=survey_total / (HBM_PEAK_GBS * 1e9) * 1e3,
-                                 frac_of_peak=survey_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 note="SURVEY.md 8(d) byte model of a literal 8-digit LSD pipeline on the same N/M/P; the step "
-                                      "beats it by moving fewer bytes, not by exceeding HBM bandwidth (see step_model)"),
-            # SURVEY 8(d) also asks for objects/s and for the sort+scan part alone (tree sort through dedup)
+            "config": {"workload": ("configs[3]: %d Index64_3D uniform-random AABBs in total over %d GPUs (gen_boxes recipe, sharded by "
+                                    "object index), per-GPU extend, Morton-range exchange, sort + scan, pair exchange by id range"
+                                    % (n_global, world)) if strong else
+                                   "%d Index64_3D uniform-random AABBs per GPU x %d GPUs (one %d-object scene)" % (n, world, n_global),
+                       "objects_per_gpu": n, "objects_total": n_global, "entries_rank0_shard": st["entries"], "pairs_rank0": n_pairs_local,
+                       "pairs_total": n_pairs, "parallelism": "morton-range shards x%d, RCCL all-to-all + all-gather of boundary keys" % world},
+            "roofline": None, "cpu_baseline": None,
             "objects_per_s": n_global / (dt / args.steps),
-            "sort_scan": {"ms_per_step": sum(per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist",
-                                                                      "pair_sort", "dedup")),
-                          "pairs_per_s": n_pairs / max(1e-12, 1e-3 * sum(per_step_ms[k] for k in (
-                              "tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist", "pair_sort", "dedup"))),
-                          # north_star's target: >= 50 % of the HBM roofline on sort+scan, where SURVEY 8(d) defines
-                          # B_sort+scan = B_treesort + B_scan (tree sort and scan proper, before the pair sort)
-                          "tree_sort_and_scan_ms": sum(per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit")),
-                          "survey_B_sort_scan": survey["B_treesort"] + survey["B_scan"],
-                          "survey_frac_of_peak": (survey["B_treesort"] + survey["B_scan"]) / max(1e-12, 1e-3 * sum(
-                              per_step_ms[k] for k in ("tree_hist", "tree_sort", "scan_count", "scan_emit"))) / 1e9 / HBM_PEAK_GBS,
-                          "note": "kernel time of tree sort + scan + pair sort + dedup in the per-class steps (see kernels_note); "
-                                  "survey_frac_of_peak prices SURVEY's model bytes, which this pipeline does not all move "
-                                  "(see step_model for the bytes it does)"},
-            "kernels": kernels,
-            "kernel_ms_per_step": per_step_ms,
-            "kernels_note": "per-class times from %d extra steps after the timed region with every class bracketed by HIP "
-                            "events (those steps run ~0.2 ms slower than ms_per_step); roofline.avg_launch_ms comes from "
-                            "events inside the timed region" % detail_steps,
+            "list_hash": [cnt, s1, s2],
+            "sharded": sharded.last,
         }
-        # HBM traffic per launch of the dominant kernel from the rocprofv3 PMC passes of the same
-        # command (profiles/traffic.json, written by profiles/summarize.py: 2 x FETCH_SIZE + WRITE_SIZE
-        # KiB, the guide's gfx950 correction); null when no such profile has been committed
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            key = {"scan_emit": "scan_expand_kernel", "dedup": "segment_finish_kernel"}.get(dom_cls, "radix_onesweep_kernel<u64, NoVal")
-            hit = [v for k, v in tj.get("bytes_per_launch", {}).items() if k.startswith(key)]
-            if hit and tj.get("objects") == n:
-                line["roofline"]["traffic"] = hit[0]
-                line["roofline"]["traffic_source"] = tj.get("source")
-        except (OSError, ValueError):
-            pass
-        if sharded_path:
-            line["sharded"] = sharded.last
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_objects, args.seed)
-        else:
-            line["cpu_baseline"] = None
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def single_gpu_line(args, r, np):
+    n, st, prof, steps = args.objects, r["stats"], r["prof"], args.steps
+    ms_per_step = r["ms_per_step"]
+    n_pairs = r["n_pairs"]
+    M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
+    pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
+    table = kernel_table(n, M, P_raw, P)
+    k = r["detail_steps"]
+    launches = {c: v[1] / k for c, v in prof.items()}
+    per_step_ms = {c: v[0] / k for c, v in prof.items()}
+    # SURVEY 8(d) bytes of each class per step = bytes per launch x launches (radix classes: one timed region per pass)
+    survey_step_bytes = {c: table[c][1] * (launches[c] if c in ("tree_sort", "pair_sort") else 1.0) for c in table}
+    kernels = {c: {"kernel": table[c][0], "ms_per_step": per_step_ms[c], "launches_per_step": launches[c],
+                   "survey_bytes_per_launch": table[c][1],
+                   "GBps": (survey_step_bytes[c] / (per_step_ms[c] * 1e-3) / 1e9) if per_step_ms[c] > 0 else 0.0,
+                   "frac_of_peak": (survey_step_bytes[c] / (per_step_ms[c] * 1e-3) / 1e9 / HBM_PEAK_GBS) if per_step_ms[c] > 0 else 0.0}
+               for c in table}
+    for c in prof:
+        if c not in kernels:
+            kernels[c] = {"ms_per_step": per_step_ms[c], "launches_per_step": launches[c]}
+    # dominant kernel: largest total time per step over ALL classes; its duration comes from HIP events on the layer's
+    # stream inside the timed region
+    dom_cls, dom_prof = r["dom_cls"], r["dom_prof"]
+    dom_name, bytes_per_launch = table[dom_cls]
+    per_launch_ms = dom_prof[0] / dom_prof[1] if dom_prof[1] else 0.0
+    achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    # bytes this pipeline really has to move per step (its own kernels' reads + writes)
+    moved = {
+        "encode": 28.0 * n + 4.0 * n + 12.0 * M,                 # bounds + ids read once, entries written (box code rides in the id)
+        "tree_sort": 24.0 * M * pk,
+        "tree_finish": 12.0 * M + 21.0 * M,                       # key + id read; key, id, box byte, {id, ctx} word written
+        "scan_emit": 16.0 * M + 8.0 * P_raw,                      # keys + {id, ctx} words read, packed pairs written
+        "pair_sort": 16.0 * P_raw * pp,
+        "dedup": 8.0 * P_raw + 8.0 * P,
+    }
+    moved_total = sum(moved.values())
+    ss_classes = ("tree_hist", "tree_sort", "tree_finish", "scan_count", "scan_emit")
+    ss_ms = sum(per_step_ms[c] for c in ss_classes)
+    ss_moved = moved["tree_sort"] + moved["tree_finish"] + moved["scan_emit"]
+    P_lit = st.get("raw_candidates", 0) or P_raw
+    survey = {"B_encode": 28.0 * n + 12.0 * M, "B_treesort": (8.0 + 24.0 * 8) * M, "B_scan": 12.0 * M + 8.0 * P_lit,
+              "B_pairsort": (8.0 + 16.0 * 8) * P_lit, "B_dedup": 8.0 * P_lit + 8.0 * P}
+    line = {
+        "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if not args.aabb_filter else
+                  "VARIANT (not the headline metric): box-overlapping pairs/sec with the device AABB narrow phase fused into the scan",
+        "value": n_pairs / (ms_per_step * 1e-3), "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": ("configs[2]: %dM Index64_3D uniform-random AABBs, single MI355X (gen_boxes recipe, density 0.001, "
+                                "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
+                                % (n // 1_000_000)) if n % 1_000_000 == 0 else "%d Index64_3D AABBs, single MI355X" % n,
+                   "objects": n, "entries": M, "raw_pairs": P_raw, "raw_candidates_examined": P_lit, "pairs": P,
+                   "tree_sort_passes": pk, "pair_sort_passes": pp, "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                     "avg_launch_ms": per_launch_ms, "launches_per_step": dom_prof[1] / steps if dom_prof[1] else 0.0,
+                     "chosen_by": "largest total time per step over all kernel classes (warm-up pass with every class timed)",
+                     "bytes_model": "SURVEY.md 8(d) per-unit figures x this run's N / M / P_raw / P"},
+        "cold_frame_ms": r["cold_frame_ms"], "first_frame_ms": r["first_frame_ms"], "cold_plan": r["cold_plan"],
+        "cold_note": "cold_frame_ms: buffers allocated, plan hints forgotten (the plan of a layer's first frame); first_frame_ms: a "
+                     "fresh layer, every hipMalloc included; ms_per_step: steady state (hints from the previous frame)",
+        "host_syncs_per_step": r["host_syncs_per_step"],
+        "step_moved": {"bytes": moved_total, "GBps": moved_total / (ms_per_step * 1e-3) / 1e9,
+                       "frac_of_peak": moved_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "reads + writes this pipeline's own kernels must make per step, over the whole step's wall time"},
+        # north_star's target is stated on sort+scan (tree sort through the scan, SURVEY 8(d) B_sort+scan); the headline
+        # fraction prices the bytes these kernels really move; the literal 8-digit model is kept as a secondary figure
+        "sort_scan": {"ms_per_step": ss_ms, "moved_bytes": ss_moved,
+                      "frac_of_peak": ss_moved / max(1e-12, ss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "survey_model_bytes": survey["B_treesort"] + survey["B_scan"],
+                      "survey_model_frac": (survey["B_treesort"] + survey["B_scan"]) / max(1e-12, ss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "frac_of_peak = bytes moved by tree-sort passes + finish + scan / their kernel time / 8 TB/s; "
+                              "survey_model_frac prices a literal 8-digit LSD sort (bytes this pipeline does not move: 2 + LDS finish "
+                              "instead of 8 passes) and is NOT a bandwidth figure"},
+        "survey_model": dict(survey, B_total=sum(survey.values()), note="SURVEY.md 8(d) byte model of a literal 8-digit pipeline on the "
+                             "same N / M / P (for reference only; see step_moved for the bytes really moved)"),
+        "objects_per_s": n / (ms_per_step * 1e-3),
+        "kernels": kernels,
+        "kernels_note": "per-class times from %d extra steps after the timed region with every class bracketed by HIP events (event "
+                        "pairs cost stream bubbles: these steps run slower than ms_per_step); roofline.avg_launch_ms comes from events "
+                        "inside the timed region" % k,
+    }
+    # HBM traffic per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
+    # (profiles/traffic.json, written by profiles/summarize.py with the guide's gfx950 corrections); null when absent
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = dom_name.split(" ")[0].split("<")[0]
+        want_noval = "NoVal" in dom_name
+        hit = [v for kk, v in tj.get("bytes_per_launch", {}).items()
+               if kk.startswith(key) and (("NoVal" in kk) == want_noval or "radix" not in key)]
+        if hit and tj.get("objects") == n:
+            line["roofline"]["traffic"] = hit[0]
+            line["roofline"]["traffic_source"] = tj.get("source")
+    except (OSError, ValueError):
+        pass
+    return line
 
 
 if __name__ == "__main__":

@@ -39,6 +39,7 @@ struct bp_layer {
     int device = 0;
     uint32_t min_depth = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t fence_ev = nullptr;   // bp_layer_wait_stream: orders this layer's stream after a producer's
 
     // persistent state: tree (src/layer.rs:49-50)
     DevBuf keys[2], ids[2];
@@ -648,7 +649,7 @@ int sort_tree(bp_layer* L) {
             const bool with_ctx = ride && !no_ctx_fuse;
             if (with_ctx) BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             {
-                ProfScope ps(L, BP_K_TREE_SORT);
+                ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
                                                 (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
                 HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
@@ -701,7 +702,7 @@ int sort_tree(bp_layer* L) {
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             {
-                ProfScope ps(L, BP_K_TREE_SORT);
+                ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tree_segment_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, L->m, seg_shift,
                                                       ride ? 1 : 0, (uint64_t*)L->keys[dst].p, (uint32_t*)L->ids[dst].p,
                                                       ride ? (uint8_t*)L->box[dst].p : nullptr, (DevScalars*)L->d_sc.p, L->stream));
@@ -713,7 +714,7 @@ int sort_tree(bp_layer* L) {
                 BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
                 BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
                 BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
-                ProfScope ps(L, BP_K_TREE_SORT);
+                ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[dst].p, L->m, gp.n_groups, gp.g0, gp.gshift,
                                                 (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
                 HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
@@ -1395,8 +1396,33 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
     free_host(L->h_shards); free_host(L->h_tstats);
+    if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
+    return BP_OK;
+}
+
+// Stream-ordering contract (include/bp_layer.h): the layer works on its own non-blocking stream, so device
+// inputs written by kernels still in flight on another stream must be fenced in explicitly.
+int bp_layer_wait_stream(bp_layer_t* L, void* producer_stream) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    DeviceGuard g(L->device);
+    if (!L->fence_ev) HIP_TRY(L, hipEventCreateWithFlags(&L->fence_ev, hipEventDisableTiming));
+    HIP_TRY(L, hipEventRecord(L->fence_ev, (hipStream_t)producer_stream));
+    HIP_TRY(L, hipStreamWaitEvent(L->stream, L->fence_ev, 0));
+    return BP_OK;
+}
+// forget what earlier sorts learned about the scene (grouped tree / pair finish hints and back-offs): the next frame
+// takes the plan of a layer's first frame.  Results never depend on the hints; only measurements need this.
+int bp_layer_reset_plan_hints(bp_layer_t* L) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
+    L->grp_next = false; L->grp_off = 0;
+    return BP_OK;
+}
+int bp_layer_stream(const bp_layer_t* L, void** stream) {
+    if (!L || !stream) return BP_ERR_INVALID_ARG;
+    *stream = (void*)L->stream;
     return BP_OK;
 }
 
@@ -1909,8 +1935,10 @@ int bp_layer_can_pack_box(const bp_layer_t* L, int* can) {
 
 int bp_layer_get_facts(const bp_layer_t* L, bp_facts* out) {
     if (!L || !out) return BP_ERR_INVALID_ARG;
-    out->key_or = L->key_or; out->key_and = L->key_and;
-    out->id_or = L->id_or; out->id_and = L->id_and;
+    // an empty layer reports neutral-but-representable AND fields (0 = "no bit is known to be set": a superset
+    // description, always safe) instead of the reductions' identities ~0, which do not survive a signed 64-bit wire
+    out->key_or = L->key_or; out->key_and = L->m ? L->key_and : 0ull;
+    out->id_or = L->id_or; out->id_and = L->m ? L->id_and : 0u;
     out->id_min = L->min_id; out->id_max = L->max_id;
     out->depth_mask = L->depth_mask;
     out->flags = (L->order_ok ? BP_FACT_ORDER_OK : 0u) | (L->ids_distinct ? BP_FACT_IDS_DISTINCT : 0u) |

@@ -49,6 +49,9 @@ def id_range_bounds(max_id, n_ranks):
     return np.array([min(span * (r + 1), 0xFFFFFFFF) for r in range(n_ranks - 1)], dtype=np.uint32)
 
 
+M64 = 0xFFFFFFFFFFFFFFFF
+
+
 def _varying_bits(lo, hi):
     """mask of the bits that can differ among integers in [lo, hi]"""
     if hi <= lo:
@@ -189,7 +192,9 @@ class TorchComm:
     def all_gather_counts(self, counts, backend):
         """every rank's count vector -> matrix C[src][k] (one small collective instead of one per exchange)"""
         torch, dist = self.torch, self.dist
-        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=self._small_device(backend))
+        # 64-bit fields (key OR / AND) travel as their two's-complement image: torch has no uint64 tensors to reduce
+        mine = torch.from_numpy(np.array([int(c) & 0xFFFFFFFFFFFFFFFF for c in counts], dtype=np.uint64).view(np.int64).copy()
+                                ).to(self._small_device(backend))
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         return torch.stack(parts).cpu().numpy()      # ONE device-to-host copy (a copy per part is a sync per rank)
@@ -335,7 +340,10 @@ class ShardedLayer:
         # codes into the ids, id ranges, OR/AND of keys and ids -- the receiving shard layers need no re-reduction
         lf = be.local_facts()
         can_pack = bool(lf["flags"] & 4)
-        fvec = [lf["key_or"], lf["key_and"], lf["id_or"], lf["id_and"], lf["id_min"], lf["id_max"], lf["depth_mask"], lf["flags"]]
+        # ... and its entry count: a rank without entries (no objects, or all of them outside the system bounds) must
+        # not take part in the AND / min / max reductions below
+        fvec = [lf["key_or"], lf["key_and"], lf["id_or"], lf["id_and"], lf["id_min"], lf["id_max"], lf["depth_mask"], lf["flags"],
+                int(hist.sum())]
         both = comm.all_gather_counts(list(hist) + fvec, be)
         hist_all = both[:, :len(hist)].sum(axis=0)
         lap("allgather_hist_facts")
@@ -343,7 +351,7 @@ class ShardedLayer:
         # 3. entries -> owners (fine), boundary keys -> everyone (coarse).  Packing must be decided
         #    before the partition, by every rank alike (from the gathered flags)
         fm = both[:, len(hist):]
-        nonempty = fm[:, 4] <= fm[:, 5]                                  # id_min <= id_max: the rank has entries
+        nonempty = fm[:, 8] > 0                                          # the rank has entries
         flags_all = fm[:, 7]
         pack = bool(np.all((flags_all[nonempty] & 4) != 0)) if nonempty.any() else False
         all_known = pack and bool(np.all((flags_all[nonempty] & 8) != 0))
@@ -370,10 +378,11 @@ class ShardedLayer:
         ne = np.flatnonzero(nonempty)
         ascending = bool(np.all(fm[ne[:-1], 5] < fm[ne[1:], 4])) if len(ne) > 1 else True
         facts = {
-            "key_or": int(np.bitwise_or.reduce(fm[:, 0])), "key_and": int(np.bitwise_and.reduce(fm[ne, 1])) if len(ne) else 0,
-            "id_or": int(np.bitwise_or.reduce(fm[:, 2])), "id_and": int(np.bitwise_and.reduce(fm[ne, 3])) if len(ne) else 0,
+            "key_or": int(np.bitwise_or.reduce(fm[ne, 0])) & M64 if len(ne) else 0,
+            "key_and": int(np.bitwise_and.reduce(fm[ne, 1])) & M64 if len(ne) else 0,
+            "id_or": int(np.bitwise_or.reduce(fm[ne, 2])) if len(ne) else 0, "id_and": int(np.bitwise_and.reduce(fm[ne, 3])) if len(ne) else 0,
             "id_min": int(fm[ne, 4].min()) if len(ne) else 0, "id_max": int(fm[ne, 5].max()) if len(ne) else 0,
-            "depth_mask": int(np.bitwise_or.reduce(fm[:, 6])),
+            "depth_mask": int(np.bitwise_or.reduce(fm[ne, 6])) if len(ne) else 0,
             "flags": (1 if (ascending and bool(np.all((flags_all[ne] & 1) != 0))) else 0)
                      | (2 if (ascending and bool(np.all((flags_all[ne] & 2) != 0))) else 0)
                      | (4 if pack else 0) | (8 if all_known else 0),

@@ -35,7 +35,7 @@ Index64_3D = _IndexKind("Index64_3D", 2, 3, 64, 5, 19)
 _KINDS = {0: Index32_2D, 1: Index64_2D, 2: Index64_3D}
 
 KERNEL_CLASSES = ("encode", "tree_hist", "tree_sort", "scan_count", "scan_emit", "pair_hist", "pair_sort",
-                  "dedup", "misc")
+                  "dedup", "misc", "tree_finish")
 
 
 class BroadphaseError(RuntimeError):
@@ -84,6 +84,7 @@ EXPORTS = [
     "bp_layer_sort_packed_device", "bp_layer_scan_filtered_aabb", "bp_layer_scan_filtered_aabb_device",
     "bp_layer_scan_filtered_sphere", "bp_layer_scan_filtered_sphere_device", "bp_layer_par_scan_shard_device", "bp_layer_sort_packed_range_device",
     "bp_layer_get_facts", "bp_layer_begin_entries", "bp_layer_commit_entries",
+    "bp_layer_wait_stream", "bp_layer_stream", "bp_layer_reset_plan_hints",
 ]
 
 
@@ -200,6 +201,9 @@ def load_library():
     for fn in (L.bp_layer_test_box_batch, L.bp_layer_test_box_batch_device, L.bp_layer_test_ray_batch,
                L.bp_layer_test_ray_batch_device):
         fn.argtypes = [vp, f32p, f32p, vp, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.bp_layer_reset_plan_hints.argtypes = [vp]
+    L.bp_layer_wait_stream.argtypes = [vp, vp]
+    L.bp_layer_stream.argtypes = [vp, C.POINTER(vp)]
     L.bp_layer_profile_select.argtypes = [vp, C.c_uint32]
     L.bp_layer_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
     for name in EXPORTS:
@@ -250,9 +254,14 @@ class DeviceArray:
         v = _View()
         signed = {4: "<i4", 8: "<i8"}[self.dtype.itemsize]
         v.__cuda_array_interface__ = {"shape": self.shape, "typestr": signed, "data": (self.ptr or 0, False), "version": 2}
+        # the OWNING layer's device, not torch's current one: a view on another device would silently be a copy
+        dev = torch.device("cuda", self._owner.device if self._owner is not None else torch.cuda.current_device())
         if int(np.prod(self.shape)) == 0:
-            return torch.empty(self.shape, dtype={4: torch.int32, 8: torch.int64}[self.dtype.itemsize], device="cuda")
-        return torch.as_tensor(v, device="cuda")
+            return torch.empty(self.shape, dtype={4: torch.int32, 8: torch.int64}[self.dtype.itemsize], device=dev)
+        t = torch.as_tensor(v, device=dev)
+        if t.data_ptr() != self.ptr:
+            raise BroadphaseError("BP_ERR_INVALID_ARG", "as_torch: torch made a copy instead of a zero-copy view")
+        return t
 
 
 class LayerBuilder:
@@ -317,6 +326,20 @@ class Layer:
             raise BroadphaseError(self._L.bp_status_string(rc).decode(),
                                   (self._L.bp_layer_last_error(self._h) or b"").decode())
 
+    def wait_stream(self, stream_handle):
+        """order the layer's work after everything enqueued so far on `stream_handle` (a hipStream_t as int; 0 = the
+        legacy default stream) -- the input side of the stream-ordering contract in include/bp_layer.h"""
+        self._check(self._L.bp_layer_wait_stream(self._h, C.c_void_p(int(stream_handle))))
+
+    def _fence(self, *objs):
+        """device tensors are read on the layer's own stream: fence it behind torch's current stream, where the
+        kernels producing those tensors may still be in flight"""
+        for o in objs:
+            if _is_device_tensor(o):
+                import torch
+                self.wait_stream(torch.cuda.current_stream(o.device).cuda_stream)
+                return
+
     # ---- reference methods ------------------------------------------------------------------------
     def clear(self):  # src/layer.rs:84-88
         self._check(self._L.bp_layer_clear(self._h))
@@ -335,6 +358,7 @@ class Layer:
                 raise ValueError("bounds must be f32 (n, 2*dim) and ids 32-bit (n,)")
             if not (bounds.is_contiguous() and ids.is_contiguous()):
                 raise ValueError("device tensors must be contiguous")
+            self._fence(bounds, ids)
             self._check(self._L.bp_layer_extend_device(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p),
                                                        C.c_void_p(bounds.data_ptr()), C.c_void_p(ids.data_ptr()), n))
             return
@@ -388,6 +412,7 @@ class Layer:
         if _is_device_tensor(bounds_by_id):
             if bounds_by_id.element_size() != 4 or not bounds_by_id.is_contiguous():
                 raise ValueError("bounds must be contiguous f32")
+            self._fence(bounds_by_id)
             return bounds_by_id.data_ptr(), int(bounds_by_id.numel()) // width, bounds_by_id
         b = np.ascontiguousarray(np.asarray(bounds_by_id, dtype=np.float32).reshape(-1, width))
         return b.ctypes.data, len(b), b
@@ -445,6 +470,7 @@ class Layer:
         if _is_device_tensor(rows):
             if rows.element_size() != 4 or not rows.is_contiguous():
                 raise ValueError("query rows must be contiguous f32")
+            self._fence(rows)
             return rows.data_ptr(), int(rows.numel()) // width, rows
         b = np.ascontiguousarray(np.asarray(rows, dtype=np.float32).reshape(-1, width))
         return b.ctypes.data, len(b), b
@@ -538,6 +564,7 @@ class Layer:
         return (DeviceArray(k.value, (m.value,), np.uint64, self), DeviceArray(i.value, (m.value,), np.uint32, self))
 
     def set_tree(self, min_depth, keys, ids, sorted_):
+        self._fence(keys, ids)
         if _is_device_tensor(keys):
             kp, ip, m = keys.data_ptr(), ids.data_ptr(), int(keys.numel())
         else:
@@ -547,6 +574,7 @@ class Layer:
         self._check(self._L.bp_layer_set_tree(self._h, min_depth, C.c_void_p(kp), C.c_void_p(ip), m, 1 if sorted_ else 0))
 
     def append_entries(self, keys, ids, count=None):
+        self._fence(keys, ids)
         if _is_device_tensor(keys):
             kp, ip, m = keys.data_ptr(), ids.data_ptr(), int(keys.numel())
         elif isinstance(keys, int):
@@ -698,6 +726,10 @@ class Layer:
         return {name: getattr(s, name) for name, _ in _Stats._fields_}
 
     # ---- measurement ------------------------------------------------------------------------------------
+    def reset_plan_hints(self):
+        """next frame = the plan of a layer's first frame (same results; for timing the cold plan)"""
+        self._check(self._L.bp_layer_reset_plan_hints(self._h))
+
     def profile_enable(self, on=True):
         self._check(self._L.bp_layer_profile_enable(self._h, 1 if on else 0))
 

@@ -56,6 +56,22 @@ def gen_boxes_powerlaw(count, seed=0, density=0.001, alpha=2.5, cap_frac=0.25):
     return sysb, bounds, np.arange(count, dtype=np.uint32)
 
 
+def gen_boxes_powerlaw_shard(count_global, rank, world, seed=0, density=0.001, alpha=2.5, cap_frac=0.25):
+    """Rank `rank`'s share of one global mixed-scale scene (configs[4]: power-law sizes, sharded by object index):
+    system bounds from the GLOBAL count, objects drawn independently per rank, ids [rank * n, (rank + 1) * n)."""
+    n = count_global // world
+    rng = np.random.Generator(np.random.PCG64([seed, rank, world, 4]))
+    linear = np.float32(np.cbrt(np.float32(count_global) / np.float32(density))) + np.float32(5.5)
+    u = rng.random(n, dtype=np.float32)
+    size = np.minimum((1.0 / np.maximum(1.0 - u, 1e-7)) ** (1.0 / alpha), cap_frac * linear).astype(np.float32)
+    size3 = np.repeat(size[:, None], 3, axis=1)
+    mn = (linear - size3) * rng.random((n, 3), dtype=np.float32)
+    mx = mn + size3
+    bounds = np.concatenate([mn, mx], axis=1).astype(np.float32)
+    sysb = np.array([[0, 0, 0], [linear, linear, linear]], dtype=np.float32)
+    return sysb, bounds, (np.arange(n, dtype=np.uint32) + np.uint32(rank * n))
+
+
 def gen_circles_2d(count, seed=0, width=1280.0, height=720.0):
     """BASELINE.json configs[0]: the example's scene (examples/main.rs:314, 415-417, 163-169):
     r = exp(U[0.5,2.0)), AABB = centre +- r, system bounds [-1, max(w,h)]^2, Index32_2D, min_depth 4."""

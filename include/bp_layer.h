@@ -11,6 +11,10 @@
  *     bp_layer_last_error() gives the detailed message of the last failure on a handle;
  *   - a handle is NOT thread-safe (it mirrors `&mut self`); each handle owns one HIP stream and
  *     all its device and pinned-host buffers; every call is complete when it returns;
+ *   - STREAM ORDERING: the handle's stream is non-blocking (it does not synchronise with the legacy default
+ *     stream).  Results are complete on return, so any stream may read them afterwards.  DEVICE INPUTS,
+ *     however, are read on the handle's stream: if kernels that write them may still be in flight on another
+ *     stream, call bp_layer_wait_stream(layer, that_stream) first (or synchronise that stream);
  *   - returned pointers are BORROWED: valid until the next mutating call on the same handle
  *     (the reference returns `&'a Vec<(ID, ID)>` tied to `&'a mut self`, src/layer.rs:449-451);
  *   - ID is u32.  Index values travel as u64 for every index kind (Index32_2D is zero-extended);
@@ -64,6 +68,14 @@ int bp_layer_destroy(bp_layer_t *layer);
 int bp_layer_clone(const bp_layer_t *layer, bp_layer_t **out);
 /* impl PartialEq (src/layer.rs:576-586): min_depth, entries in current order, sorted flag */
 int bp_layer_equals(const bp_layer_t *a, const bp_layer_t *b, int *equal);
+
+/* Orders everything the layer enqueues from now on after the work currently enqueued on `producer_stream`
+ * (a hipStream_t; NULL = the legacy default stream): event record on the producer + hipStreamWaitEvent on the
+ * layer's stream, no host wait.  Required before a call that takes device pointers whose contents are still
+ * being produced on another stream (see STREAM ORDERING above). */
+int bp_layer_wait_stream(bp_layer_t *layer, void *producer_stream);
+/* the layer's own hipStream_t (for callers that want to enqueue consumers behind it) */
+int bp_layer_stream(const bp_layer_t *layer, void **stream);
 
 /* ---- Layer methods on the hot path --------------------------------------------------------- */
 /* Layer::clear (src/layer.rs:84-88) */
@@ -293,7 +305,8 @@ typedef enum bp_kernel_class {
     BP_K_PAIR_SORT = 6,   /* onesweep radix passes over packed pairs      */
     BP_K_DEDUP = 7,       /* adjacent-unique flag/compact                 */
     BP_K_MISC = 8,        /* block-sum scans, memsets, small reductions   */
-    BP_K_COUNT = 9
+    BP_K_TREE_FINISH = 9, /* LDS finish of the partial tree sort (group bounds + finish kernels) */
+    BP_K_COUNT = 10
 } bp_kernel_class;
 int bp_layer_profile_enable(bp_layer_t *layer, int on);
 /* restrict the event pairs to the classes whose bit (1 << class) is set (default: all).  Every
@@ -302,6 +315,11 @@ int bp_layer_profile_select(bp_layer_t *layer, uint32_t class_mask);
 int bp_layer_profile_reset(bp_layer_t *layer);
 /* total device milliseconds and number of launches accumulated for one class */
 int bp_layer_profile_get(bp_layer_t *layer, int kernel_class, double *total_ms, uint64_t *launches);
+
+/* Kernel sequences are chosen from facts and from what earlier sorts on this handle learned about the scene
+ * ("plan hints": whether prefix groups fit LDS, ...).  This forgets the hints, so the next frame runs the plan of
+ * a handle's FIRST frame -- results are identical either way; bench.py uses it to time the cold plan. */
+int bp_layer_reset_plan_hints(bp_layer_t *layer);
 
 /* library version string, e.g. "broadphase_amd 0.1 gfx950" */
 const char *bp_version(void);

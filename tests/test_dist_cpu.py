@@ -64,7 +64,8 @@ class OracleBackend:
     def local_facts(self):
         keys, ids = self.local.keys, self.local.ids
         if len(keys) == 0:
-            return {"key_or": 0, "key_and": (1 << 63) - 1, "id_or": 0, "id_and": 0xFFFFFFFF, "id_min": 0xFFFFFFFF, "id_max": 0,
+            # what bp_layer_get_facts reports for an empty layer: neutral but representable AND fields
+            return {"key_or": 0, "key_and": 0, "id_or": 0, "id_and": 0, "id_min": 0xFFFFFFFF, "id_max": 0,
                     "depth_mask": 0, "flags": 3}
         asc = bool(np.all(np.diff(ids.astype(np.int64)) >= 0))
         return {"key_or": int(np.bitwise_or.reduce(keys)), "key_and": int(np.bitwise_and.reduce(keys)),
@@ -147,14 +148,27 @@ def _scene(world, n_per_rank, seed, with_giants):
     return parts
 
 
-def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q, pair_order="global"):
+def _emptied(parts, empty):
+    """empty = {rank: "none" | "oob"}: that rank extends nothing / only objects outside the system bounds"""
+    out = []
+    for r, (sysb, b, ids) in enumerate(parts):
+        mode = (empty or {}).get(r)
+        if mode == "none":
+            b, ids = b[:0], ids[:0]
+        elif mode == "oob":
+            b = b + np.float32(4.0) * np.float32(sysb[1][0])     # every box beyond the system bounds: skipped silently
+        out.append((sysb, b, ids))
+    return out
+
+
+def _worker(rank, world, port, n_per_rank, seed, with_giants, split_depth, q, pair_order="global", empty=None):
     if split_depth == 2:
         os.environ["BP_DIST_CHUNK_BYTES"] = "4096"   # force the multi-round (chunked) exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        parts = _scene(world, n_per_rank, seed, with_giants)
+        parts = _emptied(_scene(world, n_per_rank, seed, with_giants), empty)
         sysb, bounds, ids = parts[rank]
         lay = ShardedLayer(Index64_3D, 0, n_global=None, split_depth=split_depth, backend=OracleBackend(2, 0), pair_order=pair_order)
         for _round in range(2):  # reuse across "frames"
@@ -208,6 +222,36 @@ def test_sharded_pipeline_equals_single_process(world, n_per_rank, with_giants, 
         lo, hi = results[r][1]["id_range"]
         o = results[r][0]
         assert len(o) == 0 or (o[:, 0].min() >= lo and o[:, 0].max() <= hi)
+
+
+@pytest.mark.parametrize("world,empty,split_depth", [(3, {1: "none"}, 3), (2, {0: "oob"}, 2), (3, {0: "none", 2: "oob"}, 2)])
+def test_sharded_pipeline_with_ranks_that_hold_no_entries(world, empty, split_depth):
+    """a rank with no objects, or with every object outside the system bounds, contributes neutral facts and empty
+    exchanges; split_depth 2 also forces the chunked multi-round exchange (such a rank used to crash on
+    key_and = 2^64 - 1 and hang the others)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 1500, 11, True, split_depth, q, "global", empty)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, out, info = q.get(timeout=180)
+        results[rank] = (out, info)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts = _emptied(_scene(world, 1500, 11, True), empty)
+    ref = oracle.OracleLayer(2, 0)
+    for sysb, b, ids in parts:
+        ref.extend(sysb, b, ids)
+    expect = ref.scan()
+    assert len(expect) > 0
+    got = np.concatenate([results[r][0].reshape(-1, 2) for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    for r, mode in empty.items():
+        assert results[r][1]["entries_local"] == 0
 
 
 def test_owner_table_is_contiguous_and_balanced():

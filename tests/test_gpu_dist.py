@@ -75,6 +75,87 @@ def _giants(parts, world):
         b[2] = [0.3 * L, 0.3 * L, 0.3 * L, 0.62 * L, 0.62 * L, 0.62 * L]
 
 
+def _run_rank_threads(parts, world, frames=1, pair_order="global", n_global=None):
+    """one ShardedLayer per rank-thread on the same GPU (real kernels, ThreadComm exchanges) -> [(pairs, last, stats)]"""
+    import torch
+    torch.cuda.init()
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lay = ShardedLayer(bp.Index64_3D, 0, device=0, backend=HipBackend(bp.Index64_3D, 0, 0), comm=ThreadComm(shared, rank),
+                               pair_order=pair_order, n_global=n_global)
+            sysb, bounds, ids = parts[rank]
+            d_b, d_i = torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda()
+            for _frame in range(frames):
+                lay.clear()
+                lay.extend(sysb, d_b, d_i)
+                out = lay.par_scan()
+            results[rank] = (out, lay.last, lay.shard_layer.stats())
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    return results
+
+
+def _oracle_pairs(parts):
+    ref = oracle.OracleLayer(2, 0)
+    for sysb, b, ids in parts:
+        ref.extend(sysb, b, ids)
+    return ref.par_scan()
+
+
+@pytest.mark.parametrize("world,n_total,alpha", [(4, 200000, 1.5), (8, 240000, 2.5), (8, 200000, 1.5)])
+def test_rank_threads_powerlaw_scene_matches_the_oracle(world, n_total, alpha):
+    """configs[4]'s shape at test size: mixed-scale (power-law) boxes sharded over 4 / 8 ranks.  The heavy tail is the
+    boundary-key all-gather's real load: every box coarser than split_depth is replicated on every rank."""
+    parts = [scenes.gen_boxes_powerlaw_shard(n_total, r, world, seed=21, alpha=alpha) for r in range(world)]
+    results = _run_rank_threads(parts, world, frames=2)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    coarse = [results[r][1]["coarse"] for r in range(world)]
+    assert len(set(coarse)) == 1 and coarse[0] > 50 * world     # a real heavy tail, the same on every rank
+    for r in range(world):
+        assert results[r][2]["flags"] == 3
+
+
+def test_rank_threads_world8_at_the_true_per_gpu_share_of_10m():
+    """BASELINE configs[3] as stated: 10 M Index64_3D objects in total over 8 ranks (1.25 M each), every rank's slice of
+    the pair list compared with the oracle's list of the union scene"""
+    world, n_total = 8, 10_000_000
+    parts = [scenes.gen_boxes_shard(n_total, r, world, seed=0) for r in range(world)]
+    results = _run_rank_threads(parts, world, frames=1, n_global=n_total)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    loads = [results[r][1]["entries_shard"] for r in range(world)]
+    assert max(loads) < 1.2 * (sum(loads) / world)
+
+
+@pytest.mark.parametrize("world,empty", [(3, {1: "none"}), (3, {0: "oob", 2: "none"})])
+def test_rank_threads_with_ranks_that_hold_no_entries(world, empty):
+    parts = [scenes.gen_boxes_shard(world * 30000, r, world, seed=13) for r in range(world)]
+    _giants(parts, world)
+    for r, mode in empty.items():
+        sysb, b, ids = parts[r]
+        parts[r] = (sysb, b[:0], ids[:0]) if mode == "none" else (sysb, b + np.float32(4.0) * np.float32(sysb[1][0]), ids)
+    results = _run_rank_threads(parts, world, frames=2)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([np.asarray(results[r][0]).reshape(-1, 2) for r in range(world)], axis=0)
+    assert len(expect) > 0 and got.shape == expect.shape and np.array_equal(got, expect)
+    for r in empty:
+        assert results[r][1]["entries_local"] == 0
+
+
 @pytest.mark.parametrize("world,n_per_rank,giants", [(2, 40000, True), (4, 25000, True), (3, 30000, False)])
 def test_rank_threads_on_one_gpu_match_the_oracle(world, n_per_rank, giants):
     import torch

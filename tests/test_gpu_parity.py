@@ -291,6 +291,56 @@ def test_ten_million_boxes_properties():
     assert_pairs_equal(pairs, exp, "10M scan")
 
 
+def test_ten_million_steady_state_frames_match_the_oracle():
+    """The kernel sequence bench.py times: >= 3 frames of clear -> extend -> par_sort -> par_scan on ONE layer with
+    device-resident inputs.  From the second frame on the plan hints are active (grouped tree finish after 2 radix
+    passes, context words written by the finish, grouped pair finish after 2 passes); the LAST frame's tree and
+    pair list are compared with the oracle element by element (tests/test_layer.rs:74-124 at BASELINE size)."""
+    import torch
+    sysb, bounds, ids = scenes.gen_boxes(10_000_000, seed=0)
+    d_b = torch.from_numpy(bounds).cuda()
+    d_i = torch.from_numpy(ids.view(np.int32)).cuda()
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    passes = []
+    for _frame in range(3):
+        gpu.clear()
+        gpu.extend(sysb, d_b, d_i)
+        gpu.par_sort()
+        out = gpu.scan_device()
+        st = gpu.stats()
+        passes.append((st["tree_sort_passes"], st["pair_sort_passes"]))
+    assert passes[0][0] == 3, passes                       # cold plan: 3 passes + tree_segment_finish
+    assert passes[-1] == (2, 2), passes                    # the plan BENCH reports
+    ref = oracle.OracleLayer(2, 0)
+    ref.extend(sysb, bounds, ids)
+    ref.par_sort()
+    assert_tree_equal(gpu, ref, "10M steady-state tree")
+    assert_pairs_equal(out.to_numpy(), ref.par_scan(), "10M steady-state pairs")
+    assert st["pairs"] == st["raw_pairs"]                  # duplicates were suppressed at the source
+
+
+def test_extend_waits_for_the_torch_stream_that_produces_its_inputs():
+    """the layer runs on its own non-blocking stream; device tensors still being written by torch kernels
+    must be fenced in (Layer._fence -> bp_layer_wait_stream), not read early"""
+    import torch
+    sysb, bounds, ids = scenes.gen_boxes(400000, seed=5)
+    base = torch.from_numpy(bounds).cuda()
+    ti = torch.from_numpy(ids.view(np.int32)).cuda()
+    junk = torch.full_like(base, float("nan"))
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    gpu, ref = both(2)
+    ref.extend(sysb, bounds, ids)
+    for _ in range(3):
+        tb = junk.clone()
+        for _k in range(6):
+            big = (big @ big).clamp_(-1, 1)               # keeps torch's stream busy for a while ...
+        tb.copy_(base)                                     # ... before the real bounds land in tb
+        gpu.clear()
+        gpu.extend(sysb, tb, ti)                           # no torch.cuda.synchronize() in between
+        assert_tree_equal(gpu, ref, "extend behind a busy torch stream")
+
+
 def test_cpp_facade_binary():
     """include/broadphase/layer.hpp (the C++ mirror of Layer/LayerBuilder) over the C ABI"""
     import os
