@@ -123,7 +123,8 @@ def test_rank_threads_powerlaw_scene_matches_the_oracle(world, n_total, alpha):
     got = np.concatenate([results[r][0] for r in range(world)], axis=0)
     assert got.shape == expect.shape and np.array_equal(got, expect)
     coarse = [results[r][1]["coarse"] for r in range(world)]
-    assert len(set(coarse)) == 1 and coarse[0] > 50 * world     # a real heavy tail, the same on every rank
+    # the same boundary keys on every rank; alpha = 1.5 gives a real heavy tail (hundreds of boxes coarser than split_depth)
+    assert len(set(coarse)) == 1 and coarse[0] > (400 if alpha < 2.0 else 0)
     for r in range(world):
         assert results[r][2]["flags"] == 3
 
