@@ -1197,38 +1197,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 // Ranges of SX_BIG or more candidates (large objects) are cut into slices on a work list and
 // spread over the whole grid by scan_expand_big_kernel.
 // =================================================================================================
-// Per-entry word: id << 32 | ctx.  ctx packs what BoxCtx needs for a candidate test:
-//   bits  0..14  g_axis = depth - (trailing count), 5 bits per axis: the box's other cell on that axis
-//                leaves the ancestor cell of depth dd  <=>  dd >= g_axis
-//   bits 15..21  BoxCtx::table >> 1 (bit 0 of the table is never set)
-//   bits 22..27  box code (0 when unknown: own cell only)
-//   bit  28      entry takes no part as the deeper side (shard scans: coarse entry)
-//   bits 29..31  BoxCtx::two
-constexpr u32 CTX_INACTIVE = 1u << 28;
-// ids that may repeat (GEN modes below): the context carries no suppression data, bit 27 marks an entry the
+// Per-entry word: id << 32 | ctx.  ctx packs what the candidate test needs, laid out so that the test is a dozen
+// full-rate VALU instructions on whole words (no per-axis field extraction):
+//   byte a = 0, 1, 2 (one per axis):  bits 0..4  g_a = depth - (trailing count): the box's other cell on axis a leaves
+//                                                the ancestor cell of depth dd  <=>  dd >= g_a   (0 when the axis has one cell)
+//                                     bit  5     always 0 (the borrow guard of the byte-wise subtraction below;
+//                                                byte 0's bit 5 is CTX_SKIPPED in the repeated-id modes)
+//                                     bits 6..7  t_a = this entry's box code on the axis (0 one cell, 1 lower, 2 upper of two)
+//   byte 3:  table'' -- bit k (k = 3-bit set of axes on which the other cell is NOT inside the ancestor's box) set <=> the
+//            pair is emitted by an earlier cell of this object (suppressed).  Axes with one cell are don't-cares of the
+//            table, so the test needs no `two` mask.  0xFF: the entry takes no part as the deeper side (CTX_INACTIVE:
+//            a legitimate table never has bit 7 set -- with every other cell outside nothing can be earlier).
+// The ancestor (owner) side supplies two words: DJ = (dd | 32) in each of the three low bytes and CBJ = its own t fields
+// (= its ctx & CTX_CODE_MASK).
+constexpr u32 CTX_INACTIVE = 0xFF000000u;
+constexpr u32 CTX_G_MASK = 0x001F1F1Fu, CTX_GUARD = 0x00202020u, CTX_CODE_MASK = 0x00C0C0C0u;
+// ids that may repeat (GEN modes below): the context carries no suppression data (table'' = 0), bit 5 marks an entry the
 // reference's skip rule drops entirely (some ancestor carries the same id, src/layer.rs:563-565)
-constexpr u32 CTX_SKIPPED = 1u << 27;
+constexpr u32 CTX_SKIPPED = 1u << 5;
 template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 code, u32 inactive_below) {
     BoxCtx<KIND> bx;
     bx.init(key, code);
     const u32 d = bx.depth;
-    const u32 g0 = d - (bx.thr & 0xFFu), g1 = d - ((bx.thr >> 8) & 0xFFu), g2 = d - ((bx.thr >> 16) & 0xFFu);
-    u32 c = g0 | (g1 << 5) | (g2 << 10) | ((bx.table >> 1) << 15) | (bx.two << 29);
-    if (code != BOX_UNKNOWN) c |= (code & 63u) << 22;
-    if (d < inactive_below) c |= CTX_INACTIVE;
-    return c;
+    // the code always travels: every entry also acts as an ancestor, whatever its own role as the deeper side
+    const u32 cb = code == BOX_UNKNOWN ? 0u : code;
+    const u32 codebits = ((cb & 3u) << 6) | (((cb >> 2) & 3u) << 14) | (((cb >> 4) & 3u) << 22);
+    if (d < inactive_below) return CTX_INACTIVE | codebits;
+    if (code == BOX_UNKNOWN || bx.table == 0) return codebits;  // nothing is ever suppressed
+    const u32 two = bx.two;
+    const u32 g0 = (two & 1u) ? d - (bx.thr & 0xFFu) : 0u, g1 = (two & 2u) ? d - ((bx.thr >> 8) & 0xFFu) : 0u,
+              g2 = (two & 4u) ? d - ((bx.thr >> 16) & 0xFFu) : 0u;
+    // table''[k] = table[(~k & 7) & two]
+    u32 t2 = 0;
+#pragma unroll
+    for (u32 k = 0; k < 8; ++k) t2 |= ((bx.table >> ((~k & 7u) & two)) & 1u) << k;
+    return g0 | (g1 << 8) | (g2 << 16) | codebits | (t2 << 24);
 }
-// is candidate (entry i with context ctx_i, ancestor j of depth dd with box code cb_j) the emitting combo?
-__device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 cb_j, u32 dd) {
-    if (ctx_i & CTX_INACTIVE) return false;
-    const u32 table = ((ctx_i >> 15) & 0x7Fu) << 1;
-    if (table == 0) return true;
-    const u32 cr = (dd >= (ctx_i & 31u) ? 1u : 0u) | (dd >= ((ctx_i >> 5) & 31u) ? 2u : 0u) | (dd >= ((ctx_i >> 10) & 31u) ? 4u : 0u);
-    const u32 x = cb_j ^ ((ctx_i >> 22) & 63u);            // axes with two cells: code == needpat
-    const u32 mm = ~(x | (x >> 1)) & 0x15u;
-    const u32 match = (mm & 1u) | ((mm >> 1) & 2u) | ((mm >> 2) & 4u);
-    const u32 inside = (~cr | match) & (ctx_i >> 29);
-    return ((table >> inside) & 1u) == 0;
+// owner-side words of an ancestor entry of depth dd whose own context word is ctx_j
+__device__ __forceinline__ u32 ctx_owner_dj(u32 dd) { return (dd | 32u) * 0x010101u; }
+__device__ __forceinline__ u32 ctx_owner_cbj(u32 ctx_j) { return ctx_j & CTX_CODE_MASK; }
+// is candidate (entry i with context ctx_i, ancestor j described by dj / cbj) the emitting combo?
+__device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 dj, u32 cbj) {
+    const u32 t = dj - (ctx_i & CTX_G_MASK);      // per byte dd + 32 - g_a >= 1: no borrow; bit 5 <=> dd >= g_a (crossing)
+    const u32 x = ctx_i ^ cbj;                    // bits 6..7 of each byte: zero <=> the ancestor's box covers the other cell
+    const u32 y = (x >> 1) | (x >> 2);            // bit 5 of each byte: code mismatch
+    const u32 v = t & y & CTX_GUARD;              // bit 5 of byte a: the other cell on axis a is NOT inside the ancestor's box
+    // gather bits 5, 13, 21 into a 3-bit index: 24-bit multiply (full rate), products land on bits 21, 22, 23 with no carries
+    const u32 idx = (__umul24(v, (1u << 16) | (1u << 9) | (1u << 2)) >> 21) & 7u;
+    return ((ctx_i >> (24u + idx)) & 1u) == 0u;
 }
 
 template <int KIND>
@@ -1402,56 +1418,78 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #ifndef SX_WAVES_PER_EU
 #define SX_WAVES_PER_EU 0
 #endif
-#ifndef SX_LDS_WINDOW
-#define SX_LDS_WINDOW 1
-#endif
 #if SX_WAVES_PER_EU
 #define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SX_WAVES_PER_EU, SX_WAVES_PER_EU)))
 #else
 #define SX_OCC_ATTR
 #endif
+constexpr u32 SX_WIN = 128;  // entries of a chunk's LDS windows: the wave's 64 and the 64 that follow
 // GEN = 0: ids distinct, duplicates suppressed at the source (the default).
 // GEN = 1: ids may repeat, MARK pass: every candidate whose id equals its ancestor's gets CTX_SKIPPED (nothing is emitted).
 // GEN = 2: ids may repeat, EMIT pass: every combo of two unskipped entries (the reference's raw stream as a set).
+//
+// The kernel is bound by the latency chains of a chunk, not by issue slots or bytes (profiles/r01: VALU ~1/3 busy at 6
+// waves per SIMD, 18 k cycles per 64-entry chunk), so everything a chunk waits for is either fetched one chunk ahead or
+// served from LDS: (1) the chunk's four global loads -- 128 keys and 128 {id, context} words -- are issued a whole
+// chunk before they are used (register prefetch across the persistent loop); (2) both 128-entry windows go to LDS:
+// the range ends are bisected in the key window, and a candidate's {id, context} word comes from the word window
+// (nearly every range ends within the 64 entries after its owner) -- only a candidate beyond the window is a global load.
 template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
     constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
     __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
-    // owners with a non-empty range, compacted: {first candidate, id, code | depth << 8, lane}; the same storage holds
+    // owners with a non-empty range, compacted: {first candidate, id, DJ, CBJ | lane << 24}; the same storage holds
     // the wave's key window while the range ends are searched (a union, so the compiler knows the two views alias)
-    union RecWin { uint4 rec[64]; u64 win[128]; };
+    union RecWin { uint4 rec[64]; u64 win[SX_WIN]; };
     __shared__ RecWin s_recwin[SX_WAVES];
+    __shared__ u64 s_cwin[SX_WAVES][SX_WIN];  // {id, context} words of the entries [base, base + SX_WIN)
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
     sx_hist_clear(s_hist, p);
     const int w = (int)(threadIdx.x >> 6), lane = lane_id();
     uint4* const s_rec_w = s_recwin[w].rec;
+    u64* const win = s_recwin[w].win;
+    u64* const cwin = s_cwin[w];
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
     WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     const u64 le_lane = (2ull << lane) - 1ull;  // bits 0..lane
-    for (size_t base = (size_t)gw * 64; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
+    // a chunk's global loads (clamped addresses: every load is unconditional, validity is decided at use)
+    struct Pre { u64 k0, k1, w0, w1; };
+    auto prefetch = [&](size_t base) -> Pre {
+        const size_t last = p.m - 1;
+        const size_t a = base + (size_t)lane, b = a + 64;
+        Pre r;
+        r.k0 = p.keys[a < last ? a : last];
+        r.k1 = p.keys[b < last ? b : last];
+        r.w0 = p.idctx[a < last ? a : last];
+        r.w1 = p.idctx[b < last ? b : last];
+        return r;
+    };
+    size_t base = (size_t)gw * 64;
+    Pre cur_pre{};
+    if (base < p.m) cur_pre = prefetch(base);
+    for (; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
+        const Pre pre = cur_pre;
+        const size_t nbase = base + (size_t)p.n_waves * 64;
+        if (nbase < p.m) cur_pre = prefetch(nbase);  // the NEXT chunk's loads fly while this chunk is processed
         const u32 j = (u32)base + (u32)lane;
-        u32 c = 0, idj = 0, cbdd = 0;
-#if SX_LDS_WINDOW
-        // Most ranges end within the next few dozen entries: the wave puts its 64 keys and the 64 after them in LDS
-        // (aliasing s_rec, which is filled only afterwards) and every lane bisects there -- 7 LDS reads instead of a
-        // chain of dependent global loads.  Only a range that leaves the window continues in HBM.
-        u64* const win = s_recwin[w].win;
-        const u64 key = j < m ? p.keys[j] : ~0ull;
-        {
-            const u64 j2 = (u64)j + 64u;
-            win[lane] = key;
-            win[64 + lane] = j2 < p.m ? p.keys[j2] : ~0ull;
-        }
+        const bool in0 = (size_t)j < p.m, in1 = (size_t)j + 64u < p.m;
+        const u64 key = in0 ? pre.k0 : ~0ull;
+        win[lane] = key;
+        win[64 + lane] = in1 ? pre.k1 : ~0ull;
+        cwin[lane] = pre.w0;
+        cwin[64 + lane] = pre.w1;
         __builtin_amdgcn_wave_barrier();
-        if (j < m) {
-            const u64 wj = p.idctx[j];
+        u32 c = 0, idj = 0, dj = 0, cbj = 0;
+        if (in0) {
+            const u64 wj = pre.w0;
             idj = (u32)(wj >> 32);
-            cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
+            dj = ctx_owner_dj(key_depth<KIND>(key));
+            cbj = ctx_owner_cbj((u32)wj);
             const u64 upper = cell_upper<KIND>(key);
-            u32 lo = (u32)lane, hi = 128u;  // win[lo] < upper <= win[hi] (hi == 128: not in the window)
+            u32 lo = (u32)lane, hi = SX_WIN;  // win[lo] < upper <= win[hi] (hi == SX_WIN: not in the window)
 #pragma unroll
             for (int it = 0; it < 7; ++it) {
                 const u32 mid = (lo + hi) >> 1;  // <= 127: the read is unconditional (no branch per step)
@@ -1461,19 +1499,10 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 lo = ge ? lo : mid;  // mid == lo leaves lo unchanged as well
             }
             u32 end;
-            if (hi < 128u) end = (u32)base + hi;
-            else if ((u64)base + 128u >= p.m) end = m;
-            else end = range_end(p.keys, m, (u32)base + 127u, upper);
+            if (hi < SX_WIN) end = (u32)base + hi;
+            else if ((u64)base + SX_WIN >= p.m) end = m;
+            else end = range_end(p.keys, m, (u32)base + SX_WIN - 1u, upper);
             c = end - j - 1u;
-#else
-        if (j < m) {
-            const u64 key = p.keys[j];
-            const u64 wj = p.idctx[j];
-            idj = (u32)(wj >> 32);
-            cbdd = (((u32)wj >> 22) & 63u) | (key_depth<KIND>(key) << 8);
-            const u32 end = range_end(p.keys, m, j, cell_upper<KIND>(key));
-            c = end - j - 1u;
-#endif
             if (GEN == 2 && ((u32)wj & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
             if (c >= SX_BIG) {
                 const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
@@ -1497,7 +1526,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
         // popcount and one 16-byte LDS read per lane -- no per-candidate search.
         st.examined += total;
-        if (c > 0) s_rec_w[__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, cbdd, (u32)lane);
+        if (c > 0) s_rec_w[__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, dj, cbj | ((u32)lane << 24));
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
             s_ends[w][lane] = 0ull;
@@ -1508,8 +1537,8 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             __builtin_amdgcn_wave_barrier();
             const u32 left = total - ss;
             const u32 n_steps = left >= SUPER ? 64u : (left + 63u) >> 6;
-            // software pipeline: the {id, context} load of step b + 1 is in flight while step b is tested and pushed
-            struct Cand { u64 wi; u32 idj, cbdd, i; bool act; };
+            // software pipeline: the {id, context} read of step b + 1 is in flight while step b is tested and pushed
+            struct Cand { u64 wi; u32 idj, dj, cbj, i; bool act; };
             auto fetch = [&](u32 b) -> Cand {
                 const u64 e = uniform_u64(s_ends[w][b]);
                 const u32 k = ss + b * 64u + (u32)lane;
@@ -1518,8 +1547,12 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 owners_done += (u32)__popcll(e);
                 if (!act) ord = n_nz - 1u;
                 const uint4 r = s_rec_w[ord];
-                const u32 i = (u32)base + r.w + 1u + ((act ? k : total - 1u) - r.x);
-                return Cand{p.idctx[i], r.y, r.z, i, act};
+                const u32 off = (r.w >> 24) + 1u + ((act ? k : total - 1u) - r.x);   // candidate = entry base + off
+                u64 wi = cwin[off < SX_WIN ? off : SX_WIN - 1u];
+                if (__any(off >= SX_WIN)) {  // a range that leaves the window (rare): those lanes read HBM
+                    if (off >= SX_WIN) wi = p.idctx[base + off];
+                }
+                return Cand{wi, r.y, r.z, r.w & CTX_CODE_MASK, (u32)base + off, act};
             };
             Cand cur = fetch(0);
             for (u32 b = 0; b < n_steps; ++b) {
@@ -1531,7 +1564,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     cur = nxt;
                     continue;
                 }
-                bool keep = cur.act && ctx_keep((u32)cur.wi, cur.cbdd & 63u, cur.cbdd >> 8);
+                bool keep = cur.act && ctx_keep((u32)cur.wi, cur.dj, cur.cbj);
                 if (GEN == 2) keep = keep && !((u32)cur.wi & CTX_SKIPPED);
                 if (FILT && keep)
                     keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * filt_stride<FDIM>(p.filt_shape),
@@ -1571,7 +1604,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
         if (threadIdx.x == 0) s_end = range_end(p.keys, m, j, cell_upper<KIND>(key));
         __syncthreads();
         const u32 end = s_end;
-        const u32 idj = (u32)(wj >> 32), cb = ((u32)wj >> 22) & 63u, dd = key_depth<KIND>(key);
+        const u32 idj = (u32)(wj >> 32), dj = ctx_owner_dj(key_depth<KIND>(key)), cbj = ctx_owner_cbj((u32)wj);
         const u64 first = (u64)j + 1u + (u64)slice * SX_BIG;
         const u64 last = min(first + SX_BIG, (u64)end);
         if (w == 0 && last > first) st.examined += last - first;
@@ -1585,7 +1618,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
                     if ((u32)(wi >> 32) == idj && !((u32)wi & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + i, (u64)CTX_SKIPPED);
                     continue;
                 }
-                keep = ctx_keep((u32)wi, cb, dd);
+                keep = ctx_keep((u32)wi, dj, cbj);
                 if (GEN == 2) keep = keep && !((u32)wi & CTX_SKIPPED);
                 if (FILT && keep)
                     keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * filt_stride<FDIM>(p.filt_shape),
