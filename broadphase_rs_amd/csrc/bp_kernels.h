@@ -101,7 +101,10 @@ hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* id
 // ---- radix sort (K4, K7): stands in for par_sort_unstable, src/layer.rs:149,516 ---------------
 constexpr int RS_BINS = 256;
 constexpr int RS_MAX_PASSES = 12;
-constexpr int SX_HIST_MAX = 4;      // digit histograms a producer kernel (encode, scan) can count for the sort that follows
+#ifndef SX_HIST_MAX_DEF
+#define SX_HIST_MAX_DEF 4
+#endif
+constexpr int SX_HIST_MAX = SX_HIST_MAX_DEF;      // digit histograms a producer kernel (encode, scan) can count for the sort that follows
 
 struct RadixPlan {
     int n_passes;

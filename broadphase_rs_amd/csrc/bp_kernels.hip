@@ -1283,6 +1283,7 @@ struct ExpandParams {
     u64* hist;
     int hist_passes;
     int hist_shift[SX_HIST_MAX];
+    int hist_all_hi;   // every counted digit lies in the pair's high dword (shift >= 32): 32-bit digit extraction
     // multi-GPU: instead, count the pairs per OWNER of the first id (owner_n >= 0: bounds[i] = first id of rank
     // i + 1, as PairOwnerDigit) into row 0 of hist -- the bucketing pass that follows then needs no histogram read
     int owner_n;
@@ -1298,6 +1299,14 @@ __device__ __forceinline__ u32 range_end(const u64* __restrict__ keys, u32 m, u3
         const u64 pos = (u64)j + (1u << k);
         const u64 v = keys[pos < m ? pos : (u64)m - 1u];
         pv[k] = pos < m ? v : ~0ull;
+    }
+    // every probe is consumed HERE: a probe left unread on some path stays "pending" for the compiler, which then
+    // waits for ALL outstanding loads (the caller's cross-chunk prefetch included) wherever its register is reused
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        u32 a = (u32)pv[k], b = (u32)(pv[k] >> 32);
+        asm volatile("" : "+v"(a), "+v"(b));
+        pv[k] = ((u64)b << 32) | a;
     }
     u32 lo = j, hi = 0;
     bool found = false;
@@ -1369,6 +1378,24 @@ struct WaveStage {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    template <bool OWNER>
+    __device__ __forceinline__ void count(u64 pair, const ExpandParams& p) {
+        const u32 first = (u32)(pair >> 32);
+#pragma unroll
+        for (int q = 0; q < SX_HIST_MAX; ++q) {
+            if (q < p.hist_passes) {
+                // wave-uniform choice: digits of the first id come out of the high dword with 32-bit shifts
+                const u32 dg = p.hist_all_hi ? (first >> (p.hist_shift[q] - 32)) & 255u : (u32)(pair >> p.hist_shift[q]) & 255u;
+                __hip_atomic_fetch_add(&hist[q * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (OWNER) {
+            u32 o = 0;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) o += (i < p.owner_n && first >= p.owner_bounds[i]) ? 1u : 0u;
+            __hip_atomic_fetch_add(&hist[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     template <bool OWNER = false>
     __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
         const u64 mask = __ballot(keep);
@@ -1376,23 +1403,31 @@ struct WaveStage {
         if (n == 0) return;
         if (keep) {
             buf[(wp + (u32)__popcll(mask & ((1ull << lane_id()) - 1ull))) & (SX_STAGE - 1u)] = pair;
-#pragma unroll
-            for (int q = 0; q < SX_HIST_MAX; ++q) {
-                if (q < p.hist_passes)
-                    __hip_atomic_fetch_add(&hist[q * 256 + ((u32)(pair >> p.hist_shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (OWNER) {
-                const u32 first = (u32)(pair >> 32);
-                u32 o = 0;
-#pragma unroll
-                for (int i = 0; i < 15; ++i) o += (i < p.owner_n && first >= p.owner_bounds[i]) ? 1u : 0u;
-                __hip_atomic_fetch_add(&hist[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            count<OWNER>(pair, p);
         }
         const u32 before = wp / SX_BLOCK;
         wp += n;
         if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
+    }
+    // two candidates per lane (<= 128 pairs per call: still at most one half of the ring completes)
+    template <bool OWNER = false>
+    __device__ __forceinline__ void push2(bool keep0, u64 pair0, bool keep1, u64 pair1, const ExpandParams& p) {
+        static_assert(SX_BLOCK >= 128 && SX_STAGE >= SX_BLOCK + 128, "ring too small for two candidates per lane");
+        const u64 m0 = __ballot(keep0), m1 = __ballot(keep1);
+        const u32 n0 = (u32)__popcll(m0), n = n0 + (u32)__popcll(m1);
+        if (n == 0) return;
+        const u64 below = (1ull << lane_id()) - 1ull;
+        if (keep0) {
+            buf[(wp + (u32)__popcll(m0 & below)) & (SX_STAGE - 1u)] = pair0;
+            count<OWNER>(pair0, p);
+        }
+        if (keep1) {
+            buf[(wp + n0 + (u32)__popcll(m1 & below)) & (SX_STAGE - 1u)] = pair1;
+            count<OWNER>(pair1, p);
+        }
+        const u32 before = wp / SX_BLOCK;
+        wp += n;
+        if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);
     }
     __device__ __forceinline__ void finish(const ExpandParams& p) {
         const u32 rem = wp & (SX_BLOCK - 1u);
@@ -1416,7 +1451,7 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 }
 
 #ifndef SX_WAVES_PER_EU
-#define SX_WAVES_PER_EU 0
+#define SX_WAVES_PER_EU 5
 #endif
 #if SX_WAVES_PER_EU
 #define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SX_WAVES_PER_EU, SX_WAVES_PER_EU)))
@@ -1437,8 +1472,11 @@ constexpr u32 SX_WIN = 128;  // entries of a chunk's LDS windows: the wave's 64 
 template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
-    constexpr u32 SUPER = 64 * 64;  // candidates covered by one fill of the boundary masks
-    __shared__ u64 s_ends[SX_WAVES][64];   // bit q of word b: some owner's range ends before candidate 64 b + q
+#ifndef SX_SUPER_WORDS
+#define SX_SUPER_WORDS 64
+#endif
+    constexpr u32 SUPER = 64 * SX_SUPER_WORDS;  // candidates covered by one fill of the boundary masks
+    __shared__ u64 s_ends[SX_WAVES][SX_SUPER_WORDS];   // bit q of word b: some owner's range ends before candidate 64 b + q
     // owners with a non-empty range, compacted: {first candidate, id, DJ, CBJ | lane << 24}; the same storage holds
     // the wave's key window while the range ends are searched (a union, so the compiler knows the two views alias)
     union RecWin { uint4 rec[64]; u64 win[SX_WIN]; };
@@ -1529,48 +1567,73 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         if (c > 0) s_rec_w[__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, dj, cbj | ((u32)lane << 24));
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
-            s_ends[w][lane] = 0ull;
+            if (lane < (int)SX_SUPER_WORDS) s_ends[w][lane] = 0ull;
             __builtin_amdgcn_wave_barrier();
             const u32 rel = incl - ss;  // this owner's range ends before candidate ss + rel
             if (c > 0 && incl >= ss && rel < SUPER)
                 __hip_atomic_fetch_or(&s_ends[w][rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_wave_barrier();
+            // lane q keeps mask word q: a step takes its two words with v_readlane, no LDS round trip in the loop
+            const u64 my_ends = s_ends[w][lane & (SX_SUPER_WORDS - 1)];
+            const u32 ends_lo = (u32)my_ends, ends_hi = (u32)(my_ends >> 32);
             const u32 left = total - ss;
-            const u32 n_steps = left >= SUPER ? 64u : (left + 63u) >> 6;
-            // software pipeline: the {id, context} read of step b + 1 is in flight while step b is tested and pushed
-            struct Cand { u64 wi; u32 idj, dj, cbj, i; bool act; };
-            auto fetch = [&](u32 b) -> Cand {
-                const u64 e = uniform_u64(s_ends[w][b]);
-                const u32 k = ss + b * 64u + (u32)lane;
-                const bool act = k < total;
-                u32 ord = owners_done + (u32)__popcll(e & le_lane);
-                owners_done += (u32)__popcll(e);
-                if (!act) ord = n_nz - 1u;
-                const uint4 r = s_rec_w[ord];
-                const u32 off = (r.w >> 24) + 1u + ((act ? k : total - 1u) - r.x);   // candidate = entry base + off
-                u64 wi = cwin[off < SX_WIN ? off : SX_WIN - 1u];
-                if (__any(off >= SX_WIN)) {  // a range that leaves the window (rare): those lanes read HBM
-                    if (off >= SX_WIN) wi = p.idctx[base + off];
-                }
-                return Cand{wi, r.y, r.z, r.w & CTX_CODE_MASK, (u32)base + off, act};
-            };
-            Cand cur = fetch(0);
+            const u32 n_steps = left >= SUPER ? SUPER / 128u : (left + 127u) >> 7;
+            // One step = 128 candidates, two per lane (slot 0: candidate 128 b + lane, slot 1: + 64): the two lookup chains
+            // (owner record -> {id, context} word -> test) are independent, so their LDS latencies overlap, and the
+            // per-step bookkeeping is paid once per 128 candidates.
             for (u32 b = 0; b < n_steps; ++b) {
-                Cand nxt = cur;
-                if (b + 1 < n_steps) nxt = fetch(b + 1);
-                if (GEN == 1) {  // mark: candidate index i = position of the word just fetched
-                    if (cur.act && (u32)(cur.wi >> 32) == cur.idj && !((u32)cur.wi & CTX_SKIPPED))
-                        atomicOr(const_cast<u64*>(p.idctx) + cur.i, (u64)CTX_SKIPPED);
-                    cur = nxt;
+                const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
+                               (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
+                const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
+                               (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b + 1u));
+                const u32 k0 = ss + b * 128u + (u32)lane, k1 = k0 + 64u;
+                const bool act0 = k0 < total, act1 = k1 < total;
+                const u32 done0 = owners_done + (u32)__popcll(e0);
+                u32 ord0 = owners_done + (u32)__popcll(e0 & le_lane);
+                u32 ord1 = done0 + (u32)__popcll(e1 & le_lane);
+                owners_done = done0 + (u32)__popcll(e1);
+                if (!act0) ord0 = n_nz - 1u;
+                if (!act1) ord1 = n_nz - 1u;
+                const uint4 r0 = s_rec_w[ord0], r1 = s_rec_w[ord1];
+                const u32 off0 = (r0.w >> 24) + 1u + ((act0 ? k0 : total - 1u) - r0.x);   // candidate = entry base + off
+                const u32 off1 = (r1.w >> 24) + 1u + ((act1 ? k1 : total - 1u) - r1.x);
+                // the common case must stay a ds_read: left to itself the compiler merges the LDS and the global load
+                // into ONE flat load of a selected address, whose wait (vmcnt(0)) also waits for the next chunk's prefetch
+                u32 w0lo, w0hi, w1lo, w1hi;
+                {
+                    const u64 t0 = cwin[off0 < SX_WIN ? off0 : SX_WIN - 1u], t1 = cwin[off1 < SX_WIN ? off1 : SX_WIN - 1u];
+                    w0lo = (u32)t0; w0hi = (u32)(t0 >> 32); w1lo = (u32)t1; w1hi = (u32)(t1 >> 32);
+                    asm volatile("" : "+v"(w0lo), "+v"(w0hi), "+v"(w1lo), "+v"(w1hi));
+                }
+                if (__any(off0 >= SX_WIN || off1 >= SX_WIN)) {  // a range that leaves the window (rare): those lanes read HBM
+                    if (off0 >= SX_WIN) {
+                        const u64 t = p.idctx[base + off0];
+                        w0lo = (u32)t; w0hi = (u32)(t >> 32);
+                        asm volatile("" : "+v"(w0lo), "+v"(w0hi));  // consumed HERE: else its wait lands at the join, on every path
+                    }
+                    if (off1 >= SX_WIN) {
+                        const u64 t = p.idctx[base + off1];
+                        w1lo = (u32)t; w1hi = (u32)(t >> 32);
+                        asm volatile("" : "+v"(w1lo), "+v"(w1hi));
+                    }
+                }
+                if (GEN == 1) {  // mark: a candidate whose id equals its ancestor's is dropped by the skip rule
+                    if (act0 && w0hi == r0.y && !(w0lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off0, (u64)CTX_SKIPPED);
+                    if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
                     continue;
                 }
-                bool keep = cur.act && ctx_keep((u32)cur.wi, cur.dj, cur.cbj);
-                if (GEN == 2) keep = keep && !((u32)cur.wi & CTX_SKIPPED);
-                if (FILT && keep)
-                    keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(cur.wi >> 32) * filt_stride<FDIM>(p.filt_shape),
-                                             p.filt_bounds + (size_t)cur.idj * filt_stride<FDIM>(p.filt_shape), p.filt_shape);
-                st.template push<OWNER>(keep, (cur.wi & 0xFFFFFFFF00000000ull) | (u64)cur.idj, p);
-                cur = nxt;
+                bool keep0 = act0 && ctx_keep(w0lo, r0.z, r0.w & CTX_CODE_MASK);
+                bool keep1 = act1 && ctx_keep(w1lo, r1.z, r1.w & CTX_CODE_MASK);
+                if (GEN == 2) {
+                    keep0 = keep0 && !(w0lo & CTX_SKIPPED);
+                    keep1 = keep1 && !(w1lo & CTX_SKIPPED);
+                }
+                if (FILT) {
+                    const u32 fs = filt_stride<FDIM>(p.filt_shape);
+                    if (keep0) keep0 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w0hi * fs, p.filt_bounds + (size_t)r0.y * fs, p.filt_shape);
+                    if (keep1) keep1 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w1hi * fs, p.filt_bounds + (size_t)r1.y * fs, p.filt_shape);
+                }
+                st.template push2<OWNER>(keep0, ((u64)w0hi << 32) | (u64)r0.y, keep1, ((u64)w1hi << 32) | (u64)r1.y, p);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2507,11 +2570,14 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
     p.n_waves = 0; p.filt_bounds = filt_bounds; p.filt_shape = filt_shape;
-    p.hist = (u64*)hist; p.hist_passes = 0;
+    p.hist = (u64*)hist; p.hist_passes = 0; p.hist_all_hi = 1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
         p.hist_passes = hist_plan->n_passes;
-        for (int q = 0; q < hist_plan->n_passes; ++q) p.hist_shift[q] = hist_plan->shift[q];
+        for (int q = 0; q < hist_plan->n_passes; ++q) {
+            p.hist_shift[q] = hist_plan->shift[q];
+            if (hist_plan->shift[q] < 32) p.hist_all_hi = 0;
+        }
     }
     p.owner_n = -1;
     for (int i = 0; i < 15; ++i) p.owner_bounds[i] = 0xFFFFFFFFu;
@@ -2961,7 +3027,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
-    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.hist_all_hi = 1; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {

@@ -14,7 +14,8 @@ from collections import namedtuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libbroadphase_amd.so")
+# BP_LIBRARY: load another build of the same library (A/B measurements of kernel variants: `make OUT=../lib_ab/x EXTRA=-D...`)
+_LIB = os.environ.get("BP_LIBRARY") or os.path.join(_HERE, "lib", "libbroadphase_amd.so")
 
 Bounds = namedtuple("Bounds", ["min", "max"])  # src/geom.rs:84-87 (inclusive)
 
