@@ -211,6 +211,7 @@ constexpr uint32_t SX_BLOCK = SX_BLOCK_DEF;
 constexpr int SX_SHARDS = 64;
 constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
+bool scan_can_count(const RadixPlan& plan);  // launch_scan_expand counts the digits of this plan (hist_plan / hist) iff true
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
                             uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
 // scalars := init, blockfill[0..n_blocks) := 0, shards[0..n_shard_words) := 0, hist[0..n_hist_words) := 0 (hist may be null)

@@ -1283,7 +1283,6 @@ struct ExpandParams {
     u64* hist;
     int hist_passes;
     int hist_shift[SX_HIST_MAX];
-    int hist_all_hi;   // every counted digit lies in the pair's high dword (shift >= 32): 32-bit digit extraction
     // multi-GPU: instead, count the pairs per OWNER of the first id (owner_n >= 0: bounds[i] = first id of rank
     // i + 1, as PairOwnerDigit) into row 0 of hist -- the bucketing pass that follows then needs no histogram read
     int owner_n;
@@ -1384,8 +1383,9 @@ struct WaveStage {
 #pragma unroll
         for (int q = 0; q < SX_HIST_MAX; ++q) {
             if (q < p.hist_passes) {
-                // wave-uniform choice: digits of the first id come out of the high dword with 32-bit shifts
-                const u32 dg = p.hist_all_hi ? (first >> (p.hist_shift[q] - 32)) & 255u : (u32)(pair >> p.hist_shift[q]) & 255u;
+                // a counted digit never straddles the two dwords (scan_can_count): one select + one bit-field extract
+                const u32 src = p.hist_shift[q] >= 32 ? first : (u32)pair;
+                const u32 dg = (src >> (p.hist_shift[q] & 31)) & 255u;
                 __hip_atomic_fetch_add(&hist[q * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -1402,7 +1402,7 @@ struct WaveStage {
         const u32 n = (u32)__popcll(mask);
         if (n == 0) return;
         if (keep) {
-            buf[(wp + (u32)__popcll(mask & ((1ull << lane_id()) - 1ull))) & (SX_STAGE - 1u)] = pair;
+            buf[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, wp)) & (SX_STAGE - 1u)] = pair;
             count<OWNER>(pair, p);
         }
         const u32 before = wp / SX_BLOCK;
@@ -1416,13 +1416,12 @@ struct WaveStage {
         const u64 m0 = __ballot(keep0), m1 = __ballot(keep1);
         const u32 n0 = (u32)__popcll(m0), n = n0 + (u32)__popcll(m1);
         if (n == 0) return;
-        const u64 below = (1ull << lane_id()) - 1ull;
         if (keep0) {
-            buf[(wp + (u32)__popcll(m0 & below)) & (SX_STAGE - 1u)] = pair0;
+            buf[__builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, wp)) & (SX_STAGE - 1u)] = pair0;
             count<OWNER>(pair0, p);
         }
         if (keep1) {
-            buf[(wp + n0 + (u32)__popcll(m1 & below)) & (SX_STAGE - 1u)] = pair1;
+            buf[__builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, wp + n0)) & (SX_STAGE - 1u)] = pair1;
             count<OWNER>(pair1, p);
         }
         const u32 before = wp / SX_BLOCK;
@@ -1492,17 +1491,22 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
     WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
-    const u64 le_lane = (2ull << lane) - 1ull;  // bits 0..lane
     // a chunk's global loads (clamped addresses: every load is unconditional, validity is decided at use)
     struct Pre { u64 k0, k1, w0, w1; };
     auto prefetch = [&](size_t base) -> Pre {
-        const size_t last = p.m - 1;
-        const size_t a = base + (size_t)lane, b = a + 64;
         Pre r;
-        r.k0 = p.keys[a < last ? a : last];
-        r.k1 = p.keys[b < last ? b : last];
-        r.w0 = p.idctx[a < last ? a : last];
-        r.w1 = p.idctx[b < last ? b : last];
+        if (base + SX_WIN <= p.m) {  // wave-uniform: every chunk but the last one or two -- no clamping, scalar base + lane offset
+            const u64* __restrict__ k = p.keys + base;
+            const u64* __restrict__ c = p.idctx + base;
+            r.k0 = k[lane]; r.k1 = k[64 + lane]; r.w0 = c[lane]; r.w1 = c[64 + lane];
+        } else {
+            const size_t last = p.m - 1;
+            const size_t a = base + (size_t)lane, b = a + 64;
+            r.k0 = p.keys[a < last ? a : last];
+            r.k1 = p.keys[b < last ? b : last];
+            r.w0 = p.idctx[a < last ? a : last];
+            r.w1 = p.idctx[b < last ? b : last];
+        }
         return r;
     };
     size_t base = (size_t)gw * 64;
@@ -1556,7 +1560,6 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         __builtin_amdgcn_wave_barrier();  // the key window is dead from here on (s_rec is written below)
         const u64 nz = __ballot(c > 0);
         if (nz == 0) continue;  // wave-uniform
-        const u32 n_nz = (u32)__popcll(nz);
         const u32 incl = wave_incl_scan_u32(c);
         const u32 total = __shfl(incl, 63, 64);
         // The candidates of the 64 ranges, concatenated, are dealt to the lanes 64 per step.  Which
@@ -1564,13 +1567,16 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
         // popcount and one 16-byte LDS read per lane -- no per-candidate search.
         st.examined += total;
-        if (c > 0) s_rec_w[__popcll(nz & ((1ull << lane) - 1ull))] = make_uint4(incl - c, idj, dj, cbj | ((u32)lane << 24));
+        // record: {first candidate - lane - 1 (so that a candidate's entry offset is k - x), id, DJ, CBJ}
+        if (c > 0)
+            s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
+                make_uint4(incl - c - (u32)lane - 1u, idj, dj, cbj);
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
             if (lane < (int)SX_SUPER_WORDS) s_ends[w][lane] = 0ull;
             __builtin_amdgcn_wave_barrier();
-            const u32 rel = incl - ss;  // this owner's range ends before candidate ss + rel
-            if (c > 0 && incl >= ss && rel < SUPER)
+            const u32 rel = incl - 1u - ss;  // this owner's LAST candidate is ss + rel (bit rel: an owner's range ends there)
+            if (c > 0 && incl > ss && rel < SUPER)
                 __hip_atomic_fetch_or(&s_ends[w][rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_wave_barrier();
             // lane q keeps mask word q: a step takes its two words with v_readlane, no LDS round trip in the loop
@@ -1588,15 +1594,15 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                                (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b + 1u));
                 const u32 k0 = ss + b * 128u + (u32)lane, k1 = k0 + 64u;
                 const bool act0 = k0 < total, act1 = k1 < total;
+                // owner of a candidate = how many ranges ended strictly before it: the bits below the lane, counted by
+                // v_mbcnt on top of the running total (no AND / popcount per lane).  A lane beyond the last candidate
+                // reads a record past the owners' (harmless LDS garbage): everything it derives is masked by act.
                 const u32 done0 = owners_done + (u32)__popcll(e0);
-                u32 ord0 = owners_done + (u32)__popcll(e0 & le_lane);
-                u32 ord1 = done0 + (u32)__popcll(e1 & le_lane);
+                const u32 ord0 = __builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, owners_done));
+                const u32 ord1 = __builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, done0));
                 owners_done = done0 + (u32)__popcll(e1);
-                if (!act0) ord0 = n_nz - 1u;
-                if (!act1) ord1 = n_nz - 1u;
-                const uint4 r0 = s_rec_w[ord0], r1 = s_rec_w[ord1];
-                const u32 off0 = (r0.w >> 24) + 1u + ((act0 ? k0 : total - 1u) - r0.x);   // candidate = entry base + off
-                const u32 off1 = (r1.w >> 24) + 1u + ((act1 ? k1 : total - 1u) - r1.x);
+                const uint4 r0 = s_rec_w[ord0], r1 = s_rec_w[ord1];   // ord <= 64: at worst the 16 bytes after the records (still this workgroup's LDS)
+                const u32 off0 = k0 - r0.x, off1 = k1 - r1.x;   // candidate = entry base + off
                 // the common case must stay a ds_read: left to itself the compiler merges the LDS and the global load
                 // into ONE flat load of a selected address, whose wait (vmcnt(0)) also waits for the next chunk's prefetch
                 u32 w0lo, w0hi, w1lo, w1hi;
@@ -1605,13 +1611,14 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     w0lo = (u32)t0; w0hi = (u32)(t0 >> 32); w1lo = (u32)t1; w1hi = (u32)(t1 >> 32);
                     asm volatile("" : "+v"(w0lo), "+v"(w0hi), "+v"(w1lo), "+v"(w1hi));
                 }
-                if (__any(off0 >= SX_WIN || off1 >= SX_WIN)) {  // a range that leaves the window (rare): those lanes read HBM
-                    if (off0 >= SX_WIN) {
+                const bool far0 = act0 && off0 >= SX_WIN, far1 = act1 && off1 >= SX_WIN;
+                if (__any(far0 || far1)) {  // a range that leaves the window (rare): those lanes read HBM
+                    if (far0) {
                         const u64 t = p.idctx[base + off0];
                         w0lo = (u32)t; w0hi = (u32)(t >> 32);
                         asm volatile("" : "+v"(w0lo), "+v"(w0hi));  // consumed HERE: else its wait lands at the join, on every path
                     }
-                    if (off1 >= SX_WIN) {
+                    if (far1) {
                         const u64 t = p.idctx[base + off1];
                         w1lo = (u32)t; w1hi = (u32)(t >> 32);
                         asm volatile("" : "+v"(w1lo), "+v"(w1hi));
@@ -1622,8 +1629,8 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
                     continue;
                 }
-                bool keep0 = act0 && ctx_keep(w0lo, r0.z, r0.w & CTX_CODE_MASK);
-                bool keep1 = act1 && ctx_keep(w1lo, r1.z, r1.w & CTX_CODE_MASK);
+                bool keep0 = act0 && ctx_keep(w0lo, r0.z, r0.w);
+                bool keep1 = act1 && ctx_keep(w1lo, r1.z, r1.w);
                 if (GEN == 2) {
                     keep0 = keep0 && !(w0lo & CTX_SKIPPED);
                     keep1 = keep1 && !(w1lo & CTX_SKIPPED);
@@ -2557,6 +2564,14 @@ static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipSt
     return owner ? launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream)
                  : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
 }
+// digit plans the expanding scan can count while it emits: few enough passes, key digits only, and no digit that
+// straddles the two dwords of a packed pair (the kernel extracts a digit from ONE dword)
+bool scan_can_count(const RadixPlan& plan) {
+    if (plan.n_passes <= 0 || plan.n_passes > SX_HIST_MAX) return false;
+    for (int q = 0; q < plan.n_passes; ++q)
+        if (plan.from_val[q] || (plan.shift[q] < 32 && plan.shift[q] + 8 > 32)) return false;
+    return true;
+}
 hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* idctx, size_t m, const float* filt_bounds, int filt_shape,
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
@@ -2570,14 +2585,11 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
     p.n_waves = 0; p.filt_bounds = filt_bounds; p.filt_shape = filt_shape;
-    p.hist = (u64*)hist; p.hist_passes = 0; p.hist_all_hi = 1;
+    p.hist = (u64*)hist; p.hist_passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
-    if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
+    if (hist_plan && hist && scan_can_count(*hist_plan)) {
         p.hist_passes = hist_plan->n_passes;
-        for (int q = 0; q < hist_plan->n_passes; ++q) {
-            p.hist_shift[q] = hist_plan->shift[q];
-            if (hist_plan->shift[q] < 32) p.hist_all_hi = 0;
-        }
+        for (int q = 0; q < hist_plan->n_passes; ++q) p.hist_shift[q] = hist_plan->shift[q];
     }
     p.owner_n = -1;
     for (int i = 0; i < 15; ++i) p.owner_bounds[i] = 0xFFFFFFFFu;
@@ -3027,7 +3039,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
-    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.hist_all_hi = 1; p.owner_n = -1;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {

@@ -1095,7 +1095,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->shards, shard_bytes));
             BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
-            const bool count_digits = allow_holes && hist_plan && hist_plan->n_passes > 0 && hist_plan->n_passes <= SX_HIST_MAX;
+            const bool count_digits = allow_holes && hist_plan && scan_can_count(*hist_plan);
             const bool count_owners = allow_holes && !count_digits && owner_n >= 0 && owner_n <= 15;
             L->owner_hist_valid = false;
             if (count_digits || count_owners) BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
@@ -1223,7 +1223,7 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
         // the sort that follows groups by first id first (sort_dups_pairs_in): count those digits while emitting
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan hplan = make_radix_plan(((unsigned long long)idv << 32), 0, 0);
-        const bool count_digits = segment_finish_enabled() && hplan.n_passes > 0 && hplan.n_passes <= SX_HIST_MAX;
+        const bool count_digits = segment_finish_enabled() && scan_can_count(hplan);
         if (count_digits) {
             BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
             HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
