@@ -295,7 +295,10 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
                                 hipStream_t stream, int ctx_kind = -1, uint64_t* idctx_out = nullptr,
-                                const uint32_t* stats = nullptr, uint32_t abort_over = 0xFFFFFFFFu);
+                                const uint32_t* stats = nullptr, uint32_t abort_over = 0xFFFFFFFFu, int distinct_id_bits = 0);
+// distinct_id_bits > 0 (with payload_packed): the caller vouches that the ids are DISTINCT and below 2^distinct_id_bits; where
+// the rest of the key and the id fit one 64-bit word the composite-key kernel runs (a group above the capacity then sets
+// KERR_SEGMENT_TOO_LONG instead of taking the multi-round path)
 // stats / abort_over: launch_tgroup_bounds' statistics; more than abort_over entries in oversize groups -> nothing is
 // done and KERR_SEGMENT_TOO_LONG is set (the caller sorts full-width instead)
 // ctx_kind (index kind) + idctx_out with payload_packed: also writes launch_entry_ctx's output for inactive_below = 0

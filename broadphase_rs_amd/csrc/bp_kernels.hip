@@ -2129,6 +2129,113 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* 
     }
 }
 
+// Composite-key variant of the grouped finish, for the per-frame fast path (ids distinct, box codes packed into the
+// ids): inside a group the top bits of the key are equal, and inside a bin of the counting sort the next TG2_BIN_BITS are
+// as well -- what is left of the key (rem_bits) and the id (id_bits) fit ONE 64-bit word, rem << id_bits | id, whose
+// plain unsigned order is the (key, id) order.  The rank loop then costs one 8-byte LDS read and one 64-bit compare per
+// element of the bin (the generic kernel above: three reads and a three-level compare -- its rank loops were 3/4 of its
+// instructions), the arrival ticket of the counting pass doubles as the scatter slot (one returning LDS atomic per
+// entry instead of a count pass and a cursor pass), and 1024 bins keep entries of different cells apart down to three
+// levels below the group.  Equal composites cannot occur: ids are distinct and an object's cells have distinct keys.
+// A group beyond the capacity sets KERR_SEGMENT_TOO_LONG (the host sorts full-width and leaves this plan).
+constexpr int TG2_BIN_BITS = 10, TG2_BINS = 1 << TG2_BIN_BITS, TG2_BINS_PER_THREAD = TG2_BINS / TGRP_THREADS;
+static_assert(TGRP_THREADS == 256 && TG2_BINS_PER_THREAD == 4, "tgroup_finish2: four bins per thread in the prefix scan");
+template <int CTX_KIND>
+__global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ ids_in,
+                                                                      const u32* __restrict__ bounds, int gshift, int id_bits,
+                                                                      u64* __restrict__ keys_out, u32* __restrict__ ids_out,
+                                                                      uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
+                                                                      DevScalars* sc, const u32* __restrict__ stats, u32 abort_over) {
+    __shared__ u64 s_comp[TGRP_CAP];  // composites grouped by bin while ranking, then the keys in final order
+    // counts / offsets of the bins while ranking; afterwards the same storage takes the payloads in final order
+    union Aux { struct { u32 cnt[TG2_BINS]; u32 off[TG2_BINS + 4]; } b; u32 id[TGRP_CAP]; };
+    __shared__ __attribute__((aligned(16))) Aux s_aux;
+    __shared__ u32 s_ws[TGRP_THREADS / 64];
+    static_assert(sizeof(Aux) >= TGRP_CAP * sizeof(u32), "payload view must fit");
+    const u32 g = blockIdx.x, tid = threadIdx.x;
+    if (stats && stats[1] > abort_over) {
+        if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
+    const u32 lo = bounds[g], hi = bounds[g + 1];
+    const u32 ng = hi - lo;
+    if (ng == 0) return;  // workgroup-uniform
+    if (ng > (u32)TGRP_CAP) {
+        if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
+    const int bshift = gshift - TG2_BIN_BITS;  // the host guarantees 0 <= bshift and bshift + id_bits <= 64
+    const u64 rem_mask = bshift >= 64 ? ~0ull : ((1ull << bshift) - 1ull);
+    const u32 id_mask = id_bits >= 32 ? 0xFFFFFFFFu : ((1u << id_bits) - 1u);
+    reinterpret_cast<uint4*>(s_aux.b.cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    u64 k[TGRP_ITEMS];
+    u32 p[TGRP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        k[i] = x < ng ? keys_in[(size_t)lo + x] : 0ull;
+        p[i] = x < ng ? ids_in[(size_t)lo + x] : 0u;
+    }
+    __syncthreads();
+    u32 slot[TGRP_ITEMS];  // arrival ticket inside the bin, then the scatter slot, then the final position
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        slot[i] = 0;
+        if (x < ng)
+            slot[i] = __hip_atomic_fetch_add(&s_aux.b.cnt[(u32)(k[i] >> bshift) & (TG2_BINS - 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 1024 bin counts: four consecutive bins per thread
+        const uint4 c = reinterpret_cast<const uint4*>(s_aux.b.cnt)[tid];
+        u32 total;
+        const u32 excl = block_excl_scan_u32<TGRP_THREADS>(c.x + c.y + c.z + c.w, s_ws, total);
+        reinterpret_cast<uint4*>(s_aux.b.off)[tid] = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+        if (tid == 0) s_aux.b.off[TG2_BINS] = ng;
+    }
+    __syncthreads();
+    u64 comp[TGRP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        comp[i] = 0;
+        if (x < ng) {
+            comp[i] = ((k[i] & rem_mask) << id_bits) | (u64)(p[i] & id_mask);
+            slot[i] += s_aux.b.off[(u32)(k[i] >> bshift) & (TG2_BINS - 1u)];
+            s_comp[slot[i]] = comp[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        if (x < ng) {
+            const u32 b = (u32)(k[i] >> bshift) & (TG2_BINS - 1u);
+            const u32 start = s_aux.b.off[b], end = s_aux.b.off[b + 1];
+            u32 rank = 0;
+#pragma unroll 2
+            for (u32 y = start; y < end; ++y) rank += s_comp[y] < comp[i] ? 1u : 0u;
+            slot[i] = start + rank;
+        }
+    }
+    __syncthreads();  // every rank is known: the buffers now take the group in final order (bin bookkeeping is dead)
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        if (x < ng) { s_comp[slot[i]] = k[i]; s_aux.id[slot[i]] = p[i]; }
+    }
+    __syncthreads();
+    for (u32 y = tid; y < ng; y += TGRP_THREADS) {
+        const u32 px = s_aux.id[y];
+        const u64 ky = s_comp[y];
+        const u32 code = box_from_packed(px >> BOX_ID_BITS);
+        keys_out[(size_t)lo + y] = ky;
+        ids_out[(size_t)lo + y] = px & BOX_ID_MASK;
+        box_out[(size_t)lo + y] = (uint8_t)code;
+        if constexpr (CTX_KIND >= 0) idctx_out[(size_t)lo + y] = ((u64)(px & BOX_ID_MASK) << 32) | (u64)make_entry_ctx<CTX_KIND>(ky, code, 0u);
+    }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds, int shape,
                                                                 u64* __restrict__ out, DevScalars* sc) {
@@ -3313,11 +3420,27 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
     }
     return hipGetLastError();
 }
+bool tgroup_composite_fits(int gshift, int id_bits) {
+    static const bool disabled = getenv("BP_NO_TGROUP_COMPOSITE") != nullptr;  // A/B switch
+    return !disabled && gshift >= TG2_BIN_BITS && id_bits >= 1 && id_bits <= (int)BOX_ID_BITS && (gshift - TG2_BIN_BITS) + id_bits <= 64;
+}
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
-                                hipStream_t stream, int ctx_kind, uint64_t* idctx_out, const uint32_t* stats, uint32_t abort_over) {
+                                hipStream_t stream, int ctx_kind, uint64_t* idctx_out, const uint32_t* stats, uint32_t abort_over,
+                                int distinct_id_bits) {
     if (n_groups == 0) return hipSuccess;
     if (gshift < TGRP_BIN_BITS) return hipErrorInvalidValue;
+    if (payload_packed && box_out && distinct_id_bits > 0 && tgroup_composite_fits(gshift, distinct_id_bits)) {
+#define BP_TG2_LAUNCH(K)                                                                                                          \
+    tgroup_finish2_kernel<K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, distinct_id_bits,  \
+                                                                    (u64*)keys_out, ids_out, box_out, (u64*)idctx_out, sc, stats, abort_over)
+        if (!idctx_out || ctx_kind < 0) BP_TG2_LAUNCH(-1);
+        else if (ctx_kind == 0) BP_TG2_LAUNCH(0);
+        else if (ctx_kind == 1) BP_TG2_LAUNCH(1);
+        else BP_TG2_LAUNCH(2);
+#undef BP_TG2_LAUNCH
+        return hipGetLastError();
+    }
 #define BP_TGRP_LAUNCH(P, K)                                                                                                     \
     tgroup_finish_kernel<P, K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, (u64*)keys_out, \
                                                                       ids_out, box_out, (u64*)idctx_out, sc, stats, abort_over)

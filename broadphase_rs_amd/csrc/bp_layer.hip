@@ -657,7 +657,9 @@ int sort_tree(bp_layer* L) {
                                                 (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
                                                 (DevScalars*)L->d_sc.p, L->stream, with_ctx ? L->kind : -1,
                                                 with_ctx ? (uint64_t*)L->idctx.p : nullptr, (const uint32_t*)L->tgrp_stats.p,
-                                                (uint32_t)(L->m / 4)));
+                                                (uint32_t)(L->m / 4),
+                                                // ids distinct (the codes ride in them): the composite-key kernel may run
+                                                (ride && L->ids_distinct) ? std::max(1, 32 - __builtin_clz(L->id_or | 1u)) : 0));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
             HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
