@@ -46,6 +46,7 @@ enum : unsigned {
     KERR_SEGMENT_TOO_LONG = 4u,  // segment_finish: one first id owns more pairs than its window holds
     KERR_BIGLIST_OVERFLOW = 8u,  // expanding scan: more long-range slices than the work list holds
     KERR_BAD_ID = 16u,           // pick_ray: an id of the tree has no row in the bounds table
+    KERR_ENCODE_OVERFLOW = 32u,  // fused encode: the predicted entry capacity was too small (nothing beyond it was written)
 };
 
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
@@ -88,6 +89,17 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
 // pack_box: write id | box_to_packed(code) << BOX_ID_BITS into ids_out (box_out may then be nullptr)
 // hist_plan / hist: also count the key digits of every emitted entry for the passes of hist_plan
 // (<= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller)
+
+// One-pass extend (count + look-back prefix + emit): what launch_encode_count / launch_scan_block_sums / launch_encode_emit do
+// together, with the entry capacity, pack_box and hist_plan PREDICTED by the caller.  sc (reset by the caller) receives the
+// entry total, the facts of the ids and KERR_ENCODE_OVERFLOW when the total exceeds `capacity` entries (the output is then
+// incomplete and must be redone).  workspace: encode_fused_workspace_bytes(n) bytes; aux: enc_blocks(n) partials.
+size_t encode_fused_workspace_bytes(size_t n);
+hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n, uint32_t min_depth,
+                               int have_prev_id, uint32_t prev_id, void* workspace, size_t capacity, uint64_t* keys_out,
+                               uint32_t* ids_out, uint8_t* box_out, BlockAux* aux, DevScalars* sc, hipStream_t stream,
+                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
+                               unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0);
 
 // exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
 // partials are folded into *sc as well (single workgroup, no atomics)

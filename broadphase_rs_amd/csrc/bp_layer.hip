@@ -113,6 +113,9 @@ struct bp_layer {
     DevBuf tgrp_bounds, tgrp_stats;
     HostBuf h_tstats;
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
+    // one-pass extend: what the previous extend into the empty layer produced predicts what the next one needs
+    struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; } enc_hint;
+    DevBuf enc_ws;                      // tile counter + look-back status words of encode_fused
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
     std::vector<ProfRec> prof_pending;
@@ -344,6 +347,91 @@ struct TreeGroupPlan { RadixPlan plan; int gshift; uint32_t n_groups; unsigned l
 bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out);
 
 // ---- extend -------------------------------------------------------------------------------------------
+// One-pass extend into the EMPTY layer (the per-frame pattern) when an earlier extend left a prediction: one kernel, one
+// host round trip (the two-kernel path: two of each).  *done = 0: not applicable or the prediction failed -- nothing of the
+// layer's state was touched and the caller runs the two-kernel path.
+int extend_fused(bp_layer* L, const SysBounds& sb, const float* d_bounds, const uint32_t* d_ids, size_t n, int* done) {
+    *done = 0;
+    const auto& h = L->enc_hint;
+    // entries scale with the object count; 3 % + one tile of head room, and never less than what is allocated anyway
+    const double scale = h.n ? (double)n / (double)h.n : 1.0;
+    const size_t pred_m = n == h.n ? h.entries : (size_t)((double)h.entries * scale);
+    if (pred_m == 0) return BP_OK;
+    const size_t want = pred_m + pred_m / 32 + 8192;
+    BP_TRY(ensure_tree_capacity(L, want));
+    const bool pack = h.pack;
+    size_t capacity = std::min(L->keys[L->cur].cap / sizeof(uint64_t), L->ids[L->cur].cap / sizeof(uint32_t));
+    if (!pack) capacity = std::min(capacity, L->box[L->cur].cap);
+    const size_t nb = enc_blocks(n);
+    BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
+    BP_TRY(ensure_dev(L, L->enc_ws, encode_fused_workspace_bytes(n)));
+    // the digit plan the coming tree sort will most likely take (it verifies: a different plan only costs its own histogram)
+    RadixPlan hist_plan;
+    int seg_shift_unused = 0;
+    bool count_digits = tree_partial_plan(pred_m, h.key_or ^ h.key_and, &hist_plan, &seg_shift_unused) && hist_plan.n_passes <= SX_HIST_MAX;
+    {
+        TreeGroupPlan gp;
+        if (L->tgrp_ok && tree_group_plan(pred_m, h.key_and, h.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
+            hist_plan = gp.plan;
+            count_digits = true;
+        }
+    }
+    const KindInfo kic = kind_info(L->kind);
+    const bool count_cells = L->cell_fuse_depth > 0 && kic.dim * L->cell_fuse_depth <= 9;
+    const size_t cell_bytes = count_cells ? (size_t)HIST_COPIES * (((size_t)1 << (kic.dim * L->cell_fuse_depth)) + 1) * sizeof(unsigned long long) : 0;
+    if (count_cells) {
+        BP_TRY(ensure_dev(L, L->cell_hist_dev, cell_bytes));
+        HIP_TRY(L, hipMemsetAsync(L->cell_hist_dev.p, 0, cell_bytes, L->stream));
+    }
+    if (count_digits) {
+        BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+        HIP_TRY(L, hipMemsetAsync(L->tree_hist.p, 0, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+    }
+    L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
+    BP_TRY(sc_reset(L));
+    {
+        ProfScope ps(L, BP_K_ENCODE);
+        HIP_TRY(L, launch_encode_fused(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, L->enc_ws.p, capacity, cur_keys(L), cur_ids(L),
+                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
+                                       count_digits ? &hist_plan : nullptr, count_digits ? (unsigned long long*)L->tree_hist.p : nullptr,
+                                       pack ? 1 : 0, count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth));
+    }
+    DevScalars sc;
+    BP_TRY(sc_fetch(L, &sc));
+    const size_t add = (size_t)sc.total;
+    const bool can_pack = !(sc.flags & EXT_IDS_REPEAT) && (sc.id_or >> BOX_ID_BITS) == 0;
+    if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack)) {
+        // the prediction failed: remember the truth for the next frame and redo this one on the two-kernel path
+        L->enc_hint.entries = add; L->enc_hint.n = n; L->enc_hint.pack = can_pack;
+        return BP_OK;
+    }
+    L->stats.objects_invalid += sc.n_invalid;
+    L->stats.objects_valid += n - sc.n_invalid;
+    if (sc.flags & EXT_IDS_DECREASE) L->order_ok = false;
+    if (sc.flags & EXT_IDS_REPEAT) L->ids_distinct = false;
+    if (sc.flags & EXT_BOX_UNKNOWN) L->box_all_known = false;
+    L->have_ids = true;
+    L->max_id = std::max(L->max_id, sc.id_max);
+    L->min_id = std::min(L->min_id, sc.id_min);
+    *done = 1;
+    L->enc_hint.valid = true; L->enc_hint.n = n; L->enc_hint.entries = add;
+    static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;
+    L->enc_hint.pack = can_pack && !no_emit_pack;
+    L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
+    if (add == 0) return BP_OK;
+    if (count_cells) L->cell_dev_valid = true;
+    if (pack) { L->ids_packed = true; L->box_valid = false; }
+    L->tail_run = false;
+    if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
+    L->m += add;
+    L->sorted = false;
+    L->key_or |= sc.key_or; L->key_and &= sc.key_and;
+    L->id_or |= sc.id_or; L->id_and &= sc.id_and;
+    L->depth_mask |= sc.depth_mask;
+    L->stats.entries = L->m;
+    return BP_OK;
+}
+
 int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const float* d_bounds,
                   const uint32_t* d_ids, size_t n) {
     if (n == 0) return BP_OK;
@@ -355,6 +443,13 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
     }
     if (L->m) BP_TRY(ensure_unpacked(L));  // appending to a tree whose ids still carry their box codes
+    static const bool no_fused_encode = getenv("BP_NO_FUSED_ENCODE") != nullptr;  // A/B switch
+    const bool was_empty = L->m == 0 && !L->have_ids;
+    if (!no_fused_encode && was_empty && L->enc_hint.valid && L->box_valid && L->ids_distinct) {
+        int done = 0;
+        BP_TRY(extend_fused(L, sb, d_bounds, d_ids, n, &done));
+        if (done) return BP_OK;
+    }
     const size_t nb = enc_blocks(n);
     BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
@@ -428,6 +523,10 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     L->tail_run = false;
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
     BP_TRY(sync_stream(L));
+    if (was_empty) {  // what this extend produced predicts the next frame's (one-pass extend)
+        L->enc_hint.valid = true; L->enc_hint.n = n; L->enc_hint.entries = add; L->enc_hint.pack = pack;
+        L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
+    }
     L->m += add;
     L->sorted = false;  // src/layer.rs:119 (at least one valid object was appended)
     L->key_or |= sc.key_or; L->key_and &= sc.key_and;
@@ -1395,7 +1494,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->enc_ws); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
     free_host(L->h_shards); free_host(L->h_tstats);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
@@ -1420,6 +1519,7 @@ int bp_layer_reset_plan_hints(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
     L->grp_next = false; L->grp_off = 0;
+    L->enc_hint.valid = false;
     return BP_OK;
 }
 int bp_layer_stream(const bp_layer_t* L, void** stream) {
