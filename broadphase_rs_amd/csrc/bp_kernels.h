@@ -70,6 +70,7 @@ struct SysBounds {
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
+constexpr int ENCF_ROUNDS = 2;    // ... per tile of encode_fused (the cells of a tile stay in registers across its look-back)
 constexpr int ENC_STAGE = 2048;   // entries of one round staged in LDS by encode_emit (8 per object)
 constexpr int ENC_CELLS_MAX = 512; // cells encode_emit can histogram (8^3 in 3-D, 4^4 in 2-D)
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
@@ -93,7 +94,8 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
 // One-pass extend (count + look-back prefix + emit): what launch_encode_count / launch_scan_block_sums / launch_encode_emit do
 // together, with the entry capacity, pack_box and hist_plan PREDICTED by the caller.  sc (reset by the caller) receives the
 // entry total, the facts of the ids and KERR_ENCODE_OVERFLOW when the total exceeds `capacity` entries (the output is then
-// incomplete and must be redone).  workspace: encode_fused_workspace_bytes(n) bytes; aux: enc_blocks(n) partials.
+// incomplete and must be redone).  workspace: encode_fused_workspace_bytes(n) bytes; aux: encode_fused_tiles(n) partials.
+size_t encode_fused_tiles(size_t n);
 size_t encode_fused_workspace_bytes(size_t n);
 hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n, uint32_t min_depth,
                                int have_prev_id, uint32_t prev_id, void* workspace, size_t capacity, uint64_t* keys_out,

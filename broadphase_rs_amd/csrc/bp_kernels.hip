@@ -368,7 +368,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
                                                                   uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
                                                                   BlockAux* __restrict__ aux, DevScalars* sc) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
-    constexpr int NW = ENC_THREADS / 64;
+    constexpr int NW = ENC_THREADS / 64, ROUNDS = ENCF_ROUNDS;
+    constexpr u64 LANE0 = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;  // Morton lane of axis 0
     __shared__ u32 s_ws[NW];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
     __shared__ u32 s_cell[CELLS ? ENC_CELLS_MAX + 1 : 1];
@@ -386,15 +387,14 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
         for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) s_cell[k] = 0;
     __syncthreads();
     const u32 tile = s_tile;
-    const size_t n_tiles = (n + (size_t)ENC_THREADS * ENC_ROUNDS - 1) / ((size_t)ENC_THREADS * ENC_ROUNDS);
-    // ---- 1. cells of this tile's objects (registers), entry counts, facts of the ids ---------------------------------
-    Cells<KIND> c[ENC_ROUNDS];
-    u32 id[ENC_ROUNDS];
+    const size_t n_tiles = (n + (size_t)ENC_THREADS * ROUNDS - 1) / ((size_t)ENC_THREADS * ROUNDS);
+    // ---- 1. cells of this tile's objects (kept in registers), entry counts, facts of the ids ---------------------------
+    Cells<KIND> c[ROUNDS];
+    u32 id[ROUNDS];
     u32 wg_cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
-    u64 kor = 0, kand = ~0ull;
 #pragma unroll
-    for (int r = 0; r < ENC_ROUNDS; ++r) {
-        const size_t i = ((size_t)tile * ENC_ROUNDS + r) * ENC_THREADS + tid;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const size_t i = ((size_t)tile * ROUNDS + r) * ENC_THREADS + tid;
         c[r].count = 0; c[r].depth = 0; c[r].valid = false; c[r].overflow = false;
         c[r].lo[0] = c[r].lo[1] = c[r].lo[2] = 0; c[r].n[0] = c[r].n[1] = c[r].n[2] = 1;
         id[r] = 0;
@@ -417,53 +417,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
                 dmask |= 1u << c[r].depth;
                 ior |= id[r];
                 iand &= id[r];
-                u32 o[3] = {0, 0, 0}, a[3] = {0, 0, 0};
-#pragma unroll
-                for (u32 ax = 0; ax < DIM; ++ax) range_or_and(c[r].lo[ax], c[r].n[ax], o[ax], a[ax]);
-                const u32 up = AB - c[r].depth;
-                u64 mo = spread_bits<DIM>((u64)o[0] << up) | (spread_bits<DIM>((u64)o[1] << up) << 1);
-                u64 ma = spread_bits<DIM>((u64)a[0] << up) | (spread_bits<DIM>((u64)a[1] << up) << 1);
-                if (DIM == 3) {
-                    mo |= spread_bits<DIM>((u64)o[2] << up) << 2;
-                    ma |= spread_bits<DIM>((u64)a[2] << up) << 2;
-                }
-                kor |= (mo << DB) | c[r].depth;
-                kand &= (ma << DB) | c[r].depth;
             }
         }
     }
     // per-round exclusive offsets inside the workgroup
-    u32 excl[ENC_ROUNDS], round_total[ENC_ROUNDS];
+    u32 excl[ROUNDS], round_total[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < ENC_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         excl[r] = block_excl_scan_u32<ENC_THREADS>(c[r].count, s_ws, round_total[r]);
         wg_cnt += round_total[r];
     }
-    // ---- 2. this tile's facts -> aux[tile] (folded by fold_aux_kernel, no atomics) -------------------------------------
-    {
-        const u32 wd = wave_or_u32(dmask), wf = wave_or_u32(flags), we = wave_or_u32(err), wi = wave_sum_u32(inv), wo = wave_or_u32(ior),
-                  wa = wave_and_u32(iand), wm = wave_max_u32(imax), wn = wave_min_u32(imin);
-        const u64 wko = wave_or_u64(kor), wka = wave_and_u64(kand);
-        if (lane == 0) {
-            r_u32[0][w] = wd; r_u32[1][w] = wf; r_u32[2][w] = we; r_u32[3][w] = wi; r_u32[4][w] = wo; r_u32[5][w] = wa;
-            r_u32[6][w] = wm; r_u32[7][w] = wn; r_u64[0][w] = wko; r_u64[1][w] = wka;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        BlockAux b;
-        b.key_or = 0; b.key_and = ~0ull; b.depth_mask = 0; b.flags = 0; b.err = 0; b.n_invalid = 0; b.id_or = 0;
-        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.id_min = 0xFFFFFFFFu;
-        for (int k = 0; k < NW; ++k) {
-            b.depth_mask |= r_u32[0][k]; b.flags |= r_u32[1][k]; b.err |= r_u32[2][k]; b.n_invalid += r_u32[3][k];
-            b.id_or |= r_u32[4][k]; b.id_and &= r_u32[5][k];
-            b.id_max = r_u32[6][k] > b.id_max ? r_u32[6][k] : b.id_max;
-            b.id_min = r_u32[7][k] < b.id_min ? r_u32[7][k] : b.id_min;
-            b.key_or |= r_u64[0][k]; b.key_and &= r_u64[1][k];
-        }
-        aux[tile] = b;
-    }
-    // ---- 3. first entry slot of the tile: decoupled look-back, one wave looks at 64 predecessors per step --------------
+    // ---- 2. first entry slot of the tile: decoupled look-back, one wave looks at 64 predecessors per step --------------
     if (w == 0) {
         u64 base = 0;
         if (tile == 0) {
@@ -501,11 +465,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
     }
     __syncthreads();
     const u64 tile_base = s_base;
-    if (tile_base + wg_cnt > capacity) {  // workgroup-uniform: the prediction was too small -- write nothing, the host re-runs
-        if (tid == 0) atomicOr(&sc->err, (u32)KERR_ENCODE_OVERFLOW);
-        return;
-    }
-    // ---- 4. emit in append order (z outer, y, x inner: src/geom.rs:271-297), one round staged in LDS at a time ----------
+    const bool fits = tile_base + wg_cnt <= capacity;  // workgroup-uniform; false: the prediction was too small, write nothing
+    if (!fits && tid == 0) atomicOr(&sc->err, (u32)KERR_ENCODE_OVERFLOW);
+    // ---- 3. emit in append order (z outer, y, x inner: src/geom.rs:271-297), one round staged in LDS at a time -----------
+    // Each axis coordinate is spread into its Morton lane ONCE per object; the next cell along an axis is a Morton
+    // increment ((m | ~lane) + step) & lane -- three 64-bit operations instead of a five-step spread per cell and axis.
+    u64 kor = 0, kand = ~0ull;
     auto count_digits = [&](u64 key) {
 #pragma unroll
         for (int q = 0; q < SX_HIST_MAX; ++q) {
@@ -519,14 +484,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
         }
     };
     size_t round_base = (size_t)tile_base;
+    if (fits) {
 #pragma unroll
-    for (int r = 0; r < ENC_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const u32 total = round_total[r];
         const size_t this_base = round_base;
         round_base += total;
         if (total == 0) continue;  // workgroup-uniform
         const bool staged = total <= (u32)ENC_STAGE;  // workgroup-uniform
         auto put = [&](u32 local, u64 key, u32 idv, u32 code) {
+            kor |= key;
+            kand &= key;
             if (staged) {
                 s_key[local] = key;
                 s_id[local] = idv;
@@ -536,24 +504,34 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
                 ids_out[this_base + local] = idv;
                 if (box_out) box_out[this_base + local] = (uint8_t)code;
             }
+            count_digits(key);
         };
         if (c[r].count != 0) {
             u32 local = excl[r];
             if (c[r].depth == 0) {
                 put(local, 0ull, id[r], 0u);
-                count_digits(0ull);
             } else {
                 const bool boxy = c[r].n[0] <= 2 && c[r].n[1] <= 2 && c[r].n[2] <= 2;
-                for (u32 z = 0; z < c[r].n[2]; ++z)
-                    for (u32 y = 0; y < c[r].n[1]; ++y)
+                const u32 up = AB - c[r].depth;
+                const u64 step = 1ull << (DIM * up);   // one cell further along an axis, in its own Morton lane
+                const u64 mx0 = spread_bits<DIM>((u64)c[r].lo[0] << up), my0 = spread_bits<DIM>((u64)c[r].lo[1] << up);
+                u64 mz = DIM == 3 ? spread_bits<DIM>((u64)c[r].lo[2] << up) : 0ull;
+                for (u32 z = 0; z < c[r].n[2]; ++z) {
+                    u64 my = my0;
+                    for (u32 y = 0; y < c[r].n[1]; ++y) {
+                        u64 mx = mx0;
                         for (u32 x = 0; x < c[r].n[0]; ++x) {
-                            const u64 key = make_key<KIND>(c[r].depth, c[r].lo[0] + x, c[r].lo[1] + y, c[r].lo[2] + z);
+                            const u64 key = ((mx | (my << 1) | (mz << 2)) << DB) | (u64)c[r].depth;
                             const u32 tx = c[r].n[0] == 1 ? 0u : 1u + x, ty = c[r].n[1] == 1 ? 0u : 1u + y, tz = c[r].n[2] == 1 ? 0u : 1u + z;
                             const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
                             put(local, key, pack_box ? (id[r] | (box_to_packed(code) << BOX_ID_BITS)) : id[r], code);
-                            count_digits(key);
                             ++local;
+                            mx = ((mx | ~LANE0) + step) & LANE0;
                         }
+                        my = ((my | ~LANE0) + step) & LANE0;
+                    }
+                    mz = ((mz | ~LANE0) + step) & LANE0;
+                }
             }
         }
         if (staged) {
@@ -566,8 +544,32 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
             __syncthreads();  // the stage is reused by the next round
         }
     }
+    }
+    // ---- 4. this tile's facts -> aux[tile] (folded by fold_aux_kernel, no atomics) -------------------------------------
+    {
+        const u32 wd = wave_or_u32(dmask), wf = wave_or_u32(flags), we = wave_or_u32(err), wi = wave_sum_u32(inv), wo = wave_or_u32(ior),
+                  wa = wave_and_u32(iand), wm = wave_max_u32(imax), wn = wave_min_u32(imin);
+        const u64 wko = wave_or_u64(kor), wka = wave_and_u64(kand);
+        if (lane == 0) {
+            r_u32[0][w] = wd; r_u32[1][w] = wf; r_u32[2][w] = we; r_u32[3][w] = wi; r_u32[4][w] = wo; r_u32[5][w] = wa;
+            r_u32[6][w] = wm; r_u32[7][w] = wn; r_u64[0][w] = wko; r_u64[1][w] = wka;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        BlockAux b;
+        b.key_or = 0; b.key_and = ~0ull; b.depth_mask = 0; b.flags = 0; b.err = 0; b.n_invalid = 0; b.id_or = 0;
+        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.id_min = 0xFFFFFFFFu;
+        for (int k = 0; k < NW; ++k) {
+            b.depth_mask |= r_u32[0][k]; b.flags |= r_u32[1][k]; b.err |= r_u32[2][k]; b.n_invalid += r_u32[3][k];
+            b.id_or |= r_u32[4][k]; b.id_and &= r_u32[5][k];
+            b.id_max = r_u32[6][k] > b.id_max ? r_u32[6][k] : b.id_max;
+            b.id_min = r_u32[7][k] < b.id_min ? r_u32[7][k] : b.id_min;
+            b.key_or |= r_u64[0][k]; b.key_and &= r_u64[1][k];
+        }
+        aux[tile] = b;
+    }
     if (CELLS) {
-        __syncthreads();
         u64* copy = dc.cell_hist + (size_t)(tile % HIST_COPIES) * (dc.n_cells + 1);
         for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) {
             const u32 v = s_cell[k];
@@ -575,7 +577,6 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
         }
     }
     if (dc.passes) {
-        __syncthreads();
         u64* copy = dc.hist + (size_t)(tile % HIST_COPIES) * (SX_HIST_MAX * 256);
         for (int k = tid; k < dc.passes * 256; k += ENC_THREADS) {
             const u32 v = s_hist[k];
@@ -584,14 +585,15 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb,
     }
 }
 
-// folds the per-tile facts of encode_fused into *sc (single workgroup; sc->total was set by the last tile)
-__global__ __launch_bounds__(1024) void fold_aux_kernel(const BlockAux* __restrict__ aux, size_t n, DevScalars* sc) {
-    __shared__ u64 r_kor[16], r_kand[16];
-    __shared__ u32 r_dm[16], r_fl[16], r_er[16], r_inv[16], r_ior[16], r_iand[16], r_imax[16], r_imin[16];
+// folds the per-tile facts of encode_fused into *sc (sc->total was set by the last tile): every workgroup reduces a slice
+// and adds it with one device atomic per field -- OR / AND / max / min / sum commute, so the result is deterministic
+__global__ __launch_bounds__(256) void fold_aux_kernel(const BlockAux* __restrict__ aux, size_t n, DevScalars* sc) {
+    __shared__ u64 r_kor[4], r_kand[4];
+    __shared__ u32 r_dm[4], r_fl[4], r_er[4], r_inv[4], r_ior[4], r_iand[4], r_imax[4], r_imin[4];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     u64 kor = 0, kand = ~0ull;
     u32 dm = 0, fl = 0, er = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
-    for (size_t i = threadIdx.x; i < n; i += 1024) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const BlockAux b = aux[i];
         kor |= b.key_or; kand &= b.key_and; dm |= b.depth_mask; fl |= b.flags; er |= b.err; inv += b.n_invalid;
         ior |= b.id_or; iand &= b.id_and; imax = b.id_max > imax ? b.id_max : imax; imin = b.id_min < imin ? b.id_min : imin;
@@ -605,12 +607,14 @@ __global__ __launch_bounds__(1024) void fold_aux_kernel(const BlockAux* __restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 16; ++k) {
-            sc->key_or |= r_kor[k]; sc->key_and &= r_kand[k]; sc->depth_mask |= r_dm[k]; sc->flags |= r_fl[k];
-            sc->err |= r_er[k]; sc->n_invalid += r_inv[k]; sc->id_or |= r_ior[k]; sc->id_and &= r_iand[k];
-            sc->id_max = r_imax[k] > sc->id_max ? r_imax[k] : sc->id_max;
-            sc->id_min = r_imin[k] < sc->id_min ? r_imin[k] : sc->id_min;
+        for (int k = 1; k < 4; ++k) {
+            kor |= r_kor[k]; kand &= r_kand[k]; dm |= r_dm[k]; fl |= r_fl[k]; er |= r_er[k]; inv += r_inv[k];
+            ior |= r_ior[k]; iand &= r_iand[k]; imax = r_imax[k] > imax ? r_imax[k] : imax; imin = r_imin[k] < imin ? r_imin[k] : imin;
         }
+        atomicOr(&sc->key_or, kor); atomicAnd(&sc->key_and, kand); atomicOr(&sc->depth_mask, dm); atomicOr(&sc->flags, fl);
+        if (er) atomicOr(&sc->err, er);
+        if (inv) atomicAdd(&sc->n_invalid, inv);
+        atomicOr(&sc->id_or, ior); atomicAnd(&sc->id_and, iand); atomicMax(&sc->id_max, imax); atomicMin(&sc->id_min, imin);
     }
 }
 
@@ -2616,14 +2620,15 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
     return hipGetLastError();
 }
 
-size_t encode_fused_workspace_bytes(size_t n) { return 256 + enc_blocks(n) * sizeof(u64); }
+size_t encode_fused_tiles(size_t n) { return (n + (size_t)ENC_THREADS * ENCF_ROUNDS - 1) / ((size_t)ENC_THREADS * ENCF_ROUNDS); }
+size_t encode_fused_workspace_bytes(size_t n) { return 256 + encode_fused_tiles(n) * sizeof(u64); }
 hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n, uint32_t min_depth,
                                int have_prev_id, uint32_t prev_id, void* workspace, size_t capacity, uint64_t* keys_out,
                                uint32_t* ids_out, uint8_t* box_out, BlockAux* aux, DevScalars* sc, hipStream_t stream,
                                const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
                                uint32_t cell_depth) {
     if (n == 0) return hipSuccess;
-    const unsigned g = (unsigned)enc_blocks(n);
+    const unsigned g = (unsigned)encode_fused_tiles(n);
     hipError_t e = hipMemsetAsync(workspace, 0, encode_fused_workspace_bytes(n), stream);  // tile counter + status words
     if (e != hipSuccess) return e;
     u32* tile_counter = (u32*)workspace;
@@ -2657,7 +2662,7 @@ hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, cons
             box_out, dc, pack_box, aux, sc)));
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    fold_aux_kernel<<<1, 1024, 0, stream>>>(aux, (size_t)g, sc);
+    fold_aux_kernel<<<std::min(64u, (g + 255u) / 256u), 256, 0, stream>>>(aux, (size_t)g, sc);
     return hipGetLastError();
 }
 

@@ -362,7 +362,7 @@ int extend_fused(bp_layer* L, const SysBounds& sb, const float* d_bounds, const 
     const bool pack = h.pack;
     size_t capacity = std::min(L->keys[L->cur].cap / sizeof(uint64_t), L->ids[L->cur].cap / sizeof(uint32_t));
     if (!pack) capacity = std::min(capacity, L->box[L->cur].cap);
-    const size_t nb = enc_blocks(n);
+    const size_t nb = encode_fused_tiles(n);
     BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
     BP_TRY(ensure_dev(L, L->enc_ws, encode_fused_workspace_bytes(n)));
     // the digit plan the coming tree sort will most likely take (it verifies: a different plan only costs its own histogram)
