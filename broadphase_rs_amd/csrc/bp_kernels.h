@@ -141,7 +141,10 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
                       const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
-                      int ready_copies = 1);
+                      int ready_copies = 1, int unstable_first = 0);
+// unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
+// result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
+// varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.
 // blockfill / extent (key-only sorts): keys0 is the block-structured output of the expanding scan --
 // `extent` slots in blocks of SX_BLOCK, of which only the first blockfill[b] of block b hold a
 // record (n records in all).  The histogram and the first pass read around the holes; the result is

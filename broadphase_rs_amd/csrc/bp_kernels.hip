@@ -851,7 +851,9 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 #ifndef RS_MIN_WAVES_PER_EU
 #define RS_MIN_WAVES_PER_EU 1
 #endif
-template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn>
+// STABLE = false: records of equal digit may leave a tile in any order (one returning LDS atomic per record instead of the
+// mask-match rounds).  Valid for the FIRST pass of any LSD sort that does not rely on the input order of equal keys.
+template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool STABLE = true>
 __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
@@ -920,6 +922,16 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     // replace an 8-ballot match.  The masks alias the (not yet used) staging buffer.
     u64* s_mask = reinterpret_cast<u64*>(s_stage) + (size_t)w * RS_BINS;
     const u64 lanebit = 1ull << lane;
+    if constexpr (!STABLE) {
+        // all RS_ITEMS atomics of a lane are independent: they issue back to back, one LDS round trip for the lot
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const u32 dg = digit(key[r]);
+            u32 old = 0;
+            if ((vmask >> r) & 1u) old = (u32)__hip_atomic_fetch_add(&s_cnt[w][dg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            packed[r] = dg | (old << 8);
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const bool valid = (vmask >> r) & 1u;
@@ -1513,6 +1525,77 @@ template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 c
     for (u32 k = 0; k < 8; ++k) t2 |= ((bx.table >> ((~k & 7u) & two)) & 1u) << k;
     return g0 | (g1 << 8) | (g2 << 16) | codebits | (t2 << 24);
 }
+// The same word through a lookup table (the kernels that build context words per entry -- entry_ctx, tgroup_finish2 --
+// are VALU-bound): everything BoxCtx derives besides the per-axis g fields depends only on the box code (27 ternary
+// values) and on the ORDER of the deciding Morton bit positions p_a = DIM * f_a + a of the two-cell axes, i.e. on three
+// comparisons (p_1 > p_0 <=> f_1 >= f_0, p_2 > p_0 <=> f_2 >= f_0, p_2 > p_1 <=> f_2 >= f_1).  CtxLut[code * 8 + cmp] =
+// code fields | table'' << 24, generated at compile time from the same rule as BoxCtx::init.
+struct CtxLut { u32 e[27 * 8]; };
+constexpr u32 ctx_lut_entry(u32 c27, u32 cmp) {
+    const u32 t2 = c27 / 9u, t1 = (c27 % 9u) / 3u, t0 = c27 % 3u;
+    const bool ge10 = cmp & 1u, ge20 = cmp & 2u, ge21 = cmp & 4u;
+    const bool dn0 = t0 == 2u, dn1 = t1 == 2u, dn2 = t2 == 2u;
+    u32 ds = 0;
+    if (t0 && dn0) ds |= 1u << 1;
+    if (t1 && dn1) ds |= 1u << 2;
+    if (t2 && dn2) ds |= 1u << 4;
+    if (t0 && t1 && (ge10 ? dn1 : dn0)) ds |= 1u << 3;
+    if (t0 && t2 && (ge20 ? dn2 : dn0)) ds |= 1u << 5;
+    if (t1 && t2 && (ge21 ? dn2 : dn1)) ds |= 1u << 6;
+    if (t0 && t1 && t2 && ((ge21 && ge20) ? dn2 : (ge10 ? dn1 : dn0))) ds |= 1u << 7;
+    u32 tb = ds;
+    tb |= (tb & 0x55u) << 1;
+    tb |= (tb & 0x33u) << 2;
+    tb |= (tb & 0x0Fu) << 4;
+    const u32 two = (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u);
+    u32 tpp = 0;
+    for (u32 k = 0; k < 8; ++k) tpp |= ((tb >> ((~k & 7u) & two)) & 1u) << k;
+    return (t0 << 6) | (t1 << 14) | (t2 << 22) | (tpp << 24);
+}
+constexpr CtxLut make_ctx_lut() {
+    CtxLut l{};
+    for (u32 c = 0; c < 27; ++c)
+        for (u32 m = 0; m < 8; ++m) l.e[c * 8 + m] = ctx_lut_entry(c, m);
+    return l;
+}
+__constant__ CtxLut g_ctx_lut = make_ctx_lut();
+constexpr int CTX_LUT_WORDS = 27 * 8;
+// every thread of the workgroup calls this before the first entry_ctx_lut (ends with a barrier)
+__device__ __forceinline__ void ctx_lut_load(u32* s_lut) {
+    for (int k = (int)threadIdx.x; k < CTX_LUT_WORDS; k += (int)blockDim.x) s_lut[k] = g_ctx_lut.e[k];
+    __syncthreads();
+}
+// c27: the box code as it travels in the ids (t_x + 3 t_y + 9 t_z, >= 27: unknown)
+template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+    constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
+    const u32 d = key_depth<KIND>(key);
+    if (c27 >= 27u) return d < inactive_below ? CTX_INACTIVE : 0u;  // unknown box: own cell only, never suppressed
+    const u32 t2 = (c27 * 57u) >> 9, r = c27 - 9u * t2, t1 = (r * 11u) >> 5, t0 = r - 3u * t1;
+    const u64 md = d == 0 ? 0ull : ((key >> DB) >> (DIM * (AB - d)));  // DIM * depth Morton bits
+    const u64 valid = d == 0 ? 0ull : ((1ull << (DIM * d)) - 1ull);
+    // per axis: trailing ones (this is the lower cell: the other one is a step up) / zeros (a step down) of the coordinate
+    u32 f0, f1, f2 = 0;
+    {
+        const u64 src = t0 == 1u ? ((~md) & LANE & valid) : (md & LANE);
+        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
+        f0 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
+    }
+    {
+        const u64 src = t1 == 1u ? ((~(md >> 1)) & LANE & (valid >> 1)) : ((md >> 1) & LANE);
+        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
+        f1 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
+    }
+    if (DIM == 3) {
+        const u64 src = t2 == 1u ? ((~(md >> 2)) & LANE & (valid >> 2)) : ((md >> 2) & LANE);
+        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
+        f2 = (c * 171u) >> 9;
+    }
+    const u32 cmp = (f1 >= f0 ? 1u : 0u) | (f2 >= f0 ? 2u : 0u) | (f2 >= f1 ? 4u : 0u);
+    const u32 e = s_lut[c27 * 8u + cmp];
+    if (d < inactive_below) return CTX_INACTIVE | (e & CTX_CODE_MASK);
+    return e | (t0 ? d - f0 : 0u) | ((t1 ? d - f1 : 0u) << 8) | ((t2 ? d - f2 : 0u) << 16);
+}
 // owner-side words of an ancestor entry of depth dd whose own context word is ctx_j
 __device__ __forceinline__ u32 ctx_owner_dj(u32 dd) { return (dd | 32u) * 0x010101u; }
 __device__ __forceinline__ u32 ctx_owner_cbj(u32 ctx_j) { return ctx_j & CTX_CODE_MASK; }
@@ -1531,10 +1614,12 @@ template <int KIND>
 __global__ __launch_bounds__(256) void entry_ctx_kernel(const u64* __restrict__ keys, const u32* __restrict__ ids,
                                                         const uint8_t* __restrict__ box, size_t m, u32 inactive_below,
                                                         u64* __restrict__ idctx) {
+    __shared__ u32 s_lut[CTX_LUT_WORDS];
+    ctx_lut_load(s_lut);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const u32 code = box ? (u32)box[i] : (u32)BOX_UNKNOWN;
-    idctx[i] = ((u64)ids[i] << 32) | (u64)make_entry_ctx<KIND>(keys[i], code, inactive_below);
+    idctx[i] = ((u64)ids[i] << 32) | (u64)entry_ctx_lut<KIND>(keys[i], box_to_packed(code), inactive_below, s_lut);
 }
 
 constexpr int SX_THREADS = 256;
@@ -2431,7 +2516,10 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
     union Aux { struct { u32 cnt[TG2_BINS]; u32 off[TG2_BINS + 4]; } b; u32 id[TGRP_CAP]; };
     __shared__ __attribute__((aligned(16))) Aux s_aux;
     __shared__ u32 s_ws[TGRP_THREADS / 64];
+    __shared__ u32 s_lut[CTX_KIND >= 0 ? CTX_LUT_WORDS : 1];
     static_assert(sizeof(Aux) >= TGRP_CAP * sizeof(u32), "payload view must fit");
+    if constexpr (CTX_KIND >= 0)
+        for (int q = (int)threadIdx.x; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];  // visible after the barriers below
     const u32 g = blockIdx.x, tid = threadIdx.x;
     if (stats && stats[1] > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
@@ -2508,11 +2596,11 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
     for (u32 y = tid; y < ng; y += TGRP_THREADS) {
         const u32 px = s_aux.id[y];
         const u64 ky = s_comp[y];
-        const u32 code = box_from_packed(px >> BOX_ID_BITS);
+        const u32 c27 = px >> BOX_ID_BITS;
         keys_out[(size_t)lo + y] = ky;
         ids_out[(size_t)lo + y] = px & BOX_ID_MASK;
-        box_out[(size_t)lo + y] = (uint8_t)code;
-        if constexpr (CTX_KIND >= 0) idctx_out[(size_t)lo + y] = ((u64)(px & BOX_ID_MASK) << 32) | (u64)make_entry_ctx<CTX_KIND>(ky, code, 0u);
+        box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
+        if constexpr (CTX_KIND >= 0) idctx_out[(size_t)lo + y] = ((u64)(px & BOX_ID_MASK) << 32) | (u64)entry_ctx_lut<CTX_KIND>(ky, c27, 0u, s_lut);
     }
 }
 
@@ -2731,12 +2819,16 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr,
-                                  const u32* blockfill = nullptr, size_t n_out = 0) {
+                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true) {
     // n: extent of the input (tiles are cut from it); n_out: records that exist (== n without holes)
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     if (!blockfill) n_out = n;
-    radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-        ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
+    if (stable)
+        radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
+    else
+        radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, false><<<tiles, RS_THREADS_DEF, 0, stream>>>(
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
     return hipGetLastError();
 }
 
@@ -2744,7 +2836,10 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
-                      const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies) {
+                      const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies,
+                      int unstable_first) {
+    static const bool no_unstable = getenv("BP_NO_UNSTABLE_PASS") != nullptr;  // A/B switch
+    if (no_unstable) unstable_first = 0;
     *result_buf = 0;
     const int np = plan.n_passes;
     if (n == 0 || np == 0) return hipSuccess;
@@ -2791,14 +2886,15 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
             const bool holes = blockfill && p == 0;  // only the first pass sees the block-structured input
             e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, holes ? extent : n,
                                             ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream, nullptr, nullptr,
-                                            holes ? blockfill : nullptr, n);
+                                            holes ? blockfill : nullptr, n, !(unstable_first && p == 0));
         } else if (plan.from_val[p]) {
             e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
         } else {
             // box_in (bytes in the records' CURRENT order) can only be gathered by the very first pass; the codes are
             // split off again by the last pass, which must be a key pass
             e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
-                                          p == 0 ? box_in : nullptr, p == np - 1 ? box_out : nullptr);
+                                          p == 0 ? box_in : nullptr, p == np - 1 ? box_out : nullptr, nullptr, 0,
+                                          !(unstable_first && p == 0));
         }
         if (e != hipSuccess) return e;
         if (mark) mark(mark_ctx, -1);
@@ -3647,12 +3743,15 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
     }
     __syncthreads();
     // one returning LDS atomic per pair: the arrival ticket inside its bin is also its slot there (no second, cursor pass)
-    u32 ticket[GRP_ITEMS];
+    u32 ticket[GRP_ITEMS];  // bin << 16 | arrival ticket (both < 2^16: NBINS = 1024, GRP_CAP = 4096)
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
         ticket[k] = 0;
-        if (x < ng) ticket[k] = __hip_atomic_fetch_add(&s_cnt[bin_of(v[k])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (x < ng) {
+            const u32 b = bin_of(v[k]);
+            ticket[k] = (b << 16) | __hip_atomic_fetch_add(&s_cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     __syncthreads();
     const u32 c0 = s_cnt[2u * tid], c1 = s_cnt[2u * tid + 1u];
@@ -3667,7 +3766,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
-        if (x < ng) s_second[s_off[bin_of(v[k])] + ticket[k]] = (u32)v[k];
+        if (x < ng) s_second[s_off[ticket[k] >> 16] + (ticket[k] & 0xFFFFu)] = (u32)v[k];
     }
     __syncthreads();
     u32 dst[GRP_ITEMS];
@@ -3676,7 +3775,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         const u32 x = (u32)k * GRP_THREADS + tid;
         dst[k] = 0;
         if (x < ng) {
-            const u32 b = bin_of(v[k]), vb = (u32)v[k];
+            const u32 b = ticket[k] >> 16, vb = (u32)v[k];
             const u32 start = s_off[b], end = s_off[b + 1];
             u32 rank = 0;
             if (end - start <= GRP_SEG_MAX) {  // longer: the host discards this output

@@ -740,7 +740,8 @@ int sort_tree(bp_layer* L) {
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
-                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES));
+                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES,
+                                  /*unstable_first=*/1));  // the finish kernel orders every group by (key, id, position)
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             // the finish has key and box code at hand: it also writes the scan's per-entry context words
@@ -799,7 +800,8 @@ int sort_tree(bp_layer* L) {
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
-                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES));
+                                  hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES,
+                                  /*unstable_first=*/1));  // the finish kernel orders every group by (key, id, position)
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             {
@@ -978,7 +980,8 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
         BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), 1,
+                              /*unstable_first=*/1));  // distinct pairs, finished by (first id, second id) in LDS
     }
     BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
     if (n_groups) {
