@@ -46,7 +46,7 @@ enum : unsigned {
     KERR_SEGMENT_TOO_LONG = 4u,  // segment_finish: one first id owns more pairs than its window holds
     KERR_BIGLIST_OVERFLOW = 8u,  // expanding scan: more long-range slices than the work list holds
     KERR_BAD_ID = 16u,           // pick_ray: an id of the tree has no row in the bounds table
-    KERR_ENCODE_OVERFLOW = 32u,  // fused encode: the predicted entry capacity was too small (nothing beyond it was written)
+    KERR_ENCODE_OVERFLOW = 32u,  // encode_emit launched on a PREDICTED capacity that was too small (nothing was written)
 };
 
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
@@ -70,7 +70,6 @@ struct SysBounds {
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
-constexpr int ENCF_ROUNDS = 2;    // ... per tile of encode_fused (the cells of a tile stay in registers across its look-back)
 constexpr int ENC_STAGE = 2048;   // entries of one round staged in LDS by encode_emit (8 per object)
 constexpr int ENC_CELLS_MAX = 512; // cells encode_emit can histogram (8^3 in 3-D, 4^4 in 2-D)
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
@@ -84,24 +83,15 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
-                              unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0);
+                              unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0, DevScalars* sc_guard = nullptr,
+                              size_t capacity = 0);
+// sc_guard / capacity: launched straight behind launch_scan_block_sums, without the host having read the entry total: if
+// sc_guard->total exceeds `capacity` entries the kernel writes nothing and sets KERR_ENCODE_OVERFLOW in sc_guard->err
 // cell_hist / cell_depth: also count the entries per cell at cell_depth (multi-GPU splitter selection) into
 // HIST_COPIES copies of 2^(dim*cell_depth) + 1 counters (zeroed by the caller; at most ENC_CELLS_MAX cells)
 // pack_box: write id | box_to_packed(code) << BOX_ID_BITS into ids_out (box_out may then be nullptr)
 // hist_plan / hist: also count the key digits of every emitted entry for the passes of hist_plan
 // (<= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller)
-
-// One-pass extend (count + look-back prefix + emit): what launch_encode_count / launch_scan_block_sums / launch_encode_emit do
-// together, with the entry capacity, pack_box and hist_plan PREDICTED by the caller.  sc (reset by the caller) receives the
-// entry total, the facts of the ids and KERR_ENCODE_OVERFLOW when the total exceeds `capacity` entries (the output is then
-// incomplete and must be redone).  workspace: encode_fused_workspace_bytes(n) bytes; aux: encode_fused_tiles(n) partials.
-size_t encode_fused_tiles(size_t n);
-size_t encode_fused_workspace_bytes(size_t n);
-hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n, uint32_t min_depth,
-                               int have_prev_id, uint32_t prev_id, void* workspace, size_t capacity, uint64_t* keys_out,
-                               uint32_t* ids_out, uint8_t* box_out, BlockAux* aux, DevScalars* sc, hipStream_t stream,
-                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
-                               unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0);
 
 // exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
 // partials are folded into *sc as well (single workgroup, no atomics)

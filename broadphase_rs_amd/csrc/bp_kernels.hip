@@ -225,10 +225,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                                                                  const u32* __restrict__ counts,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
-                                                                 uint8_t* __restrict__ box_out, DigitCount dc, int pack_box) {
+                                                                 uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
+                                                                 DevScalars* sc_guard, u64 capacity) {
     // pack_box: the box code rides in bits 27..31 of the id from the start (ids < 2^27, see BOX_ID_BITS) and
     // no box byte is written: the first pass of the tree sort then has no byte stream to gather
+    // sc_guard / capacity (launch without a host round trip after the count pass): sc_guard->total is the entry total the
+    // block-sum scan left on the device; beyond `capacity` entries nothing is written and KERR_ENCODE_OVERFLOW is set
     constexpr u32 DIM = KT<KIND>::DIM;
+    if (sc_guard && sc_guard->total > capacity) {  // grid-uniform
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc_guard->err, (u32)KERR_ENCODE_OVERFLOW);
+        return;
+    }
     __shared__ u32 s_ws[ENC_THREADS / 64];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
     __shared__ u32 s_cell[CELLS ? ENC_CELLS_MAX + 1 : 1];  // CELLS: a separate instantiation, the default kernel pays nothing
@@ -337,285 +344,6 @@ __device__ __forceinline__ void st_store(u64* p, u64 v) {
 }
 __device__ __forceinline__ u64 st_load(u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// =================================================================================================
-// Fused encode: Layer::extend (src/layer.rs:94-121) in ONE pass over the objects.  The two-kernel form above
-// reads every AABB twice (count, then emit) with a host round trip in between for the entry total; here a tile of
-// ENC_THREADS x ENC_ROUNDS objects computes its cells once, keeps them in registers, obtains the first entry slot of
-// the tile by a decoupled look-back over the tiles before it (tile ticket from an atomic counter, so a tile only
-// ever waits on tiles that are already running: no dispatch-order assumption; one 8-byte {flag, value} status word per
-// tile, relaxed agent-scope loads / stores -- the guide's "data is the flag" granule), and emits in append order.
-// What the host normally learns from the count pass before it launches the emit pass is PREDICTED from the previous
-// extend of the layer instead -- buffer capacity, whether the box codes can ride in the ids, the digit plan of the
-// coming tree sort -- and verified afterwards: capacity overflow sets KERR_ENCODE_OVERFLOW (nothing beyond the
-// capacity is written), the facts of the ids come back in DevScalars as before; a wrong prediction costs a re-run on
-// the two-kernel path, never a wrong result.
-// =================================================================================================
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const u32 lo = __shfl_xor((u32)v, o, 64), hi = __shfl_xor((u32)(v >> 32), o, 64);
-        v += ((u64)hi << 32) | lo;
-    }
-    return v;
-}
-template <int KIND, bool CELLS>
-__global__ __launch_bounds__(ENC_THREADS) void encode_fused_kernel(SysBounds sb, const float* __restrict__ bounds,
-                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth, int have_prev,
-                                                                  u32 prev_id, u64* tile_status, u32* tile_counter, u64 capacity,
-                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
-                                                                  uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
-                                                                  BlockAux* __restrict__ aux, DevScalars* sc) {
-    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
-    constexpr int NW = ENC_THREADS / 64, ROUNDS = ENCF_ROUNDS;
-    constexpr u64 LANE0 = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;  // Morton lane of axis 0
-    __shared__ u32 s_ws[NW];
-    __shared__ u32 s_hist[SX_HIST_MAX * 256];
-    __shared__ u32 s_cell[CELLS ? ENC_CELLS_MAX + 1 : 1];
-    __shared__ u64 s_key[ENC_STAGE];
-    __shared__ u32 s_id[ENC_STAGE];
-    __shared__ uint8_t s_box[ENC_STAGE];
-    __shared__ u32 s_tile;
-    __shared__ u64 s_base;
-    __shared__ u32 r_u32[8][NW];
-    __shared__ u64 r_u64[2][NW];
-    const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
-    for (int k = tid; k < dc.passes * 256; k += ENC_THREADS) s_hist[k] = 0;
-    if (CELLS)
-        for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) s_cell[k] = 0;
-    __syncthreads();
-    const u32 tile = s_tile;
-    const size_t n_tiles = (n + (size_t)ENC_THREADS * ROUNDS - 1) / ((size_t)ENC_THREADS * ROUNDS);
-    // ---- 1. cells of this tile's objects (kept in registers), entry counts, facts of the ids ---------------------------
-    Cells<KIND> c[ROUNDS];
-    u32 id[ROUNDS];
-    u32 wg_cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const size_t i = ((size_t)tile * ROUNDS + r) * ENC_THREADS + tid;
-        c[r].count = 0; c[r].depth = 0; c[r].valid = false; c[r].overflow = false;
-        c[r].lo[0] = c[r].lo[1] = c[r].lo[2] = 0; c[r].n[0] = c[r].n[1] = c[r].n[2] = 1;
-        id[r] = 0;
-        if (i < n) {
-            c[r] = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
-            id[r] = ids[i];
-            u32 prev = prev_id;
-            bool hp = have_prev != 0;
-            if (i > 0) { prev = ids[i - 1]; hp = true; }
-            if (hp) {
-                if (id[r] < prev) flags |= EXT_IDS_DECREASE | EXT_IDS_REPEAT;
-                else if (id[r] == prev) flags |= EXT_IDS_REPEAT;
-            }
-            imax = id[r] > imax ? id[r] : imax;
-            imin = id[r] < imin ? id[r] : imin;
-            if (c[r].overflow && c[r].valid) err |= KERR_COUNT_OVERFLOW;
-            if (!c[r].valid) inv += 1;
-            if (c[r].count > 0) {
-                if (c[r].n[0] > 2 || c[r].n[1] > 2 || c[r].n[2] > 2) flags |= EXT_BOX_UNKNOWN;
-                dmask |= 1u << c[r].depth;
-                ior |= id[r];
-                iand &= id[r];
-            }
-        }
-    }
-    // per-round exclusive offsets inside the workgroup
-    u32 excl[ROUNDS], round_total[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        excl[r] = block_excl_scan_u32<ENC_THREADS>(c[r].count, s_ws, round_total[r]);
-        wg_cnt += round_total[r];
-    }
-    // ---- 2. first entry slot of the tile: decoupled look-back, one wave looks at 64 predecessors per step --------------
-    if (w == 0) {
-        u64 base = 0;
-        if (tile == 0) {
-            if (lane == 0) st_store(tile_status, ST_FLAG_PRE | (u64)wg_cnt);
-        } else {
-            if (lane == 0) st_store(tile_status + tile, ST_FLAG_AGG | (u64)wg_cnt);
-            long long p = (long long)tile;  // tiles [p, tile) are summed into base
-            u32 spins = 0;
-            for (;;) {
-                const long long q = p - 1 - lane;
-                const u64 sv = q >= 0 ? st_load(tile_status + q) : (ST_FLAG_PRE | 0ull);  // "tile -1" holds the prefix 0
-                const u32 f = (u32)(sv >> 62);
-                const u64 not_ready = __ballot(f == 0), is_pre = __ballot(f == 2);
-                const int first_nr = not_ready ? (int)__builtin_ctzll(not_ready) : 64;
-                const int first_pre = is_pre ? (int)__builtin_ctzll(is_pre) : 64;
-                const bool hit = first_pre < first_nr;              // a prefix before any gap: done after this step
-                const int upto = hit ? first_pre + 1 : first_nr;    // lanes [0, upto) contribute
-                base += wave_sum_u64(lane < upto ? (sv & ST_VALUE) : 0ull);
-                if (hit) break;
-                p -= upto;
-                if (upto == 0) {
-                    if (++spins > LOOKBACK_SPIN_LIMIT) {  // never expected; keeps every wave finite
-                        if (lane == 0) atomicOr(&sc->err, (u32)KERR_LOOKBACK_TIMEOUT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (lane == 0) st_store(tile_status + tile, ST_FLAG_PRE | (base + (u64)wg_cnt));
-        }
-        if (lane == 0) {
-            s_base = base;
-            if ((size_t)tile + 1 == n_tiles) sc->total = base + (u64)wg_cnt;   // the layer's entry total
-        }
-    }
-    __syncthreads();
-    const u64 tile_base = s_base;
-    const bool fits = tile_base + wg_cnt <= capacity;  // workgroup-uniform; false: the prediction was too small, write nothing
-    if (!fits && tid == 0) atomicOr(&sc->err, (u32)KERR_ENCODE_OVERFLOW);
-    // ---- 3. emit in append order (z outer, y, x inner: src/geom.rs:271-297), one round staged in LDS at a time -----------
-    // Each axis coordinate is spread into its Morton lane ONCE per object; the next cell along an axis is a Morton
-    // increment ((m | ~lane) + step) & lane -- three 64-bit operations instead of a five-step spread per cell and axis.
-    u64 kor = 0, kand = ~0ull;
-    auto count_digits = [&](u64 key) {
-#pragma unroll
-        for (int q = 0; q < SX_HIST_MAX; ++q) {
-            if (q < dc.passes)
-                __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(key >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (CELLS) {
-            const u32 slot = ((u32)key & dc.depth_mask) < dc.cell_depth ? dc.n_cells : (u32)(key >> dc.cell_shift);
-            __hip_atomic_fetch_add(&s_cell[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    size_t round_base = (size_t)tile_base;
-    if (fits) {
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const u32 total = round_total[r];
-        const size_t this_base = round_base;
-        round_base += total;
-        if (total == 0) continue;  // workgroup-uniform
-        const bool staged = total <= (u32)ENC_STAGE;  // workgroup-uniform
-        auto put = [&](u32 local, u64 key, u32 idv, u32 code) {
-            kor |= key;
-            kand &= key;
-            if (staged) {
-                s_key[local] = key;
-                s_id[local] = idv;
-                s_box[local] = (uint8_t)code;
-            } else {
-                keys_out[this_base + local] = key;
-                ids_out[this_base + local] = idv;
-                if (box_out) box_out[this_base + local] = (uint8_t)code;
-            }
-            count_digits(key);
-        };
-        if (c[r].count != 0) {
-            u32 local = excl[r];
-            if (c[r].depth == 0) {
-                put(local, 0ull, id[r], 0u);
-            } else {
-                const bool boxy = c[r].n[0] <= 2 && c[r].n[1] <= 2 && c[r].n[2] <= 2;
-                const u32 up = AB - c[r].depth;
-                const u64 step = 1ull << (DIM * up);   // one cell further along an axis, in its own Morton lane
-                const u64 mx0 = spread_bits<DIM>((u64)c[r].lo[0] << up), my0 = spread_bits<DIM>((u64)c[r].lo[1] << up);
-                u64 mz = DIM == 3 ? spread_bits<DIM>((u64)c[r].lo[2] << up) : 0ull;
-                for (u32 z = 0; z < c[r].n[2]; ++z) {
-                    u64 my = my0;
-                    for (u32 y = 0; y < c[r].n[1]; ++y) {
-                        u64 mx = mx0;
-                        for (u32 x = 0; x < c[r].n[0]; ++x) {
-                            const u64 key = ((mx | (my << 1) | (mz << 2)) << DB) | (u64)c[r].depth;
-                            const u32 tx = c[r].n[0] == 1 ? 0u : 1u + x, ty = c[r].n[1] == 1 ? 0u : 1u + y, tz = c[r].n[2] == 1 ? 0u : 1u + z;
-                            const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
-                            put(local, key, pack_box ? (id[r] | (box_to_packed(code) << BOX_ID_BITS)) : id[r], code);
-                            ++local;
-                            mx = ((mx | ~LANE0) + step) & LANE0;
-                        }
-                        my = ((my | ~LANE0) + step) & LANE0;
-                    }
-                    mz = ((mz | ~LANE0) + step) & LANE0;
-                }
-            }
-        }
-        if (staged) {
-            __syncthreads();
-            for (u32 k = threadIdx.x; k < total; k += ENC_THREADS) {
-                keys_out[this_base + k] = s_key[k];
-                ids_out[this_base + k] = s_id[k];
-                if (box_out) box_out[this_base + k] = s_box[k];
-            }
-            __syncthreads();  // the stage is reused by the next round
-        }
-    }
-    }
-    // ---- 4. this tile's facts -> aux[tile] (folded by fold_aux_kernel, no atomics) -------------------------------------
-    {
-        const u32 wd = wave_or_u32(dmask), wf = wave_or_u32(flags), we = wave_or_u32(err), wi = wave_sum_u32(inv), wo = wave_or_u32(ior),
-                  wa = wave_and_u32(iand), wm = wave_max_u32(imax), wn = wave_min_u32(imin);
-        const u64 wko = wave_or_u64(kor), wka = wave_and_u64(kand);
-        if (lane == 0) {
-            r_u32[0][w] = wd; r_u32[1][w] = wf; r_u32[2][w] = we; r_u32[3][w] = wi; r_u32[4][w] = wo; r_u32[5][w] = wa;
-            r_u32[6][w] = wm; r_u32[7][w] = wn; r_u64[0][w] = wko; r_u64[1][w] = wka;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        BlockAux b;
-        b.key_or = 0; b.key_and = ~0ull; b.depth_mask = 0; b.flags = 0; b.err = 0; b.n_invalid = 0; b.id_or = 0;
-        b.id_and = 0xFFFFFFFFu; b.id_max = 0; b.id_min = 0xFFFFFFFFu;
-        for (int k = 0; k < NW; ++k) {
-            b.depth_mask |= r_u32[0][k]; b.flags |= r_u32[1][k]; b.err |= r_u32[2][k]; b.n_invalid += r_u32[3][k];
-            b.id_or |= r_u32[4][k]; b.id_and &= r_u32[5][k];
-            b.id_max = r_u32[6][k] > b.id_max ? r_u32[6][k] : b.id_max;
-            b.id_min = r_u32[7][k] < b.id_min ? r_u32[7][k] : b.id_min;
-            b.key_or |= r_u64[0][k]; b.key_and &= r_u64[1][k];
-        }
-        aux[tile] = b;
-    }
-    if (CELLS) {
-        u64* copy = dc.cell_hist + (size_t)(tile % HIST_COPIES) * (dc.n_cells + 1);
-        for (u32 k = threadIdx.x; k <= dc.n_cells; k += ENC_THREADS) {
-            const u32 v = s_cell[k];
-            if (v) atomicAdd(&copy[k], (u64)v);
-        }
-    }
-    if (dc.passes) {
-        u64* copy = dc.hist + (size_t)(tile % HIST_COPIES) * (SX_HIST_MAX * 256);
-        for (int k = tid; k < dc.passes * 256; k += ENC_THREADS) {
-            const u32 v = s_hist[k];
-            if (v) atomicAdd(&copy[k], (u64)v);
-        }
-    }
-}
-
-// folds the per-tile facts of encode_fused into *sc (sc->total was set by the last tile): every workgroup reduces a slice
-// and adds it with one device atomic per field -- OR / AND / max / min / sum commute, so the result is deterministic
-__global__ __launch_bounds__(256) void fold_aux_kernel(const BlockAux* __restrict__ aux, size_t n, DevScalars* sc) {
-    __shared__ u64 r_kor[4], r_kand[4];
-    __shared__ u32 r_dm[4], r_fl[4], r_er[4], r_inv[4], r_ior[4], r_iand[4], r_imax[4], r_imin[4];
-    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
-    u64 kor = 0, kand = ~0ull;
-    u32 dm = 0, fl = 0, er = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const BlockAux b = aux[i];
-        kor |= b.key_or; kand &= b.key_and; dm |= b.depth_mask; fl |= b.flags; er |= b.err; inv += b.n_invalid;
-        ior |= b.id_or; iand &= b.id_and; imax = b.id_max > imax ? b.id_max : imax; imin = b.id_min < imin ? b.id_min : imin;
-    }
-    kor = wave_or_u64(kor); kand = wave_and_u64(kand); dm = wave_or_u32(dm); fl = wave_or_u32(fl);
-    er = wave_or_u32(er); inv = wave_sum_u32(inv); ior = wave_or_u32(ior); iand = wave_and_u32(iand);
-    imax = wave_max_u32(imax); imin = wave_min_u32(imin);
-    if (lane == 0) {
-        r_kor[w] = kor; r_kand[w] = kand; r_dm[w] = dm; r_fl[w] = fl; r_er[w] = er; r_inv[w] = inv;
-        r_ior[w] = ior; r_iand[w] = iand; r_imax[w] = imax; r_imin[w] = imin;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) {
-            kor |= r_kor[k]; kand &= r_kand[k]; dm |= r_dm[k]; fl |= r_fl[k]; er |= r_er[k]; inv += r_inv[k];
-            ior |= r_ior[k]; iand &= r_iand[k]; imax = r_imax[k] > imax ? r_imax[k] : imax; imin = r_imin[k] < imin ? r_imin[k] : imin;
-        }
-        atomicOr(&sc->key_or, kor); atomicAnd(&sc->key_and, kand); atomicOr(&sc->depth_mask, dm); atomicOr(&sc->flags, fl);
-        if (er) atomicOr(&sc->err, er);
-        if (inv) atomicAdd(&sc->n_invalid, inv);
-        atomicOr(&sc->id_or, ior); atomicAnd(&sc->id_and, iand); atomicMax(&sc->id_max, imax); atomicMin(&sc->id_min, imin);
-    }
 }
 
 __global__ __launch_bounds__(RS_BINS) void hist_reduce_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist) {
@@ -2676,7 +2404,7 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
-                              uint32_t cell_depth) {
+                              uint32_t cell_depth, DevScalars* sc_guard, size_t capacity) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
@@ -2700,58 +2428,26 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
     }
     if (dc.cell_hist) {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
+                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     } else {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
-                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box)));
+                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     }
     return hipGetLastError();
 }
 
-size_t encode_fused_tiles(size_t n) { return (n + (size_t)ENC_THREADS * ENCF_ROUNDS - 1) / ((size_t)ENC_THREADS * ENCF_ROUNDS); }
-size_t encode_fused_workspace_bytes(size_t n) { return 256 + encode_fused_tiles(n) * sizeof(u64); }
-hipError_t launch_encode_fused(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n, uint32_t min_depth,
-                               int have_prev_id, uint32_t prev_id, void* workspace, size_t capacity, uint64_t* keys_out,
-                               uint32_t* ids_out, uint8_t* box_out, BlockAux* aux, DevScalars* sc, hipStream_t stream,
-                               const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
-                               uint32_t cell_depth) {
-    if (n == 0) return hipSuccess;
-    const unsigned g = (unsigned)encode_fused_tiles(n);
-    hipError_t e = hipMemsetAsync(workspace, 0, encode_fused_workspace_bytes(n), stream);  // tile counter + status words
-    if (e != hipSuccess) return e;
-    u32* tile_counter = (u32*)workspace;
-    u64* tile_status = (u64*)((unsigned char*)workspace + 256);
-    DigitCount dc;
-    const KindInfo ki = kind_info(kind);
-    dc.cell_hist = nullptr; dc.cell_shift = 0; dc.cell_depth = 0; dc.n_cells = 0; dc.depth_mask = (1u << ki.depth_bits) - 1u;
-    if (cell_hist && cell_depth > 0 && ki.dim * cell_depth <= 12 && (1u << (ki.dim * cell_depth)) <= (uint32_t)ENC_CELLS_MAX) {
-        dc.cell_hist = (u64*)cell_hist;
-        dc.cell_depth = cell_depth;
-        dc.n_cells = 1u << (ki.dim * cell_depth);
-        dc.cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * cell_depth);
+// resident workgroups of a persistent kernel = CUs x occupancy (queried once per kernel)
+template <typename Kern>
+static unsigned resident_blocks(Kern kernel, int threads) {
+    int dev = 0, cus = 256, per_cu = 4;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    dc.hist = (u64*)hist; dc.passes = 0;
-    for (int q = 0; q < SX_HIST_MAX; ++q) dc.shift[q] = 0;
-    if (hist_plan && hist && hist_plan->n_passes <= SX_HIST_MAX) {
-        bool key_digits_only = true;
-        for (int q = 0; q < hist_plan->n_passes; ++q) key_digits_only = key_digits_only && !hist_plan->from_val[q];
-        if (key_digits_only) {
-            dc.passes = hist_plan->n_passes;
-            for (int q = 0; q < hist_plan->n_passes; ++q) dc.shift[q] = hist_plan->shift[q];
-        }
-    }
-    if (dc.cell_hist) {
-        BP_DISPATCH_KIND(kind, (encode_fused_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(
-            sb, bounds, ids, n, min_depth, have_prev_id, prev_id, tile_status, tile_counter, (u64)capacity, (u64*)keys_out, ids_out,
-            box_out, dc, pack_box, aux, sc)));
-    } else {
-        BP_DISPATCH_KIND(kind, (encode_fused_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(
-            sb, bounds, ids, n, min_depth, have_prev_id, prev_id, tile_status, tile_counter, (u64)capacity, (u64*)keys_out, ids_out,
-            box_out, dc, pack_box, aux, sc)));
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    fold_aux_kernel<<<std::min(64u, (g + 255u) / 256u), 256, 0, stream>>>(aux, (size_t)g, sc);
-    return hipGetLastError();
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) == hipSuccess && nb > 0) per_cu = nb;
+    (void)hipGetLastError();
+    return (unsigned)(cus * per_cu);
 }
 
 hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
@@ -3039,20 +2735,6 @@ hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids,
         default: entry_ctx_kernel<2><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
     }
     return hipGetLastError();
-}
-
-// resident workgroups of a persistent kernel = CUs x occupancy (queried once per kernel)
-template <typename Kern>
-static unsigned resident_blocks(Kern kernel, int threads) {
-    int dev = 0, cus = 256, per_cu = 4;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) == hipSuccess && nb > 0) per_cu = nb;
-    (void)hipGetLastError();
-    return (unsigned)(cus * per_cu);
 }
 
 // one launch instead of a scalar upload and three memsets in front of every scan: neutral reduction scalars,

@@ -113,9 +113,14 @@ struct bp_layer {
     DevBuf tgrp_bounds, tgrp_stats;
     HostBuf h_tstats;
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
-    // one-pass extend: what the previous extend into the empty layer produced predicts what the next one needs
+    // extend without a host round trip between its kernels: what the previous extend into the empty layer produced
+    // predicts what the next one needs
     struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; } enc_hint;
-    DevBuf enc_ws;                      // tile counter + look-back status words of encode_fused
+    // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
+    // NEXT host round trip (the scan's) instead of one of their own
+    struct { bool on = false; int src = 0; bool ride = false; } sort_pend;
+    DevBuf d_sort_sc;                   // DevScalars of the tree sort's kernels (the scan re-initialises d_sc)
+    HostBuf h_sort_sc;
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
     std::vector<ProfRec> prof_pending;
@@ -329,8 +334,11 @@ int ensure_tree_capacity(bp_layer* L, size_t entries) {
     return BP_OK;
 }
 
-// ids committed with their box codes still packed are split before anything but the sort reads them
+int settle_sort(bp_layer* L, bool already_synced = false, bool* redone = nullptr);
+// ids committed with their box codes still packed are split before anything but the sort reads them; a tree sort whose
+// check was deferred is settled first (every accessor of the tree comes through here)
 int ensure_unpacked(bp_layer* L) {
+    if (L->sort_pend.on) BP_TRY(settle_sort(L));
     if (!L->ids_packed) return BP_OK;
     if (L->m) {
         BP_TRY(ensure_dev(L, L->box[L->cur], L->m));
@@ -347,13 +355,16 @@ struct TreeGroupPlan { RadixPlan plan; int gshift; uint32_t n_groups; unsigned l
 bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out);
 
 // ---- extend -------------------------------------------------------------------------------------------
-// One-pass extend into the EMPTY layer (the per-frame pattern) when an earlier extend left a prediction: one kernel, one
-// host round trip (the two-kernel path: two of each).  *done = 0: not applicable or the prediction failed -- nothing of the
-// layer's state was touched and the caller runs the two-kernel path.
-int extend_fused(bp_layer* L, const SysBounds& sb, const float* d_bounds, const uint32_t* d_ids, size_t n, int* done) {
+// Extend into the EMPTY layer (the per-frame pattern) when an earlier extend left a prediction: count, block sums and
+// emit are enqueued back to back and the host reads the outcome ONCE (the plain path: a round trip after the count
+// pass for the entry total, the id facts and the digit plan, and one after the emit pass).  Predicted: entry capacity
+// (guarded on the device: encode_emit writes nothing beyond it), whether the box codes may ride in the ids, the digit
+// plan of the coming tree sort.  *done = 0: not applicable or a prediction failed -- nothing of the layer's state was
+// touched and the caller runs the plain path.
+int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, const uint32_t* d_ids, size_t n, int* done) {
     *done = 0;
     const auto& h = L->enc_hint;
-    // entries scale with the object count; 3 % + one tile of head room, and never less than what is allocated anyway
+    // entries scale with the object count; 3 % + a little head room, and never less than what is allocated anyway
     const double scale = h.n ? (double)n / (double)h.n : 1.0;
     const size_t pred_m = n == h.n ? h.entries : (size_t)((double)h.entries * scale);
     if (pred_m == 0) return BP_OK;
@@ -362,9 +373,10 @@ int extend_fused(bp_layer* L, const SysBounds& sb, const float* d_bounds, const 
     const bool pack = h.pack;
     size_t capacity = std::min(L->keys[L->cur].cap / sizeof(uint64_t), L->ids[L->cur].cap / sizeof(uint32_t));
     if (!pack) capacity = std::min(capacity, L->box[L->cur].cap);
-    const size_t nb = encode_fused_tiles(n);
+    const size_t nb = enc_blocks(n);
+    BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
     BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
-    BP_TRY(ensure_dev(L, L->enc_ws, encode_fused_workspace_bytes(n)));
     // the digit plan the coming tree sort will most likely take (it verifies: a different plan only costs its own histogram)
     RadixPlan hist_plan;
     int seg_shift_unused = 0;
@@ -391,17 +403,28 @@ int extend_fused(bp_layer* L, const SysBounds& sb, const float* d_bounds, const 
     BP_TRY(sc_reset(L));
     {
         ProfScope ps(L, BP_K_ENCODE);
-        HIP_TRY(L, launch_encode_fused(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, L->enc_ws.p, capacity, cur_keys(L), cur_ids(L),
-                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
-                                       count_digits ? &hist_plan : nullptr, count_digits ? (unsigned long long*)L->tree_hist.p : nullptr,
-                                       pack ? 1 : 0, count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth));
+        HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, (uint32_t*)L->counts.p,
+                                       (unsigned long long*)L->block_sums.p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_MISC);
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
+    }
+    {
+        ProfScope ps(L, BP_K_ENCODE);
+        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
+                                      (const unsigned long long*)L->block_sums.p, cur_keys(L), cur_ids(L),
+                                      pack ? nullptr : (uint8_t*)L->box[L->cur].p, L->stream, count_digits ? &hist_plan : nullptr,
+                                      count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0,
+                                      count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth,
+                                      (DevScalars*)L->d_sc.p, capacity));
     }
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));
     const size_t add = (size_t)sc.total;
     const bool can_pack = !(sc.flags & EXT_IDS_REPEAT) && (sc.id_or >> BOX_ID_BITS) == 0;
     if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack)) {
-        // the prediction failed: remember the truth for the next frame and redo this one on the two-kernel path
+        // the prediction failed: remember the truth for the next frame and redo this one on the plain path
         L->enc_hint.entries = add; L->enc_hint.n = n; L->enc_hint.pack = can_pack;
         return BP_OK;
     }
@@ -443,11 +466,11 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         sb.mx[a] = a < ki.dim ? sys_max[a] : 0.f;
     }
     if (L->m) BP_TRY(ensure_unpacked(L));  // appending to a tree whose ids still carry their box codes
-    static const bool no_fused_encode = getenv("BP_NO_FUSED_ENCODE") != nullptr;  // A/B switch
+    static const bool no_predicted = getenv("BP_NO_PREDICTED_EXTEND") != nullptr;  // A/B switch
     const bool was_empty = L->m == 0 && !L->have_ids;
-    if (!no_fused_encode && was_empty && L->enc_hint.valid && L->box_valid && L->ids_distinct) {
+    if (!no_predicted && was_empty && L->enc_hint.valid && L->box_valid && L->ids_distinct) {
         int done = 0;
-        BP_TRY(extend_fused(L, sb, d_bounds, d_ids, n, &done));
+        BP_TRY(extend_predicted(L, sb, d_bounds, d_ids, n, &done));
         if (done) return BP_OK;
     }
     const size_t nb = enc_blocks(n);
@@ -653,7 +676,8 @@ bool same_plan(const RadixPlan& a, const RadixPlan& b) {
     return true;
 }
 
-int sort_tree(bp_layer* L);
+int sort_tree(bp_layer* L, bool defer_check = false);
+int sort_tree_full(bp_layer* L, bool payload_already_packed);
 // tree = [head | sorted tail run]: sort the head alone, then one merge pass.  Returns 1 when it did the job.
 int sort_tree_by_merge(bp_layer* L, int* handled) {
     static const bool disabled = getenv("BP_NO_MERGE_SORT") != nullptr;  // A/B switch
@@ -702,7 +726,38 @@ int sort_tree_by_merge(bp_layer* L, int* handled) {
     return BP_OK;
 }
 
-int sort_tree(bp_layer* L) {
+// The grouped tree sort was enqueued without waiting for it (sort_tree with defer_check): read its error word and group
+// statistics now.  already_synced: the caller has just synchronised the stream.  A group that did not fit (the scene
+// changed under the plan) is repaired here by the full-width sort of the partially sorted data; *redone tells the caller
+// that whatever it enqueued behind the sort read a tree that was not yet in order and must be run again.
+int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
+    if (redone) *redone = false;
+    if (!L->sort_pend.on) return BP_OK;
+    L->sort_pend.on = false;
+    if (!already_synced) BP_TRY(sync_stream(L));
+    const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
+    if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+    L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
+    if (sc.err & KERR_SEGMENT_TOO_LONG) {
+        L->tgrp_ok = false;
+        L->cur = L->sort_pend.src;
+        L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
+        ++L->epoch;
+        BP_TRY(sort_tree_full(L, L->sort_pend.ride));
+        L->ids_packed = false;
+        BP_TRY(ensure_unpacked(L));
+        L->sorted = true;
+        L->order_ok = true;
+        if (redone) *redone = true;
+    }
+    return BP_OK;
+}
+
+int sort_tree(bp_layer* L, bool defer_check) {
+    if (L->sort_pend.on) {
+        if (defer_check && L->sorted) return BP_OK;  // still pending: this caller settles it at its own host round trip
+        BP_TRY(settle_sort(L));
+    }
     if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
     ++L->epoch;
     if (L->tail_run && L->m > 1) {
@@ -731,13 +786,20 @@ int sort_tree(bp_layer* L) {
             BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
             BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
-            BP_TRY(sc_reset(L));
+            BP_TRY(ensure_dev(L, L->d_sort_sc, sizeof(DevScalars)));
+            BP_TRY(ensure_host(L, L->h_sort_sc, 2 * sizeof(DevScalars)));
+            {   // the sort's own scalars (slot 1 of the host buffer is the upload source, slot 0 receives the result)
+                DevScalars* up = (DevScalars*)L->h_sort_sc.p + 1;
+                *up = neutral_scalars();
+                HIP_TRY(L, hipMemcpyAsync(L->d_sort_sc.p, up, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
+            }
+            DevScalars* const d_ssc = (DevScalars*)L->d_sort_sc.p;
             int res = 0;
             uint64_t* kb[2] = {(uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p};
             uint32_t* vb[2] = {(uint32_t*)L->ids[L->cur].p, (uint32_t*)L->ids[other].p};
             const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(gp.plan, L->tree_hist_plan);
             L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
-            HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
+            HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, d_ssc,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
                                   hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES,
@@ -755,28 +817,27 @@ int sort_tree(bp_layer* L) {
                 HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
                                                 (const uint32_t*)L->tgrp_bounds.p, gp.gshift, ride ? 1 : 0, (uint64_t*)L->keys[dst].p,
                                                 (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
-                                                (DevScalars*)L->d_sc.p, L->stream, with_ctx ? L->kind : -1,
+                                                d_ssc, L->stream, with_ctx ? L->kind : -1,
                                                 with_ctx ? (uint64_t*)L->idctx.p : nullptr, (const uint32_t*)L->tgrp_stats.p,
                                                 (uint32_t)(L->m / 4),
                                                 // ids distinct (the codes ride in them): the composite-key kernel may run
                                                 (ride && L->ids_distinct) ? std::max(1, 32 - __builtin_clz(L->id_or | 1u)) : 0));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
-            HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
-            BP_TRY(sync_stream(L));
-            const DevScalars sc = *(DevScalars*)L->h_sc.p;
-            if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
-            L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
-            if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group beyond the multi-round path: full-width sort of the partially sorted data
-                L->tgrp_ok = false;
-                L->cur = src;
-                BP_TRY(sort_tree_full(L, ride));
-            } else {
-                L->cur = dst;
-                L->box_valid = ride;
-                if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; }
-            }
+            HIP_TRY(L, hipMemcpyAsync(L->h_sort_sc.p, L->d_sort_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+            // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
+            L->cur = dst;
+            L->box_valid = ride;
+            if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; }
             L->ids_packed = false;
+            L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride;
+            static const bool no_defer = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
+            if (defer_check && !no_defer) {  // no host round trip here: the check rides on the caller's next one
+                L->sorted = true;
+                L->order_ok = true;
+                return BP_OK;
+            }
+            BP_TRY(settle_sort(L));
             done = true;
         }
         if (!done && partial) {
@@ -1149,14 +1210,19 @@ int make_raw_dense(bp_layer* L);
 int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool source_dedup, const float* filt_bounds = nullptr,
                       uint32_t filt_rows = 0, bool allow_holes = false, const RadixPlan* hist_plan = nullptr,
                       const uint32_t* owner_bounds = nullptr, int owner_n = -1) {
-    BP_TRY(sort_tree(L));
+    BP_TRY(sort_tree(L, /*defer_check=*/true));  // settled at this function's own host round trip (after the scan kernel)
     L->n_raw = 0;
     L->raw_is_unique = false;
     L->raw_holes = false;
     L->pair_hist_valid = false;
     L->owner_hist_valid = false;
-    if (L->m == 0) return BP_OK;
+    if (L->m == 0) return settle_sort(L);
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
+    // the scan kernel ran behind a tree sort whose check was deferred and that check failed: the tree has been repaired,
+    // run the scan again (it read entries that were not yet in order -- memory-safe, but its output is void)
+    auto rerun = [&]() {
+        return scan_fused_device(L, coarse_depth, emit_coarse, source_dedup, filt_bounds, filt_rows, allow_holes, hist_plan, owner_bounds, owner_n);
+    };
     ScanParams p;
     p.keys = (const unsigned long long*)cur_keys(L);
     p.ids = cur_ids(L);
@@ -1229,6 +1295,11 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
             DevScalars sc;
             BP_TRY(sc_fetch(L, &sc));
+            {
+                bool redone = false;
+                BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));
+                if (redone) return rerun();
+            }
             if (sc.err & KERR_BIGLIST_OVERFLOW) {  // pathological nesting: the per-entry walk handles it
                 expand = false;
                 continue;
@@ -1261,6 +1332,11 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         }
         DevScalars sc;
         BP_TRY(sc_fetch(L, &sc));
+        {
+            bool redone = false;
+            BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));
+            if (redone) return rerun();
+        }
         if ((size_t)sc.total <= cap) {
             L->n_raw = (size_t)sc.total;
             L->stats.raw_pairs = L->n_raw;
@@ -1385,7 +1461,7 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
     static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // A/B switches for measurements
     static const bool no_fused = getenv("BP_NO_FUSED_SCAN") != nullptr;
     if (L->ids_distinct && !no_fused) {
-        BP_TRY(sort_tree(L));  // settles box_valid, which decides whether the raw stream will be duplicate-free
+        BP_TRY(sort_tree(L, /*defer_check=*/true));  // settles box_valid (optimistically: scan_fused_device checks), which decides whether the raw stream will be duplicate-free
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv,
                                               !no_source_dedup && L->box_valid && L->box_all_known, L->grp_next);
@@ -1497,9 +1573,9 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->enc_ws); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
-    free_host(L->h_shards); free_host(L->h_tstats);
+    free_host(L->h_shards); free_host(L->h_tstats); free_host(L->h_sort_sc);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
@@ -1533,6 +1609,7 @@ int bp_layer_stream(const bp_layer_t* L, void** stream) {
 
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
+    L->sort_pend.on = false;  // a sort whose result is dropped needs no check (its kernels stay ordered on the stream)
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
     L->m = 0;
@@ -1658,7 +1735,7 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
 int bp_layer_sort(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     DeviceGuard g(L->device);
-    return sort_tree(L);
+    return sort_tree(L, /*defer_check=*/true);  // completion and the check fold into the next call that needs the tree
 }
 int bp_layer_par_sort(bp_layer_t* L) { return bp_layer_sort(L); }
 
