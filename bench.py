@@ -268,13 +268,44 @@ def main():
     d_bounds = torch.from_numpy(bounds).to(dev)
     d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
     torch.cuda.synchronize()
+    # Engine: the whole sharded pipeline behind the C ABI (include/bp_sharded.h: RCCL bound by the library itself --
+    # what a Rust / C++ host calls), or the same steps driven from Python over torch.distributed (dist.py).  The C
+    # engine is tried first; every rank must have joined its RCCL group for it to be used (agreed by an all-reduce).
     from broadphase_rs_amd import dist as bpd
-    sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
+    engine_name = os.environ.get("BP_SHARDED_ENGINE", "c")
+    sharded = None
+    if engine_name == "c" and dist_backend == "nccl":
+        ok = 1
+        try:
+            from broadphase_rs_amd import sharded as bps
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.tensor(list(bps.Group.unique_id()), dtype=torch.uint8, device=dev)
+            dist.broadcast(uid, 0)
+            group = bps.Group.rccl(rank, world, bytes(uid.cpu().tolist()), local_rank)
+            sharded = bps.CShardedLayer(group, rank, bp.Index64_3D, device=local_rank, id_count=n_global)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: C sharded engine unavailable (%s): using torch.distributed\n" % (rank, e))
+            ok = 0
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            sharded = None
+    if sharded is not None:
+        engine_name = "c-abi (include/bp_sharded.h), RCCL bound by the library"
 
-    def step():
-        sharded.clear()
-        sharded.extend(sysb, d_bounds, d_ids)
-        return sharded.par_scan_device()
+        def step():
+            sharded.clear()
+            sharded.extend(sysb, d_bounds, d_ids)
+            return sharded.par_scan_device(args.pair_order)
+    else:
+        engine_name = "python (broadphase_rs_amd/dist.py) over torch.distributed"
+        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
+
+        def step():
+            sharded.clear()
+            sharded.extend(sysb, d_bounds, d_ids)
+            return sharded.par_scan_device()
 
     def barrier():
         torch.cuda.synchronize()
@@ -321,7 +352,8 @@ def main():
                                     % (n_global, world)) if strong else
                                    "%d Index64_3D uniform-random AABBs per GPU x %d GPUs (one %d-object scene)" % (n, world, n_global),
                        "objects_per_gpu": n, "objects_total": n_global, "entries_rank0_shard": st["entries"], "pairs_rank0": n_pairs_local,
-                       "pairs_total": n_pairs, "parallelism": "morton-range shards x%d, RCCL all-to-all + all-gather of boundary keys" % world},
+                       "pairs_total": n_pairs, "parallelism": "morton-range shards x%d, RCCL all-to-all + all-gather of boundary keys" % world,
+                       "engine": engine_name},
             "roofline": None, "cpu_baseline": None,
             "objects_per_s": n_global / (dt / args.steps),
             "list_hash": [cnt, s1, s2],

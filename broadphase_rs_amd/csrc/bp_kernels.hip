@@ -2804,7 +2804,7 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     }
     p.owner_n = -1;
     for (int i = 0; i < 15; ++i) p.owner_bounds[i] = 0xFFFFFFFFu;
-    if (hist && owner_bounds && owner_n >= 0 && owner_n <= 15 && p.hist_passes == 0) {
+    if (hist && (owner_bounds || owner_n == 0) && owner_n >= 0 && owner_n <= 15 && p.hist_passes == 0) {  // owner_n == 0: one owner, no bounds
         p.owner_n = owner_n;
         for (int i = 0; i < owner_n; ++i) p.owner_bounds[i] = owner_bounds[i];
     }

@@ -1,0 +1,176 @@
+"""The multi-GPU Layer behind the C ABI (include/bp_sharded.h, csrc/bp_sharded.hip): CPU checks of the boundary, and on
+the GPU the whole pipeline with LOCAL groups (ranks = host threads of this process, real kernels on one GPU) and with
+a 1-rank RCCL group, against the oracle's list of the union scene."""
+import os
+import re
+import threading
+
+import numpy as np
+import pytest
+
+import broadphase_rs_amd as bp
+from broadphase_rs_amd import scenes, sharded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sharded_header_symbols_all_exported():
+    text = open(os.path.join(ROOT, "include", "bp_sharded.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", text)))
+    lib = bp.load_library()
+    for name in declared:
+        assert hasattr(lib, name), "symbol %s declared in include/bp_sharded.h is not exported" % name
+    assert declared == sorted(sharded.EXPORTS)
+
+
+def test_local_group_lifecycle_and_argument_checks_without_a_gpu():
+    import torch
+    g = sharded.Group.local(3)
+    assert g.world == 3
+    with pytest.raises(bp.BroadphaseError):
+        sharded.CShardedLayer(g, 5)                      # rank out of range
+    if not torch.cuda.is_available():
+        with pytest.raises(bp.BroadphaseError) as ei:    # no CPU fallback: the rank's layers need a device
+            sharded.CShardedLayer(g, 0)
+        assert ei.value.status == "BP_ERR_NO_DEVICE"
+    g.destroy()
+    with pytest.raises(bp.BroadphaseError):
+        sharded.Group.local(0)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+def _giants(parts, world):
+    for r, (sysb, b, _ids) in enumerate(parts):
+        L = float(sysb[1][0])
+        b[0] = [0, 0, 0, L, L, L]
+        b[1] = [0.1 * L * (r + 1) / world, 0, 0, 0.1 * L * (r + 1) / world + 0.4 * L, 0.5 * L, 0.45 * L]
+        b[2] = [0.3 * L, 0.3 * L, 0.3 * L, 0.62 * L, 0.62 * L, 0.62 * L]
+
+
+def _run_local_group(parts, world, frames=1, pair_order="global", id_count=0, device_inputs=True):
+    import torch
+    torch.cuda.init()
+    group = sharded.Group.local(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            sh = sharded.CShardedLayer(group, rank, bp.Index64_3D, device=0, id_count=id_count)
+            sysb, bounds, ids = parts[rank]
+            if device_inputs:
+                b_in, i_in = torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda()
+            else:
+                b_in, i_in = bounds, ids
+            for _frame in range(frames):
+                sh.clear()
+                sh.extend(sysb, b_in, i_in)
+                out = sh.par_scan(pair_order)
+            results[rank] = (out, sh.last, sh.shard_layer.stats())
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    group.destroy()
+    return results
+
+
+def _oracle_pairs(parts):
+    import oracle
+    ref = oracle.OracleLayer(2, 0)
+    for sysb, b, ids in parts:
+        ref.extend(sysb, b, ids)
+    return ref.par_scan()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_per_rank,giants", [(1, 30000, True), (2, 40000, True), (4, 25000, True), (3, 30000, False)])
+def test_c_sharded_local_group_matches_the_oracle(world, n_per_rank, giants):
+    parts = [scenes.gen_boxes_shard(world * n_per_rank, r, world, seed=3) for r in range(world)]
+    if giants:
+        _giants(parts, world)
+    results = _run_local_group(parts, world, frames=2)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    for r in range(world):
+        assert results[r][2]["flags"] == 3          # shard layers ran the fast (key-only sort, distinct-id) kernels
+        assert results[r][1]["pair_order"] == "global" and results[r][1]["box_codes"] == 1
+        if giants:
+            assert results[r][1]["coarse"] >= 3 * world
+        lo, hi = results[r][1]["id_range"]
+        o = results[r][0]
+        assert len(o) == 0 or (o[:, 0].min() >= lo and o[:, 0].max() <= hi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_total,alpha", [(4, 200000, 1.5), (8, 240000, 2.5)])
+def test_c_sharded_powerlaw_and_host_inputs(world, n_total, alpha):
+    parts = [scenes.gen_boxes_powerlaw_shard(n_total, r, world, seed=21, alpha=alpha) for r in range(world)]
+    results = _run_local_group(parts, world, frames=1, id_count=n_total, device_inputs=False)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,empty", [(3, {1: "none"}), (3, {0: "oob", 2: "none"})])
+def test_c_sharded_ranks_that_hold_no_entries(world, empty):
+    parts = [scenes.gen_boxes_shard(world * 30000, r, world, seed=13) for r in range(world)]
+    _giants(parts, world)
+    for r, mode in empty.items():
+        sysb, b, ids = parts[r]
+        parts[r] = (sysb, b[:0], ids[:0]) if mode == "none" else (sysb, b + np.float32(4.0) * np.float32(sysb[1][0]), ids)
+    results = _run_local_group(parts, world, frames=2)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([np.asarray(results[r][0]).reshape(-1, 2) for r in range(world)], axis=0)
+    assert len(expect) > 0 and got.shape == expect.shape and np.array_equal(got, expect)
+    for r in empty:
+        assert results[r][1]["entries_local"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,giants", [(3, False), (2, True)])
+def test_c_sharded_local_pair_order_is_a_disjoint_cover(world, giants):
+    parts = [scenes.gen_boxes_shard(world * 30000, r, world, seed=5) for r in range(world)]
+    if giants:
+        _giants(parts, world)
+    results = _run_local_group(parts, world, pair_order="local")
+    expect = _oracle_pairs(parts)
+    packed = []
+    for r in range(world):
+        out = results[r][0]
+        pk = (out[:, 0].astype(np.uint64) << np.uint64(32)) | out[:, 1].astype(np.uint64)
+        assert np.all(pk[1:] > pk[:-1])
+        packed.append(pk)
+    allp = np.sort(np.concatenate(packed))
+    exp = (expect[:, 0].astype(np.uint64) << np.uint64(32)) | expect[:, 1].astype(np.uint64)
+    assert np.array_equal(allp, exp)
+    assert len({results[r][1]["pair_order"] for r in range(world)}) == 1
+
+
+@pytest.mark.gpu
+def test_c_sharded_single_rank_rccl_group():
+    """the RCCL transport (librccl bound with dlopen) with world = 1 -- all one GPU box can host; the collectives
+    (ncclAllGather, grouped ncclSend / ncclRecv to self) run for real"""
+    import oracle
+    uid = sharded.Group.unique_id()
+    assert len(uid) == 128
+    g = sharded.Group.rccl(0, 1, uid, 0)
+    sysb, bounds, ids = scenes.gen_boxes(120000, seed=9)
+    sh = sharded.CShardedLayer(g, 0, bp.Index64_3D, device=0, id_count=len(ids))
+    for _ in range(2):
+        sh.clear()
+        sh.extend(sysb, bounds, ids)
+        got = sh.par_scan()
+    ref = oracle.OracleLayer(2, 0)
+    ref.extend(sysb, bounds, ids)
+    expect = ref.scan()
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    del sh
+    g.destroy()
