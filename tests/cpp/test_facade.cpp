@@ -1,5 +1,6 @@
 // C++ facade test (GPU): mirrors the reference's usage snippet (src/lib.rs:24-47) and the
 // assertions of tests/test_layer.rs on the SURVEY.md 8(c) worked example.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +83,52 @@ int main() {
     flat.extend(Bounds<2>{{-1, -1}, {1280, 1280}}, {{Bounds<2>{{10, 10}, {20, 20}}, 1}, {Bounds<2>{{15, 15}, {30, 30}}, 2}, {Bounds<2>{{600, 600}, {610, 610}}, 3}});
     auto p2 = flat.par_scan();
     CHECK(p2.size() == 1 && ((p2[0].first == 2 && p2[0].second == 1) || (p2[0].first == 1 && p2[0].second == 2)));
+
+    // ---- the example's frame loop, call for call (examples/main.rs:364-374 layer setup, :410-418 clear + extend over the
+    // circles' AABBs, :420 par_sort, :459 par_scan, :461-479 narrow phase over the candidate pairs).  The Rust shim
+    // (rust/src/lib.rs) has this exact shape; it cannot be compiled here, this twin can.
+    {
+        struct Ball { float x, y, r; };
+        std::vector<Ball> balls;
+        uint32_t rng = 12345u;
+        auto frand = [&]() { rng = rng * 1664525u + 1013904223u; return (float)(rng >> 8) / 16777216.0f; };
+        const float W = 1280.f, H = 720.f;
+        for (int i = 0; i < 2500; ++i) {                                   // BALL_COUNT_MAX (examples/main.rs:304)
+            const float r = std::exp(0.5f + 1.5f * frand());               // :314
+            balls.push_back(Ball{r + (W - 2 * r) * frand(), r + (H - 2 * r) * frand(), r});
+        }
+        const Bounds<2> bounds2{{-1.f, -1.f}, {W, W}};                       // system bounds :163-169
+        auto frame_layer = LayerBuilder::create().with_min_depth(4).build<Index32_2D, uint32_t>();   // :364-374
+        size_t hits_last = 0;
+        for (int frame = 0; frame < 3; ++frame) {
+            for (auto& b : balls) b.y += 0.25f * (float)frame;            // the scene moves between frames
+            std::vector<std::pair<Bounds<2>, uint32_t>> objs;
+            for (uint32_t i = 0; i < balls.size(); ++i)
+                objs.push_back({Bounds<2>{{balls[i].x - balls[i].r, balls[i].y - balls[i].r}, {balls[i].x + balls[i].r, balls[i].y + balls[i].r}}, i});
+            frame_layer.clear();                                           // :410
+            frame_layer.extend(bounds2, objs);                             // :412-418
+            frame_layer.par_sort();                                        // :420
+            auto cand = frame_layer.par_scan();                            // :459
+            size_t hits = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> narrow;
+            for (size_t k = 0; k < cand.size(); ++k) {                     // narrow phase :461-479
+                const Ball &a = balls[cand[k].first], &b = balls[cand[k].second];
+                const float dx = b.x - a.x, dy = b.y - a.y;
+                if (!(std::sqrt(dx * dx + dy * dy) > a.r + b.r)) { ++hits; narrow.push_back({std::min(cand[k].first, cand[k].second), std::max(cand[k].first, cand[k].second)}); }
+            }
+            // the broadphase may only add false positives: every touching pair of circles must be among the candidates
+            size_t brute = 0;
+            for (uint32_t i = 0; i < balls.size(); ++i)
+                for (uint32_t j = i + 1; j < balls.size(); ++j) {
+                    const float dx = balls[j].x - balls[i].x, dy = balls[j].y - balls[i].y;
+                    if (!(std::sqrt(dx * dx + dy * dy) > balls[i].r + balls[j].r)) ++brute;
+                }
+            CHECK(hits == brute && cand.size() >= hits);
+            for (size_t k = 1; k < cand.size(); ++k) CHECK(cand[k - 1] < cand[k]);   // sorted, duplicate-free (tests/test_layer.rs:42-54)
+            hits_last = hits;
+        }
+        std::printf("example frame loop ok: %zu colliding pairs in the last frame\n", hits_last);
+    }
 
     std::printf("facade ok: %zu pairs, %zu merged pairs\n", pairs.size(), merged.size());
     return 0;
