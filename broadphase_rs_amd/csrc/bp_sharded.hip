@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -477,6 +478,15 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     if (hipSetDevice(s->device) != hipSuccess) return sfail(s, BP_ERR_HIP, "hipSetDevice failed");
     s->info = bp_sharded_info{};
     s->d_out = nullptr; s->n_out = 0;
+    typedef std::chrono::steady_clock clk;
+    const clk::time_point t_begin = clk::now();
+    clk::time_point t_prev = t_begin;
+    auto lap = [&](int stage) {   // every stage ends with this rank's device work complete (the layer calls are synchronous)
+        const clk::time_point now = clk::now();
+        s->info.stage_ms[stage] += std::chrono::duration<float, std::milli>(now - t_prev).count();
+        t_prev = now;
+    };
+    auto finish = [&]() { s->info.stage_ms[7] = std::chrono::duration<float, std::milli>(clk::now() - t_begin).count(); };
 
     // ---- 2. cell histogram + facts of every rank in ONE small all-gather ------------------------------------------------
     std::vector<uint64_t> hist(n_cells + 1, 0);
@@ -498,6 +508,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         for (size_t c = 0; c < n_cells; ++c) hist_all[c] += (uint64_t)all[(size_t)r * vlen + c];
     std::vector<uint8_t> lut;
     choose_owner_lut(hist_all, G, lut);
+    lap(0);
     auto fact = [&](int r, int k) { return all[(size_t)r * vlen + n_cells + 1 + k]; };
     // packing (box codes inside the ids) must be decided before the partition, by every rank alike
     bool any_nonempty = false, pack = true, all_known = true;
@@ -515,6 +526,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     const uint64_t* d_keys = nullptr;
     const uint32_t* d_ids = nullptr;
     L_TRY(s, s->local, bp_layer_partition_entries_packed_device(s->local, d_s, lut.data(), n_cells, (uint32_t)G, pack ? 1 : 0, counts.data(), &d_keys, &d_ids));
+    lap(1);
     std::vector<int64_t> cmine(G + 1), cm((size_t)(G + 1) * G);
     for (int k = 0; k <= G; ++k) cmine[k] = (int64_t)counts[k];
     G_TRY(s, grp_allgather_i64(g, rank, cmine.data(), (size_t)G + 1, cm.data()));   // cm[src][dst], cm[src][G] = coarse
@@ -536,6 +548,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         G_TRY(s, grp_allgatherv(g, rank, d_keys + n_fine, coarse_sizes.data(), sizeof(uint64_t), sk + n_recv, s->stream));
         G_TRY(s, grp_allgatherv(g, rank, d_ids + n_fine, coarse_sizes.data(), sizeof(uint32_t), si + n_recv, s->stream));
     }
+    lap(2);
     // facts of the union.  Chunks arrive in rank order and every rank's entries are in its own append order, so the order /
     // distinctness facts hold iff they hold locally everywhere and the ranks' id ranges ascend with the rank
     bp_facts uf;
@@ -561,6 +574,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     uf.flags = ((ascending && order_all) ? BP_FACT_ORDER_OK : 0u) | ((ascending && distinct_all) ? BP_FACT_IDS_DISTINCT : 0u) |
                (pack ? BP_FACT_IDS_CARRY_BOX : 0u) | (all_known ? BP_FACT_BOX_ALL_KNOWN : 0u);
     L_TRY(s, s->shard, bp_layer_commit_entries(s->shard, (size_t)(n_recv + n_coarse), &uf));
+    lap(3);
     s->info.entries_local = m_local;
     s->info.entries_shard = n_recv + n_coarse;
     s->info.coarse = n_coarse;
@@ -578,6 +592,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         size_t np = 0;
         int unique = 0;
         L_TRY(s, s->shard, bp_layer_par_scan_shard_device(s->shard, d_s, emit_coarse, &dp, &np, &unique));
+        lap(4);
         std::vector<int64_t> u1(1, unique ? 0 : 1), uall(G);
         G_TRY(s, grp_allgather_i64(g, rank, u1.data(), 1, uall.data()));
         bool all_unique = true;
@@ -586,6 +601,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
             s->d_out = dp; s->n_out = np;
             s->info.raw_pairs = np; s->info.pairs = np; s->info.id_lo = 0; s->info.id_hi = (uint32_t)max_id; s->info.pair_order = BP_PAIRS_LOCAL;
             *d_pairs = dp; *n_pairs = np;
+            finish();
             return BP_OK;
         }
         // a shard could not vouch for uniqueness after all: take the exchange route (re-scans)
@@ -595,6 +611,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     size_t n_raw = 0;
     int unique = 0;
     L_TRY(s, s->shard, bp_layer_scan_shard_partition_device(s->shard, d_s, emit_coarse, bounds.data(), n_bounds, pcounts.data(), &d_grouped, &n_raw, &unique));
+    lap(4);
     // the final step may skip dedup only if EVERY rank suppressed its duplicates at the source: the flag rides with the counts
     std::vector<int64_t> pmine(G + 1), pm((size_t)(G + 1) * G);
     for (int k = 0; k < G; ++k) pmine[k] = (int64_t)pcounts[k];
@@ -620,6 +637,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         s->recv_cap = want;
     }
     G_TRY(s, grp_alltoallv(g, rank, d_grouped, pcounts.data(), precv.data(), sizeof(uint64_t), s->d_recv_pairs, pmax, s->stream));
+    lap(5);
     const uint64_t lo = rank == 0 ? 0 : bounds[rank - 1];
     const uint64_t hi_raw = rank == G - 1 ? max_id : (uint64_t)bounds[rank] - 1;
     const uint64_t hi = std::max(hi_raw, lo);
@@ -630,6 +648,8 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         L_TRY(s, s->shard, bp_layer_sort_packed_range_device(s->shard, (uint64_t*)s->d_recv_pairs, (size_t)n_in, varying, (uint32_t)lo, (uint32_t)hi, &dp, &np));
     else
         L_TRY(s, s->shard, bp_layer_sort_unique_packed_device(s->shard, (uint64_t*)s->d_recv_pairs, (size_t)n_in, varying, &dp, &np));
+    lap(6);
+    finish();
     s->d_out = dp; s->n_out = np;
     s->info.raw_pairs = n_raw; s->info.raw_pairs_recv = n_in; s->info.pairs = np;
     s->info.id_lo = (uint32_t)lo; s->info.id_hi = (uint32_t)hi_raw; s->info.pair_order = BP_PAIRS_GLOBAL;

@@ -26,7 +26,7 @@ EXPORTS = [
 class _Info(C.Structure):
     _fields_ = [("entries_local", C.c_uint64), ("entries_shard", C.c_uint64), ("coarse", C.c_uint64), ("raw_pairs", C.c_uint64),
                 ("raw_pairs_recv", C.c_uint64), ("pairs", C.c_uint64), ("id_lo", C.c_uint32), ("id_hi", C.c_uint32),
-                ("box_codes", C.c_uint32), ("pair_order", C.c_uint32)]
+                ("box_codes", C.c_uint32), ("pair_order", C.c_uint32), ("stage_ms", C.c_float * 8)]
 
 
 _bound = False
@@ -168,7 +168,10 @@ class CShardedLayer:
     def last(self):
         info = _Info()
         self._check(self._L.bp_sharded_last_info(self._h, C.byref(info)))
-        d = {k: int(getattr(info, k)) for k, _ in _Info._fields_}
+        d = {k: int(getattr(info, k)) for k, _ in _Info._fields_ if k != "stage_ms"}
+        names = ("hist_facts", "partition_entries", "exchange_entries", "shard_commit", "sort_scan_partition", "exchange_pairs",
+                 "sort_pairs", "total")
+        d["stage_ms"] = {n: round(float(v), 3) for n, v in zip(names, info.stage_ms)}
         d["pair_order"] = "local" if d["pair_order"] == PAIRS_LOCAL else "global"
         d["id_range"] = (d.pop("id_lo"), d.pop("id_hi"))
         return d

@@ -85,6 +85,11 @@ typedef struct bp_sharded_info {
     uint32_t id_lo, id_hi;   /* first-id range of this rank (GLOBAL route)                        */
     uint32_t box_codes;      /* the box codes travelled in the ids (duplicates suppressed at the source) */
     uint32_t pair_order;     /* the route taken: BP_PAIRS_GLOBAL / BP_PAIRS_LOCAL                 */
+    /* host wall time of the stages of the last bp_sharded_par_scan on this rank, milliseconds (every stage ends with the
+     * rank's device work complete): 0 cell histogram + all-gather of histograms and facts, 1 partition of the entries by
+     * owner, 2 exchange of entries and boundary keys, 3 commit into the shard layer, 4 shard sort + scan (+ bucketing of
+     * the pairs by owner), 5 exchange of pairs, 6 sort (+ dedup) of this rank's pairs, 7 the whole call */
+    float stage_ms[8];
 } bp_sharded_info;
 int bp_sharded_last_info(const bp_sharded_t *sh, bp_sharded_info *out);
 /* the rank's shard layer (sort / scan target), e.g. for bp_layer_stats; owned by the handle */
