@@ -650,7 +650,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     // replace an 8-ballot match.  The masks alias the (not yet used) staging buffer.
     u64* s_mask = reinterpret_cast<u64*>(s_stage) + (size_t)w * RS_BINS;
     const u64 lanebit = 1ull << lane;
-    if constexpr (!STABLE) {
+    if constexpr (!STABLE && sizeof(s_cnt[0][0]) == 4) {   // (16-bit counters have no native LDS atomic: stable rounds then)
         // all RS_ITEMS atomics of a lane are independent: they issue back to back, one LDS round trip for the lot
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
@@ -724,7 +724,10 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
         } else {
             // LB_BATCH independent status loads per step (one fabric round trip per step instead of
             // per predecessor).  Tile 0 always holds a prefix, so the walk ends there at the latest.
-            constexpr int LB_BATCH = 8;
+#ifndef RS_LB_BATCH
+#define RS_LB_BATCH 8
+#endif
+            constexpr int LB_BATCH = RS_LB_BATCH;
             size_t p = tile;  // tiles [p, tile) are already summed into excl
             u32 spins = 0;
             bool done = false;

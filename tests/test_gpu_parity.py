@@ -258,6 +258,22 @@ def test_powerlaw_deep_stack():
     assert_pairs_equal(gpu.par_scan(), ref.par_scan(), "powerlaw scan")
 
 
+def test_powerlaw_two_million_full_compare():
+    """configs[4]'s shape (mixed scales, Pareto sizes) at a size the oracle still finishes in seconds: tree and pair list
+    element by element, over two frames on one layer (the second one runs on the plan hints)"""
+    sysb, bounds, ids = scenes.gen_boxes_powerlaw(2_000_000, seed=4, alpha=2.5)
+    gpu, ref = both(2)
+    ref.extend(sysb, bounds, ids)
+    ref.par_sort()
+    exp = ref.par_scan()
+    for _frame in range(2):
+        gpu.clear()
+        gpu.extend(sysb, bounds, ids)
+        gpu.par_sort()
+        assert_tree_equal(gpu, ref, "2M power-law sort")
+        assert_pairs_equal(gpu.par_scan(), exp, "2M power-law scan")
+
+
 def test_one_million_boxes_full_compare():
     sysb, bounds, ids = scenes.gen_boxes(1_000_000, seed=0)
     gpu, ref = both(2)
