@@ -320,6 +320,15 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
 // stats (2 words of scratch): group-size statistics; with more than a quarter of the pairs in oversize groups the finish
 // does nothing and sets KERR_SEGMENT_TOO_LONG
 int group_finish_capacity();
+// the same for pairs that may repeat: the first copy of every pair leaves, compacted inside its group's input range, in
+// tmp (ABI layout); counts[0 .. n_groups] (counts[n_groups] = 0) take the groups' unique counts.  After an exclusive scan
+// of counts (launch_scan_block_sums), launch_group_compact moves the groups to their final offsets.
+hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds, uint64_t* tmp,
+                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max);
+hipError_t launch_group_compact(const uint64_t* tmp, const uint32_t* bounds, const unsigned long long* offs, uint32_t n_groups,
+                                uint32_t* pairs_out, hipStream_t stream);
+int group_finish_dups_capacity();
+int group_finish_dups_max_bits();
 hipError_t launch_segment_finish(const uint64_t* in, size_t n, uint32_t* pairs_out, DevScalars* sc, hipStream_t stream);
 // same for pairs that may repeat: equal pairs keep their input order, the output stays packed u64 (sorted), ready
 // for unique_count / unique_emit.  sorted_out must not alias `in`.

@@ -3503,6 +3503,200 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
 }
 int group_finish_capacity() { return GRP_CAP; }
 
+// The grouped finish for pairs that MAY REPEAT (ids shared between objects: the source cannot suppress duplicates).
+// Same plan -- the radix passes stop above the low G bits of the first id (G <= 7, chosen by the host so that a group
+// of 2^G ids fits), one workgroup orders a group in LDS -- with
+// every element ranked by the elements of its bin BELOW it, so that the copies of a pair claim the same slot of the final
+// order and the slots behind it stay free; the taken slots leave, compacted, at the group's input offset in `tmp`, and
+// counts[g] says how many did.  launch_group_compact then closes the gaps
+// between groups (exclusive scan of counts -> final offsets).  Raw lists with repeats are about twice as long per id,
+// hence the larger group capacity (8192) than the distinct kernel's.
+constexpr int GRD_THREADS = 1024, GRD_ITEMS = 12, GRD_CAP = GRD_THREADS * GRD_ITEMS, GRD_WAVES = GRD_THREADS / 64;
+constexpr int GRD_HEADS = GRD_ITEMS * GRD_WAVES, GRD_HEADS_PER_LANE = GRD_HEADS / 64;
+// LDS (dynamic: above the 64 KB a kernel may declare statically): second ids, id-in-group bytes, bin counts / offsets
+constexpr size_t GRD_LDS_BYTES = (size_t)GRD_CAP * 5 + (1024 + 1024 + 1) * 4 + GRD_WAVES * 4 + (GRD_HEADS + 1) * 4 + 64;
+constexpr int GRD_MAX_BITS = 7;  // ids within a group < 128: the byte 0xFF marks a free slot
+constexpr u32 GRD_SEG_MAX = 2048;  // a bin (id x second-id range) longer than this: fall back (quadratic rank loop)
+__global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void group_finish_dups_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
+                                                                        int gbits, int sshift, uint2* __restrict__ tmp,
+                                                                        u64* __restrict__ counts, DevScalars* sc,
+                                                                        const u32* __restrict__ stats) {
+    constexpr u32 NBINS = 1024u;
+    static_assert(NBINS == (u32)GRD_THREADS, "one bin per thread in the prefix scan");
+    static_assert(GRD_HEADS % 64 == 0, "the head counts are scanned by one wave, a few per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    u32* s_second = (u32*)s_dyn;                          // [GRD_CAP]
+    u32* s_cnt = s_second + GRD_CAP;                      // [NBINS]
+    u32* s_off = s_cnt + NBINS;                           // [NBINS + 1]
+    u32* s_ws = s_off + NBINS + 1;                        // [GRD_WAVES]
+    u32* s_heads = s_ws + GRD_WAVES;                      // [GRD_HEADS + 1] heads per (round, wave), then their exclusive prefix; last = total
+    uint8_t* s_idof = (uint8_t*)(s_heads + GRD_HEADS + 2);  // [GRD_CAP] id within the group (< 128) of the slot's pair, 0xFF = free
+    const u32 g = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32 lo = bounds[g], hi = bounds[g + 1];
+    const u32 ng = hi - lo;
+    // any group above the capacity: the host discards this output and runs the ungrouped path
+    if ((stats && stats[1] != 0) || ng > (u32)GRD_CAP) {
+        if (tid == 0) {
+            atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+            counts[g] = 0;
+        }
+        return;
+    }
+    if (ng == 0) {  // workgroup-uniform
+        if (tid == 0) counts[g] = 0;
+        return;
+    }
+    const u32 bmask = (1u << gbits) - 1u;
+    // 1024 bins: id within the group x 2^(10 - gbits) ranges of the second id
+    const u32 sub_bits = 10u - (u32)gbits, sub_max = (1u << sub_bits) - 1u;
+    auto bin_of = [&](u64 v) {
+        const u32 sub = min((u32)v >> sshift, sub_max);
+        return (((u32)(v >> 32) & bmask) << sub_bits) | sub;
+    };
+    s_cnt[tid] = 0;
+    __syncthreads();
+    // registers per element: the second id and one word that is first bin << 16 | arrival ticket, then the final slot
+    // (the id within the group is the bin's high part): 24 + a few, so that two workgroups share a CU
+    // (element state is updated outside the divergent branches: the compiler keeps the arrays as register tuples, and a
+    // tuple assigned inside a branch is copied whole at the join)
+    u32 sec[GRD_ITEMS], tk[GRD_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        const u64 v = in[(size_t)lo + min(x, ng - 1u)];
+        const u32 b = bin_of(v);
+        u32 t = 0;
+        if (x < ng) t = __hip_atomic_fetch_add(&s_cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sec[k] = (u32)v;
+        tk[k] = (b << 16) | t;
+    }
+    __syncthreads();
+    const u32 c0 = s_cnt[tid];
+    u32 total;
+    const u32 excl = block_excl_scan_u32<GRD_THREADS>(c0, s_ws, total);
+    s_off[tid] = excl;
+    if (tid == 0) s_off[NBINS] = ng;
+    if (__any(c0 > GRD_SEG_MAX) && lane == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+    // no slot of the final order is taken yet (four marks per word)
+    for (u32 x = tid; 4u * x < ng; x += GRD_THREADS) reinterpret_cast<u32*>(s_idof)[x] = 0xFFFFFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        if (x < ng) s_second[s_off[tk[k] >> 16] + (tk[k] & 0xFFFFu)] = sec[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        const u32 b = tk[k] >> 16, vb = sec[k];
+        u32 slot = 0;
+        if (x < ng) {
+            const u32 start = s_off[b], end = s_off[b + 1];
+            u32 rank = 0;
+            if (end - start <= GRD_SEG_MAX) {  // longer: the host discards this output
+                // rank = elements of the bin below this one: the copies of a pair all get the same slot
+#pragma unroll 4
+                for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
+            }
+            slot = start + rank;
+        }
+        tk[k] = ((b >> sub_bits) << 16) | slot;  // id within the group << 16 | final slot (< 2^14)
+    }
+    __syncthreads();
+    // the copies of a pair store the same words to the same slot; the slots behind it (one per extra copy) stay marked free
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        if (x < ng) {
+            s_second[tk[k] & 0xFFFFu] = sec[k];
+            s_idof[tk[k] & 0xFFFFu] = (uint8_t)(tk[k] >> 16);
+        }
+    }
+    __syncthreads();
+    // heads: the taken slots, in final order x = round * THREADS + tid
+    u32 idof[GRD_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        idof[k] = x < ng ? (u32)s_idof[x] : 0xFFu;
+        const u64 bal = __ballot(idof[k] != 0xFFu);
+        if (lane == 0) s_heads[k * GRD_WAVES + (int)w] = (u32)__popcll(bal);
+    }
+    __syncthreads();
+    if (w == 0) {
+        u32 h[GRD_HEADS_PER_LANE], sum = 0;
+#pragma unroll
+        for (int q = 0; q < GRD_HEADS_PER_LANE; ++q) {
+            h[q] = s_heads[(u32)GRD_HEADS_PER_LANE * lane + q];
+            sum += h[q];
+        }
+        const u32 incl = wave_incl_scan_u32(sum);
+        u32 run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < GRD_HEADS_PER_LANE; ++q) {
+            s_heads[(u32)GRD_HEADS_PER_LANE * lane + q] = run;
+            run += h[q];
+        }
+        if (lane == 63) s_heads[GRD_HEADS] = incl;
+    }
+    __syncthreads();
+    const u32 first_base = (g0 + g) << gbits;
+#pragma unroll
+    for (int k = 0; k < GRD_ITEMS; ++k) {
+        const u32 x = (u32)k * GRD_THREADS + tid;
+        const bool head = idof[k] != 0xFFu;
+        const u64 bal = __ballot(head);
+        if (head) {
+            const u32 pos = s_heads[k * GRD_WAVES + (int)w] + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+            tmp[(size_t)lo + pos] = make_uint2(first_base | idof[k], s_second[x]);
+        }
+    }
+    if (tid == 0) counts[g] = (u64)s_heads[GRD_HEADS];
+}
+// offs: exclusive scan of the groups' counts, offs[n_groups] = total; the group's heads move from tmp[bounds[g] ..] to out[offs[g] ..]
+__global__ __launch_bounds__(256) void group_compact_kernel(const uint2* __restrict__ tmp, const u32* __restrict__ bounds,
+                                                            const u64* __restrict__ offs, u32 n_groups, uint2* __restrict__ out) {
+    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const u64 o = offs[g];
+        const u32 cnt = (u32)(offs[g + 1] - o), lo = bounds[g];
+        for (u32 x = threadIdx.x; x < cnt; x += 256u) out[o + x] = tmp[(size_t)lo + x];
+    }
+}
+hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds, uint64_t* tmp,
+                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max) {
+    // counts: n_groups + 1 words; counts[n_groups] = 0 so that the exclusive scan leaves the total there
+    if (n == 0 || n_groups == 0) return hipSuccess;
+    if (n >= 0xFFFFFFFFull || gbits < 4 || gbits > GRD_MAX_BITS) return hipErrorInvalidValue;
+    group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
+    hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRD_CAP, stats);
+    e = hipMemsetAsync(counts + n_groups, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    int bits = 0;
+    while (bits < 32 && (second_max >> bits) != 0) ++bits;
+    const int sub_bits = 10 - gbits;
+    const int sshift = bits > sub_bits ? bits - sub_bits : 0;
+    static bool lds_set = false;
+    if (!lds_set) {
+        e = hipFuncSetAttribute((const void*)group_finish_dups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRD_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        lds_set = true;
+    }
+    group_finish_dups_kernel<<<n_groups, GRD_THREADS, GRD_LDS_BYTES, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)tmp, (u64*)counts, sc, stats);
+    return hipGetLastError();
+}
+hipError_t launch_group_compact(const uint64_t* tmp, const uint32_t* bounds, const unsigned long long* offs, uint32_t n_groups,
+                                uint32_t* pairs_out, hipStream_t stream) {
+    if (n_groups == 0) return hipSuccess;
+    group_compact_kernel<<<std::min<unsigned>(n_groups, 8192u), 256, 0, stream>>>((const uint2*)tmp, bounds, (const u64*)offs, n_groups,
+                                                                                 (uint2*)pairs_out);
+    return hipGetLastError();
+}
+int group_finish_dups_capacity() { return GRD_CAP; }
+int group_finish_dups_max_bits() { return GRD_MAX_BITS; }
+
 hipError_t launch_segment_finish_dups(const uint64_t* in, size_t n, uint64_t* sorted_out, DevScalars* sc, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)((n + SEGP_CHUNK - 1) / SEGP_CHUNK);

@@ -106,6 +106,8 @@ struct bp_layer {
     bp_stats stats{};
     bool prof_on = false;
     uint32_t grp_off = 0;               // sorts left for which the grouped pair finish stays off (after a refusal)
+    uint32_t grp_off_dups = 0;          // the same for the grouped finish of pairs that may repeat
+    int grp_next_dups = 0;              // that finish ran last frame on groups of 2^this ids: the scan counts the digits of its plan
     bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
     // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (tgrp_stats) allow it
     bool tgrp_ok = false, tgrp_known = false;
@@ -1072,8 +1074,79 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
 // n packed pairs that MAY REPEAT in buf0: radix sort on the first id only, rank-sort the equal-first-id segments
 // in LDS (equal pairs by position), then the adjacent-unique pass -- 3 passes + finish instead of 6 passes.
 // *done = 0: not applicable / a segment was too long (the caller runs the full-width sort).
-int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes, int* done) {
+int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long varying, bool holes, int* done,
+                       const uint32_t* first_range = nullptr) {
     *done = 0;
+    // grouped route: radix passes above the low 7 (6) bits of the first id, one workgroup per group of ids orders the
+    // group, drops the repeats and leaves its survivors compacted; a copy kernel closes the gaps between groups
+    if (first_range && !L->grp_off_dups && n >= 4096 && n < 0xFFFFFFFFull && first_range[1] >= first_range[0] && segment_finish_enabled() &&
+        !getenv("BP_NO_GROUP_FINISH")) {
+        const uint32_t idv = (uint32_t)(varying >> 32);
+        const unsigned long long span = (unsigned long long)first_range[1] - first_range[0] + 1ull;
+        // groups of 2^gb consecutive first ids: the widest that leaves headroom below the kernel's capacity
+        int gb = group_finish_dups_max_bits();
+        // (the first id of a pair is the larger one: pairs per first id rise linearly over the id range, and the fullest
+        // groups hold about twice the mean)
+        const double mean_max = 0.42 * group_finish_dups_capacity();
+        while (gb > 5 && (double)n * (double)(1u << gb) / (double)span > mean_max) --gb;
+        const double per_group = (double)n * (double)(1u << gb) / (double)span;
+        const uint32_t low = (1u << gb) - 1u;
+        if ((idv >> gb) != 0 && (idv & low) == low && per_group >= 320.0 && per_group <= mean_max) {
+            const uint32_t n_groups = (first_range[1] >> gb) - (first_range[0] >> gb) + 1u;
+            const RadixPlan gplan = make_radix_plan(varying & ~((1ull << (32 + gb)) - 1ull), 0, 0);
+            L->stats.pair_sort_passes = (uint32_t)gplan.n_passes;
+            DevBuf& partner = (buf0 == (uint64_t*)L->pairs[1].p) ? L->pairs[0] : L->pairs[1];
+            BP_TRY(ensure_dev(L, partner, n * sizeof(uint64_t)));
+            uint64_t* bufs[2] = {buf0, (uint64_t*)partner.p};
+            int res = 0;
+            BP_TRY(sc_reset(L));
+            const size_t extent = holes ? L->raw_extent : n;
+            BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, gplan.n_passes)));
+            HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, gplan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
+                                  &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
+                                  holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, gplan, holes), 1,
+                                  /*unstable_first=*/1));  // equal pairs are interchangeable; the finish orders by (first, second)
+            BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->block_sums, ((size_t)n_groups + 1) * sizeof(unsigned long long)));
+            {
+                ProfScope ps(L, BP_K_DEDUP);
+                HIP_TRY(L, launch_group_finish_dups(bufs[res], n, n_groups, first_range[0] >> gb, gb, (uint32_t*)L->grp_bounds.p, bufs[res ^ 1],
+                                                    (unsigned long long*)L->block_sums.p, (DevScalars*)L->d_sc.p, L->stream,
+                                                    (uint32_t*)L->tgrp_stats.p, (uint32_t)(varying & 0xFFFFFFFFull)));
+            }
+            {
+                ProfScope ps(L, BP_K_MISC);
+                HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, (size_t)n_groups + 1, nullptr, (DevScalars*)L->d_sc.p,
+                                                  L->stream));
+            }
+            DevScalars scg;
+            BP_TRY(sc_fetch(L, &scg));
+            if (!(scg.err & KERR_SEGMENT_TOO_LONG)) {
+                const size_t npg = (size_t)scg.total;
+                BP_TRY(ensure_dev(L, L->out_pairs, npg * 2 * sizeof(uint32_t)));
+                {
+                    ProfScope ps(L, BP_K_DEDUP);
+                    HIP_TRY(L, launch_group_compact(bufs[res ^ 1], (const uint32_t*)L->grp_bounds.p, (const unsigned long long*)L->block_sums.p,
+                                                    n_groups, (uint32_t*)L->out_pairs.p, L->stream));
+                }
+                BP_TRY(sync_stream(L));
+                L->n_pairs = npg;
+                L->stats.pairs = npg;
+                L->grp_next_dups = gb;
+                *done = 1;
+                return BP_OK;
+            }
+            // uneven groups: the stream (grouped by the high digits, nothing lost) goes through the ungrouped route below;
+            // the grouped one stays off for the next 16 sorts of this layer
+            L->grp_off_dups = 16;
+            L->grp_next_dups = 0;
+            buf0 = bufs[res];
+            holes = false;
+        }
+    } else if (L->grp_off_dups) {
+        --L->grp_off_dups;
+    }
     const RadixPlan plan = make_radix_plan(varying & 0xFFFFFFFF00000000ull, 0, 0);
     if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return BP_OK;
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
@@ -1196,7 +1269,7 @@ int sort_unique_pairs(bp_layer* L, size_t n, uint32_t id_varying, bool assume_un
     const uint32_t own_range[2] = {L->id_and, L->id_or};
     if (assume_unique) return sort_distinct_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, own_ids ? own_range : nullptr);
     int done = 0;
-    BP_TRY(sort_dups_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, &done));
+    BP_TRY(sort_dups_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, holes, &done, own_ids ? own_range : nullptr));
     if (done) return BP_OK;
     return sort_unique_pairs_in(L, (uint64_t*)L->pairs[0].p, n, varying, false, holes);
 }
@@ -1402,8 +1475,9 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
         HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
         // the sort that follows groups by first id first (sort_dups_pairs_in): count those digits while emitting
         const uint32_t idv = L->id_or ^ L->id_and;
-        const RadixPlan hplan = make_radix_plan(((unsigned long long)idv << 32), 0, 0);
-        const bool count_digits = segment_finish_enabled() && scan_can_count(hplan);
+        // (grp_next_dups: the previous frame's sort took the grouped route, which stops above that many low bits)
+        const RadixPlan hplan = make_radix_plan(((unsigned long long)idv << 32) & ~((1ull << (32 + L->grp_next_dups)) - 1ull), 0, 0);
+        const bool count_digits = segment_finish_enabled() && hplan.n_passes > 0 && scan_can_count(hplan);
         if (count_digits) {
             BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
             HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
@@ -1475,7 +1549,7 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         int done = 0;
         BP_TRY(scan_general_expand_device(L, coarse_depth, emit_coarse, &done));
         if (done) {
-            BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, false, L->raw_holes));
+            BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, false, L->raw_holes, true));
             if (L->n_raw == 0) BP_TRY(sync_stream(L));
             return BP_OK;
         }
@@ -1597,7 +1671,7 @@ int bp_layer_wait_stream(bp_layer_t* L, void* producer_stream) {
 int bp_layer_reset_plan_hints(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
-    L->grp_next = false; L->grp_off = 0;
+    L->grp_next = false; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
     L->enc_hint.valid = false;
     return BP_OK;
 }

@@ -510,6 +510,38 @@ def test_grouped_pair_finish_handles_oversize_and_empty_groups(k):
         gpu.clear(); gpu.extend(sysb, bounds, ids)
 
 
+@pytest.mark.parametrize("density,cluster", [(0.0005, 0), (0.003, 0), (0.0005, 700)])
+def test_grouped_finish_of_pairs_that_repeat(density, cluster):
+    """ids shared by two objects each (src/layer.rs:92-93 allows it): the raw stream holds every pair up to four times,
+    nothing can be suppressed at the source, and the pair sort takes the grouped route that drops the copies inside
+    the LDS finish (radix passes above the group digit, counts per group, compaction).  The denser scene needs groups
+    of 64 ids instead of 128.  cluster > 0: one group far above the group capacity -- the route is refused, the
+    ungrouped sort runs and the list is still the oracle's"""
+    n = 120000
+    sysb, bounds, _ = scenes.gen_boxes(n, seed=57, density=density)
+    ids = (np.arange(n, dtype=np.uint32) >> 1)                    # non-decreasing, every id twice
+    if cluster:
+        L = float(sysb[1][0])
+        rng = np.random.default_rng(3)
+        c = np.float32(0.41) * L
+        lo = c - rng.uniform(0.5, 3.0, size=(cluster, 3)).astype(np.float32)
+        bounds[4096:4096 + cluster] = np.concatenate([lo, lo + np.float32(6.0)], axis=1)
+    gpu, ref = both(2, 0)
+    gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+    exp = ref.scan()
+    raw_ref, _ = ref.scan_raw()
+    assert len(raw_ref) > 1.5 * len(exp) > 100000
+    per_256 = len(raw_ref) * 256 / (n >> 1)
+    if not cluster:                                                # the grouped route's window: 128 ids / 64 ids per group
+        assert (640 < per_256 < 10000) if density < 0.001 else (10400 < per_256 < 20000), per_256
+    for frame in range(3):                                         # frame 1+: the scan counts the shortened plan's digits
+        assert_pairs_equal(np.array(gpu.par_scan()), exp, "pairs that repeat, frame %d" % frame)
+        st = gpu.stats()
+        assert st["raw_pairs"] == len(raw_ref) and st["flags"] & 2 == 0
+        assert st["pair_sort_passes"] <= 2, st
+        gpu.clear(); gpu.extend(sysb, bounds, ids)
+
+
 def _clustered_scene(n, n_cluster, seed, frac):
     """uniform scene whose first n_cluster objects are squeezed into a cube of `frac` of the system side"""
     sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
