@@ -324,7 +324,8 @@ int group_finish_capacity();
 // tmp (ABI layout); counts[0 .. n_groups] (counts[n_groups] = 0) take the groups' unique counts.  After an exclusive scan
 // of counts (launch_scan_block_sums), launch_group_compact moves the groups to their final offsets.
 hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds, uint64_t* tmp,
-                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max);
+                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_lo,
+                                    uint32_t second_hi);
 hipError_t launch_group_compact(const uint64_t* tmp, const uint32_t* bounds, const unsigned long long* offs, uint32_t n_groups,
                                 uint32_t* pairs_out, hipStream_t stream);
 int group_finish_dups_capacity();

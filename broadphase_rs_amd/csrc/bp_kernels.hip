@@ -3504,7 +3504,7 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
 int group_finish_capacity() { return GRP_CAP; }
 
 // The grouped finish for pairs that MAY REPEAT (ids shared between objects: the source cannot suppress duplicates).
-// Same plan -- the radix passes stop above the low G bits of the first id (G <= 7, chosen by the host so that a group
+// Same plan -- the radix passes stop above the low G bits of the first id (G <= 8, chosen by the host so that a group
 // of 2^G ids fits), one workgroup orders a group in LDS -- with
 // every element ranked by the elements of its bin BELOW it, so that the copies of a pair claim the same slot of the final
 // order and the slots behind it stay free; the taken slots leave, compacted, at the group's input offset in `tmp`, and
@@ -3514,11 +3514,11 @@ int group_finish_capacity() { return GRP_CAP; }
 constexpr int GRD_THREADS = 1024, GRD_ITEMS = 12, GRD_CAP = GRD_THREADS * GRD_ITEMS, GRD_WAVES = GRD_THREADS / 64;
 constexpr int GRD_HEADS = GRD_ITEMS * GRD_WAVES, GRD_HEADS_PER_LANE = GRD_HEADS / 64;
 // LDS (dynamic: above the 64 KB a kernel may declare statically): second ids, id-in-group bytes, bin counts / offsets
-constexpr size_t GRD_LDS_BYTES = (size_t)GRD_CAP * 5 + (1024 + 1024 + 1) * 4 + GRD_WAVES * 4 + (GRD_HEADS + 1) * 4 + 64;
-constexpr int GRD_MAX_BITS = 7;  // ids within a group < 128: the byte 0xFF marks a free slot
+constexpr size_t GRD_LDS_BYTES = (size_t)GRD_CAP * 5 + GRD_CAP / 8 + (1024 + 1024 + 1) * 4 + GRD_WAVES * 4 + (GRD_HEADS + 1) * 4 + 64;
+constexpr int GRD_MAX_BITS = 8;
 constexpr u32 GRD_SEG_MAX = 2048;  // a bin (id x second-id range) longer than this: fall back (quadratic rank loop)
 __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void group_finish_dups_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
-                                                                        int gbits, int sshift, uint2* __restrict__ tmp,
+                                                                        int gbits, int sshift, u32 second_lo, uint2* __restrict__ tmp,
                                                                         u64* __restrict__ counts, DevScalars* sc,
                                                                         const u32* __restrict__ stats) {
     constexpr u32 NBINS = 1024u;
@@ -3530,7 +3530,8 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     u32* s_off = s_cnt + NBINS;                           // [NBINS + 1]
     u32* s_ws = s_off + NBINS + 1;                        // [GRD_WAVES]
     u32* s_heads = s_ws + GRD_WAVES;                      // [GRD_HEADS + 1] heads per (round, wave), then their exclusive prefix; last = total
-    uint8_t* s_idof = (uint8_t*)(s_heads + GRD_HEADS + 2);  // [GRD_CAP] id within the group (< 128) of the slot's pair, 0xFF = free
+    u32* s_taken = s_heads + GRD_HEADS + 1;               // [GRD_CAP / 32] one bit per slot of the final order
+    uint8_t* s_idof = (uint8_t*)(s_taken + GRD_CAP / 32);  // [GRD_CAP] id within the group of the slot's pair
     const u32 g = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u32 lo = bounds[g], hi = bounds[g + 1];
     const u32 ng = hi - lo;
@@ -3547,10 +3548,10 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         return;
     }
     const u32 bmask = (1u << gbits) - 1u;
-    // 1024 bins: id within the group x 2^(10 - gbits) ranges of the second id
+    // 1024 bins: id within the group x 2^(10 - gbits) ranges of the second id (second_lo: a lower bound of the ids)
     const u32 sub_bits = 10u - (u32)gbits, sub_max = (1u << sub_bits) - 1u;
     auto bin_of = [&](u64 v) {
-        const u32 sub = min((u32)v >> sshift, sub_max);
+        const u32 sub = min(((u32)v - second_lo) >> sshift, sub_max);
         return (((u32)(v >> 32) & bmask) << sub_bits) | sub;
     };
     s_cnt[tid] = 0;
@@ -3577,8 +3578,8 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     s_off[tid] = excl;
     if (tid == 0) s_off[NBINS] = ng;
     if (__any(c0 > GRD_SEG_MAX) && lane == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
-    // no slot of the final order is taken yet (four marks per word)
-    for (u32 x = tid; 4u * x < ng; x += GRD_THREADS) reinterpret_cast<u32*>(s_idof)[x] = 0xFFFFFFFFu;
+    // no slot of the final order is taken yet
+    if (tid < (u32)GRD_CAP / 32u) s_taken[tid] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < GRD_ITEMS; ++k) {
@@ -3611,6 +3612,7 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         if (x < ng) {
             s_second[tk[k] & 0xFFFFu] = sec[k];
             s_idof[tk[k] & 0xFFFFu] = (uint8_t)(tk[k] >> 16);
+            __hip_atomic_fetch_or(&s_taken[(tk[k] & 0xFFFFu) >> 5], 1u << (tk[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
@@ -3619,8 +3621,9 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
     for (int k = 0; k < GRD_ITEMS; ++k) {
         const u32 x = (u32)k * GRD_THREADS + tid;
-        idof[k] = x < ng ? (u32)s_idof[x] : 0xFFu;
-        const u64 bal = __ballot(idof[k] != 0xFFu);
+        const bool taken = x < ng && ((s_taken[x >> 5] >> (x & 31u)) & 1u) != 0u;
+        idof[k] = taken ? (u32)s_idof[min(x, ng - 1u)] : 0xFFFFu;
+        const u64 bal = __ballot(taken);
         if (lane == 0) s_heads[k * GRD_WAVES + (int)w] = (u32)__popcll(bal);
     }
     __syncthreads();
@@ -3645,7 +3648,7 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
     for (int k = 0; k < GRD_ITEMS; ++k) {
         const u32 x = (u32)k * GRD_THREADS + tid;
-        const bool head = idof[k] != 0xFFu;
+        const bool head = idof[k] != 0xFFFFu;
         const u64 bal = __ballot(head);
         if (head) {
             const u32 pos = s_heads[k * GRD_WAVES + (int)w] + (u32)__popcll(bal & ((1ull << lane) - 1ull));
@@ -3664,7 +3667,8 @@ __global__ __launch_bounds__(256) void group_compact_kernel(const uint2* __restr
     }
 }
 hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds, uint64_t* tmp,
-                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max) {
+                                    unsigned long long* counts, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_lo,
+                                    uint32_t second_hi) {
     // counts: n_groups + 1 words; counts[n_groups] = 0 so that the exclusive scan leaves the total there
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 4 || gbits > GRD_MAX_BITS) return hipErrorInvalidValue;
@@ -3674,8 +3678,8 @@ hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_gro
     tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRD_CAP, stats);
     e = hipMemsetAsync(counts + n_groups, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    int bits = 0;
-    while (bits < 32 && (second_max >> bits) != 0) ++bits;
+    int bits = 0;  // second ids lie in [second_lo, second_hi]
+    while (bits < 32 && ((second_hi - second_lo) >> bits) != 0) ++bits;
     const int sub_bits = 10 - gbits;
     const int sshift = bits > sub_bits ? bits - sub_bits : 0;
     static bool lds_set = false;
@@ -3684,7 +3688,7 @@ hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_gro
         if (e != hipSuccess) return e;
         lds_set = true;
     }
-    group_finish_dups_kernel<<<n_groups, GRD_THREADS, GRD_LDS_BYTES, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)tmp, (u64*)counts, sc, stats);
+    group_finish_dups_kernel<<<n_groups, GRD_THREADS, GRD_LDS_BYTES, stream>>>((const u64*)in, bounds, g0, gbits, sshift, second_lo, (uint2*)tmp, (u64*)counts, sc, stats);
     return hipGetLastError();
 }
 hipError_t launch_group_compact(const uint64_t* tmp, const uint32_t* bounds, const unsigned long long* offs, uint32_t n_groups,

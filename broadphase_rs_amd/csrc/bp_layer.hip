@@ -982,7 +982,11 @@ bool segment_finish_enabled() {
     return !disabled;
 }
 // the plan the sort of a pair stream will use (distinct pairs: first id only, then segment finish)
-RadixPlan pair_sort_plan(unsigned long long varying, bool distinct, bool grouped = false) {
+RadixPlan pair_sort_plan(unsigned long long varying, bool distinct, bool grouped = false, int dups_bits = 0) {
+    if (!distinct && segment_finish_enabled()) {  // sort_dups_pairs_in: first id only, above the grouped finish's low bits
+        const RadixPlan plan = make_radix_plan(varying & ~((1ull << (32 + dups_bits)) - 1ull), 0, 0);
+        if (plan.n_passes > 0) return plan;
+    }
     if (distinct && segment_finish_enabled()) {
         if (grouped) {  // the grouped finish takes the lowest 8 bits of the first id as well
             const RadixPlan plan = make_radix_plan(varying & 0xFFFFFF0000000000ull, 0, 0);
@@ -1085,8 +1089,7 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
         const unsigned long long span = (unsigned long long)first_range[1] - first_range[0] + 1ull;
         // groups of 2^gb consecutive first ids: the widest that leaves headroom below the kernel's capacity
         int gb = group_finish_dups_max_bits();
-        // (the first id of a pair is the larger one: pairs per first id rise linearly over the id range, and the fullest
-        // groups hold about twice the mean)
+        // (headroom of 2.4x the mean: ids handed out along the scene's structure give uneven groups)
         const double mean_max = 0.42 * group_finish_dups_capacity();
         while (gb > 5 && (double)n * (double)(1u << gb) / (double)span > mean_max) --gb;
         const double per_group = (double)n * (double)(1u << gb) / (double)span;
@@ -1113,7 +1116,7 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
                 ProfScope ps(L, BP_K_DEDUP);
                 HIP_TRY(L, launch_group_finish_dups(bufs[res], n, n_groups, first_range[0] >> gb, gb, (uint32_t*)L->grp_bounds.p, bufs[res ^ 1],
                                                     (unsigned long long*)L->block_sums.p, (DevScalars*)L->d_sc.p, L->stream,
-                                                    (uint32_t*)L->tgrp_stats.p, (uint32_t)(varying & 0xFFFFFFFFull)));
+                                                    (uint32_t*)L->tgrp_stats.p, first_range[0], first_range[1]));
             }
             {
                 ProfScope ps(L, BP_K_MISC);
@@ -1538,7 +1541,7 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         BP_TRY(sort_tree(L, /*defer_check=*/true));  // settles box_valid (optimistically: scan_fused_device checks), which decides whether the raw stream will be duplicate-free
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv,
-                                              !no_source_dedup && L->box_valid && L->box_all_known, L->grp_next);
+                                              !no_source_dedup && L->box_valid && L->box_all_known, L->grp_next, L->grp_next_dups);
         BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true, &plan));
         BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes, true));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));

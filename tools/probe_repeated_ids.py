@@ -1,4 +1,5 @@
-"""frame times of a 10 M-object scene whose ids repeat (every id on two objects): the duplicate-tolerant pair route"""
+"""frame times of a 10 M-object scene whose ids repeat (every id on two objects; `big`: distinct ids >= 2^27, which
+cannot carry box codes): the duplicate-tolerant pair route"""
 import numpy as np, time, sys
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -7,7 +8,7 @@ from broadphase_rs_amd.layer import Layer, Index64_3D
 import torch
 n = 10_000_000
 sysb, bounds, ids = scenes.gen_boxes(n, seed=1)
-ids2 = (np.arange(n, dtype=np.uint32) >> 1)
+ids2 = (np.arange(n, dtype=np.uint32) >> 1) if "big" not in sys.argv else (np.arange(n, dtype=np.uint32) + np.uint32(1 << 27))
 L = Layer(Index64_3D)
 db = torch.from_numpy(bounds).cuda(); di = torch.from_numpy(ids2).cuda()
 for f in range(6):
