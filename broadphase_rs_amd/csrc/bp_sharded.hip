@@ -121,6 +121,9 @@ void local_break(bp_group* g) {
     g->cv.notify_all();
 }
 
+// test switch: the part of an exchange that stays on the rank also goes through ncclSend / ncclRecv (a one-rank group
+// then exercises the whole RCCL binding)
+bool self_through_rccl() { return getenv("BP_SHARDED_SELF_SEND") != nullptr; }  // read per call: tests flip it
 constexpr size_t CHUNK_BYTES = 256u << 20;  // per-peer message size cap (RCCL of PyTorch-ROCm 2.10 halves messages > 1 GiB)
 
 #define RCCL_TRY(g, call)                                                                                   \
@@ -195,9 +198,14 @@ int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_
     const RcclApi* a = rccl_api();
     const uint64_t ch = std::max<uint64_t>(1, CHUNK_BYTES / elem);
     const uint64_t rounds = std::max<uint64_t>(1, (max_msg + ch - 1) / ch);
+    // the part that stays on this rank is a device copy (about three times the rate of a send to oneself)
+    if (send_counts[rank] && !self_through_rccl())
+        GHIP_TRY(g, hipMemcpyAsync((char*)recv + roff[rank] * elem, (const char*)send + soff[rank] * elem, send_counts[rank] * elem,
+                                   hipMemcpyDeviceToDevice, g->stream));
     for (uint64_t rd = 0; rd < rounds; ++rd) {
         RCCL_TRY(g, a->GroupStart());
         for (int p = 0; p < W; ++p) {
+            if (p == rank && !self_through_rccl()) continue;
             const uint64_t s0 = std::min(send_counts[p], rd * ch), s1 = std::min(send_counts[p], (rd + 1) * ch);
             const uint64_t r0 = std::min(recv_counts[p], rd * ch), r1 = std::min(recv_counts[p], (rd + 1) * ch);
             if (s1 > s0) RCCL_TRY(g, a->Send((const char*)send + (soff[p] + s0) * elem, (s1 - s0) * elem, RCCL_INT8, p, g->comm, g->stream));
@@ -248,6 +256,62 @@ int grp_allgatherv(bp_group* g, int rank, const void* send, const uint64_t* size
             const uint64_t r0 = std::min(sizes[p], rd * ch), r1 = std::min(sizes[p], (rd + 1) * ch);
             if (s1 > s0) RCCL_TRY(g, a->Send((const char*)send + s0 * elem, (s1 - s0) * elem, RCCL_INT8, p, g->comm, g->stream));
             if (r1 > r0) RCCL_TRY(g, a->Recv((char*)recv + (roff[p] + r0) * elem, (r1 - r0) * elem, RCCL_INT8, p, g->comm, g->stream));
+        }
+        RCCL_TRY(g, a->GroupEnd());
+    }
+    GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    return BP_OK;
+}
+
+// Several exchanges in ONE round of grouped sends / receives (one launch latency instead of one per array): the entry
+// keys and ids to their owners plus the boundary keys and ids to everyone.  Per transfer and peer: element offsets and
+// counts on both sides.  Both ends post the transfers of a peer pair in the same order, which is how RCCL matches them.
+struct Xfer {
+    const void* send = nullptr;
+    void* recv = nullptr;
+    size_t elem = 0;
+    std::vector<uint64_t> s_off, s_cnt, r_off, r_cnt;  // [world]
+};
+Xfer xfer_alltoallv(int W, const void* send, const uint64_t* send_counts, const uint64_t* recv_counts, size_t elem, void* recv) {
+    Xfer x;
+    x.send = send; x.recv = recv; x.elem = elem;
+    x.s_off.assign(W, 0); x.s_cnt.assign(W, 0); x.r_off.assign(W, 0); x.r_cnt.assign(W, 0);
+    uint64_t so = 0, ro = 0;
+    for (int r = 0; r < W; ++r) {
+        x.s_off[r] = so; x.s_cnt[r] = send_counts[r]; so += send_counts[r];
+        x.r_off[r] = ro; x.r_cnt[r] = recv_counts[r]; ro += recv_counts[r];
+    }
+    return x;
+}
+Xfer xfer_allgatherv(int W, int rank, const void* send, const uint64_t* sizes, size_t elem, void* recv) {
+    Xfer x;
+    x.send = send; x.recv = recv; x.elem = elem;
+    x.s_off.assign(W, 0); x.s_cnt.assign(W, sizes[rank]); x.r_off.assign(W, 0); x.r_cnt.assign(W, 0);
+    uint64_t ro = 0;
+    for (int r = 0; r < W; ++r) { x.r_off[r] = ro; x.r_cnt[r] = sizes[r]; ro += sizes[r]; }
+    return x;
+}
+// max_msg_bytes: the largest single message of ANY rank in ANY of the transfers (every rank passes the same value)
+int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg_bytes) {
+    const RcclApi* a = rccl_api();
+    const int W = g->world;
+    const uint64_t rounds = std::max<uint64_t>(1, (max_msg_bytes + CHUNK_BYTES - 1) / CHUNK_BYTES);
+    // what stays on this rank is a device copy (about three times the rate of a send to oneself)
+    for (const Xfer& x : xs)
+        if (x.s_cnt[g->rank] && !self_through_rccl())
+            GHIP_TRY(g, hipMemcpyAsync((char*)x.recv + x.r_off[g->rank] * x.elem, (const char*)x.send + x.s_off[g->rank] * x.elem,
+                                       x.s_cnt[g->rank] * x.elem, hipMemcpyDeviceToDevice, g->stream));
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        RCCL_TRY(g, a->GroupStart());
+        for (int p = 0; p < W; ++p) {
+            if (p == g->rank && !self_through_rccl()) continue;
+            for (const Xfer& x : xs) {
+                const uint64_t ch = std::max<uint64_t>(1, CHUNK_BYTES / x.elem);
+                const uint64_t s0 = std::min(x.s_cnt[p], rd * ch), s1 = std::min(x.s_cnt[p], (rd + 1) * ch);
+                const uint64_t r0 = std::min(x.r_cnt[p], rd * ch), r1 = std::min(x.r_cnt[p], (rd + 1) * ch);
+                if (s1 > s0) RCCL_TRY(g, a->Send((const char*)x.send + (x.s_off[p] + s0) * x.elem, (s1 - s0) * x.elem, RCCL_INT8, p, g->comm, g->stream));
+                if (r1 > r0) RCCL_TRY(g, a->Recv((char*)x.recv + (x.r_off[p] + r0) * x.elem, (r1 - r0) * x.elem, RCCL_INT8, p, g->comm, g->stream));
+            }
         }
         RCCL_TRY(g, a->GroupEnd());
     }
@@ -527,26 +591,46 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     const uint32_t* d_ids = nullptr;
     L_TRY(s, s->local, bp_layer_partition_entries_packed_device(s->local, d_s, lut.data(), n_cells, (uint32_t)G, pack ? 1 : 0, counts.data(), &d_keys, &d_ids));
     lap(1);
-    std::vector<int64_t> cmine(G + 1), cm((size_t)(G + 1) * G);
-    for (int k = 0; k <= G; ++k) cmine[k] = (int64_t)counts[k];
-    G_TRY(s, grp_allgather_i64(g, rank, cmine.data(), (size_t)G + 1, cm.data()));   // cm[src][dst], cm[src][G] = coarse
+    // cm[src][dst] entries go from src to dst, cm[src][G] = src's boundary keys: every rank derives the whole matrix from
+    // the gathered histograms and the table (no second exchange of counts)
+    std::vector<uint64_t> cm((size_t)(G + 1) * G, 0);
+    for (int r = 0; r < G; ++r) {
+        for (size_t c = 0; c < n_cells; ++c) cm[(size_t)r * (G + 1) + lut[c]] += (uint64_t)all[(size_t)r * vlen + c];
+        cm[(size_t)r * (G + 1) + G] = (uint64_t)all[(size_t)r * vlen + n_cells];
+    }
+    for (int k = 0; k <= G; ++k)
+        if (cm[(size_t)rank * (G + 1) + k] != counts[k]) {
+            if (g->kind == GRP_LOCAL && G > 1) local_break(g);
+            return sfail(s, BP_ERR_COMM, "partition counts disagree with the cell histogram");
+        }
     std::vector<uint64_t> recv_counts(G), coarse_sizes(G), send_counts(G);
     uint64_t n_recv = 0, n_coarse = 0, n_fine = 0, max_msg = 0;
     for (int r = 0; r < G; ++r) {
-        recv_counts[r] = (uint64_t)cm[(size_t)r * (G + 1) + rank];
-        coarse_sizes[r] = (uint64_t)cm[(size_t)r * (G + 1) + G];
+        recv_counts[r] = cm[(size_t)r * (G + 1) + rank];
+        coarse_sizes[r] = cm[(size_t)r * (G + 1) + G];
         send_counts[r] = counts[r];
         n_recv += recv_counts[r]; n_coarse += coarse_sizes[r]; n_fine += counts[r];
-        for (int d = 0; d < G; ++d) max_msg = std::max(max_msg, (uint64_t)cm[(size_t)r * (G + 1) + d]);
+        for (int d = 0; d <= G; ++d) max_msg = std::max(max_msg, cm[(size_t)r * (G + 1) + d]);
     }
     uint64_t* sk = nullptr;
     uint32_t* si = nullptr;
     L_TRY(s, s->shard, bp_layer_begin_entries(s->shard, (size_t)(n_recv + n_coarse), &sk, &si));
-    G_TRY(s, grp_alltoallv(g, rank, d_keys, send_counts.data(), recv_counts.data(), sizeof(uint64_t), sk, max_msg, s->stream));
-    G_TRY(s, grp_alltoallv(g, rank, d_ids, send_counts.data(), recv_counts.data(), sizeof(uint32_t), si, max_msg, s->stream));
-    if (n_coarse) {
-        G_TRY(s, grp_allgatherv(g, rank, d_keys + n_fine, coarse_sizes.data(), sizeof(uint64_t), sk + n_recv, s->stream));
-        G_TRY(s, grp_allgatherv(g, rank, d_ids + n_fine, coarse_sizes.data(), sizeof(uint32_t), si + n_recv, s->stream));
+    if (g->kind == GRP_RCCL) {
+        std::vector<Xfer> xs;
+        xs.push_back(xfer_alltoallv(G, d_keys, send_counts.data(), recv_counts.data(), sizeof(uint64_t), sk));
+        xs.push_back(xfer_alltoallv(G, d_ids, send_counts.data(), recv_counts.data(), sizeof(uint32_t), si));
+        if (n_coarse) {
+            xs.push_back(xfer_allgatherv(G, rank, d_keys + n_fine, coarse_sizes.data(), sizeof(uint64_t), sk + n_recv));
+            xs.push_back(xfer_allgatherv(G, rank, d_ids + n_fine, coarse_sizes.data(), sizeof(uint32_t), si + n_recv));
+        }
+        G_TRY(s, grp_exchange_rccl(g, xs, max_msg * sizeof(uint64_t)));
+    } else {
+        G_TRY(s, grp_alltoallv(g, rank, d_keys, send_counts.data(), recv_counts.data(), sizeof(uint64_t), sk, max_msg, s->stream));
+        G_TRY(s, grp_alltoallv(g, rank, d_ids, send_counts.data(), recv_counts.data(), sizeof(uint32_t), si, max_msg, s->stream));
+        if (n_coarse) {
+            G_TRY(s, grp_allgatherv(g, rank, d_keys + n_fine, coarse_sizes.data(), sizeof(uint64_t), sk + n_recv, s->stream));
+            G_TRY(s, grp_allgatherv(g, rank, d_ids + n_fine, coarse_sizes.data(), sizeof(uint32_t), si + n_recv, s->stream));
+        }
     }
     lap(2);
     // facts of the union.  Chunks arrive in rank order and every rank's entries are in its own append order, so the order /

@@ -155,10 +155,16 @@ def test_c_sharded_local_pair_order_is_a_disjoint_cover(world, giants):
 
 
 @pytest.mark.gpu
-def test_c_sharded_single_rank_rccl_group():
-    """the RCCL transport (librccl bound with dlopen) with world = 1 -- all one GPU box can host; the collectives
-    (ncclAllGather, grouped ncclSend / ncclRecv to self) run for real"""
+@pytest.mark.parametrize("self_send", [True, False])
+def test_c_sharded_single_rank_rccl_group(self_send, monkeypatch):
+    """the RCCL transport (librccl bound with dlopen) with world = 1 -- all one GPU box can host.  self_send: the part of
+    every exchange that stays on the rank (here: everything) goes through grouped ncclSend / ncclRecv as a peer's would,
+    so the whole binding runs for real; otherwise it is the device copy the product path uses, next to ncclAllGather"""
     import oracle
+    if self_send:
+        monkeypatch.setenv("BP_SHARDED_SELF_SEND", "1")
+    else:
+        monkeypatch.delenv("BP_SHARDED_SELF_SEND", raising=False)
     uid = sharded.Group.unique_id()
     assert len(uid) == 128
     g = sharded.Group.rccl(0, 1, uid, 0)
