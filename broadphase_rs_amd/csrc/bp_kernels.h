@@ -34,7 +34,11 @@ struct DevScalars {
     unsigned int id_max;           // largest id handed to the last extend (valid or not)
     unsigned int id_min;           // smallest id handed to the last extend
     unsigned int big_count;        // expanding scan: slices on the long-range work list
+    unsigned int grp_max;          // grouped finishes: the largest group ...
+    unsigned int grp_over;         // ... and the records in groups above the finish kernel's capacity (group_stats_words)
 };
+// the two words a bounds kernel reduces the group sizes into (zero after a reset of the scalars): [0] = grp_max, [1] = grp_over
+inline unsigned int* group_stats_words(DevScalars* d_sc) { return &d_sc->grp_max; }
 enum : unsigned {
     EXT_IDS_DECREASE = 1u,   // some id is smaller than its predecessor in append order
     EXT_IDS_REPEAT = 2u,     // some id is <= its predecessor (ids not provably distinct)
@@ -126,12 +130,15 @@ size_t radix_workspace_bytes(size_t n, int n_passes);
 // the result (0 or 1).  vals0 == nullptr: keys only.
 // box_in / box_out (optional, key+u32-payload sorts only): per-record byte packed into the payload's
 // bits 27..31 by the first pass and unpacked by the last one into box_out (may alias box_in).
+// epoch_io (optional): the caller's launch counter for THIS workspace -- the passes tag their look-back status words with
+// it instead of zero-filling the workspace (the caller zero-fills once, when the workspace is allocated, and starts the
+// counter at 0).  sc_init (optional): *sc is set to this by the sort's first kernel (saves the caller's own reset).
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
                       const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
-                      int ready_copies = 1, int unstable_first = 0);
+                      int ready_copies = 1, int unstable_first = 0, uint32_t* epoch_io = nullptr, const DevScalars* sc_init = nullptr);
 // unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
 // result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
 // varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.

@@ -335,7 +335,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
 // decoupled look-back status words (fused encode below, radix one-sweep further down)
 constexpr u64 ST_FLAG_AGG = 1ull << 62;   // tile-local digit count published
 constexpr u64 ST_FLAG_PRE = 2ull << 62;   // inclusive prefix over tiles 0..t published
-constexpr u64 ST_VALUE = (1ull << 62) - 1ull;
+constexpr u64 ST_VALUE = (1ull << 32) - 1ull;                 // counts / prefixes (inputs are shorter than 2^32 records)
+constexpr u32 ST_EPOCH_MASK = (1u << 30) - 1u;                 // launch tag, bits 32..61
+constexpr u64 ST_TAG_BITS = (u64)ST_EPOCH_MASK << 32;
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
 constexpr u32 HOLE_BLOCK = SX_BLOCK;  // records per block of a block-structured input (expanding scan output)
 
@@ -538,6 +540,35 @@ __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __res
     bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
 }
 
+// The front end of a sort in one launch (blockIdx.x = pass): digit counts (summed over the producer's copies, or already
+// in `hist`), their exclusive prefix = the bins' bases, the pass's tile ticket back to zero and -- optionally -- the
+// scalars the sort's kernels report into reset to `sc_init`.
+__global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
+                                                                u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
+                                                                DevScalars sc_init, int set_sc) {
+    __shared__ u64 s_wave[RS_BINS / 64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const size_t k = (size_t)blockIdx.x * RS_BINS + threadIdx.x;
+    u64 v;
+    if (copies) {
+        v = 0;
+        for (int c = 0; c < n_copies; ++c) v += copies[(size_t)c * (SX_HIST_MAX * 256) + k];
+        hist[k] = v;
+    } else {
+        v = hist[k];
+    }
+    const u64 incl = wave_incl_scan_u64(v);
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    u64 base = 0;
+    for (int q = 0; q < w; ++q) base += s_wave[q];
+    bin_base[k] = base + incl - v;
+    if (threadIdx.x == 0) {
+        counters[blockIdx.x] = 0;
+        if (set_sc && blockIdx.x == 0) *sc = sc_init;
+    }
+}
+
 // digit functors: what a one-sweep pass buckets by
 struct ShiftDigit {  // LSD radix digit
     int shift;
@@ -587,7 +618,10 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
                                                                     u64* status, u32* tile_counter, DevScalars* sc,
                                                                     const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out,
-                                                                    const u32* __restrict__ blockfill, size_t n_out) {
+                                                                    const u32* __restrict__ blockfill, size_t n_out, u32 epoch) {
+    // epoch: tag of this launch's status words (bits 32..61; counts and prefixes are < 2^32).  A word with another tag is
+    // a leftover of an earlier launch on the same workspace and reads as "nothing published": no zero-fill between launches
+    const u64 st_tag = (u64)(epoch & ST_EPOCH_MASK) << 32;
     constexpr int RS_THREADS = THREADS, RS_ITEMS = ITEMS, RS_TILE = THREADS * ITEMS, RS_WAVES = THREADS / 64;
     static_assert(THREADS >= RS_BINS && RS_WAVES * RS_BINS * 8 <= RS_TILE * (int)sizeof(K), "tile geometry");
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
@@ -689,7 +723,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     if (tid < RS_BINS) {
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) total += s_cnt[ww][tid];
-        if (tile != 0) st_store(my_status, ST_FLAG_AGG | (u64)total);
+        if (tile != 0) st_store(my_status, ST_FLAG_AGG | st_tag | (u64)total);
     }
     u32 tile_total;
     const u32 tile_off = block_excl_scan_u32<RS_THREADS>(total, s_ws, tile_total);
@@ -720,7 +754,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     if (tid < RS_BINS) {
         u64 excl = 0;
         if (tile == 0) {
-            st_store(my_status, ST_FLAG_PRE | (u64)total);
+            st_store(my_status, ST_FLAG_PRE | st_tag | (u64)total);
         } else {
             // LB_BATCH independent status loads per step (one fabric round trip per step instead of
             // per predecessor).  Tile 0 always holds a prefix, so the walk ends there at the latest.
@@ -742,7 +776,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
 #pragma unroll
                 for (int k = 0; k < LB_BATCH; ++k) {
                     if (!done && consumed == (size_t)k) {
-                        const u64 f = sv[k] >> 62;
+                        const u64 f = (sv[k] & ST_TAG_BITS) == st_tag ? sv[k] >> 62 : 0ull;
                         if (f == 2) { excl += sv[k] & ST_VALUE; done = true; }
                         else if (f == 1) { excl += sv[k] & ST_VALUE; consumed = (size_t)k + 1; }
                     }
@@ -758,7 +792,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
                     }
                 }
             }
-            st_store(my_status, ST_FLAG_PRE | (excl + (u64)total));
+            st_store(my_status, ST_FLAG_PRE | st_tag | (excl + (u64)total));
         }
         s_glob[tid] = bin_base[tid] + excl - (u64)tile_off;
     }
@@ -2049,28 +2083,46 @@ constexpr int TGRP_THREADS = TGRP_THREADS_MACRO, TGRP_CAP = TGRP_CAP_MACRO, TGRP
 constexpr int TGRP_BIN_BITS = TGRP_THREADS >= 256 ? 8 : (TGRP_THREADS == 128 ? 7 : 6), TGRP_BINS = 1 << TGRP_BIN_BITS;
 static_assert(TGRP_THREADS >= TGRP_BINS && TGRP_CAP % TGRP_THREADS == 0, "tree group geometry");
 constexpr u32 TGRP_SLOW_MAX = 32768;  // input positions travel as u16 + rounds stay few; longer groups: classic sort
-__global__ __launch_bounds__(256) void tgroup_bounds_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
-                                                            u32* __restrict__ bounds) {
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t > n_groups) return;
-    const u64 key = g0 + (u64)t;
-    u32 a = 0, b = n;
-    while (a < b) {
-        const u32 mid = a + ((b - a) >> 1);
-        if ((keys[mid] >> gshift) < key) a = mid + 1; else b = mid;
+// bounds[t] = first index whose (key >> gshift) is >= g0 + t, for t = 0 .. n_groups; and, in the same launch, the
+// statistics of the group sizes bounds[t + 1] - bounds[t]: stats[0] = largest group, stats[1] = records in groups above
+// `cap` (both zero beforehand: they live in the scalars the caller has just reset).  A workgroup covers 255 groups: its
+// 256 threads find 256 consecutive bounds, the last one again by the next workgroup.
+__global__ __launch_bounds__(256) void group_bounds_stats_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
+                                                                 u32* __restrict__ bounds, u32 cap, u32* __restrict__ stats) {
+    __shared__ u32 s_b[256];
+    __shared__ u32 s_mx[4], s_ov[4];
+    const u32 t = blockIdx.x * 255u + threadIdx.x;
+    u32 a = n;
+    if (t <= n_groups) {
+        const u64 key = g0 + (u64)t;
+        u32 b = n;
+        a = 0;
+        while (a < b) {
+            const u32 mid = a + ((b - a) >> 1);
+            if ((keys[mid] >> gshift) < key) a = mid + 1; else b = mid;
+        }
+        bounds[t] = a;
     }
-    bounds[t] = a;
-}
-// stats[0] = largest group, stats[1] = entries in groups larger than cap (zeroed by the caller)
-__global__ __launch_bounds__(256) void tgroup_stats_kernel(const u32* __restrict__ bounds, u32 n_groups, u32 cap, u32* __restrict__ stats) {
-    u32 mx = 0, over = 0;
-    for (u32 g = blockIdx.x * 256 + threadIdx.x; g < n_groups; g += gridDim.x * 256) {
-        const u32 c = bounds[g + 1] - bounds[g];
-        mx = max(mx, c);
-        over += c > cap ? c : 0u;
-    }
+    if (!stats) return;
+    s_b[threadIdx.x] = a;
+    __syncthreads();
+    u32 c = 0;
+    if (threadIdx.x < 255u && t < n_groups) c = s_b[threadIdx.x + 1u] - a;
+    u32 mx = c, over = c > cap ? c : 0u;
     for (int o = 32; o; o >>= 1) { mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); }
-    if (lane_id() == 0) { atomicMax(&stats[0], mx); if (over) atomicAdd(&stats[1], over); }
+    if (lane_id() == 0) { s_mx[threadIdx.x >> 6] = mx; s_ov[threadIdx.x >> 6] = over; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        over = s_ov[0] + s_ov[1] + s_ov[2] + s_ov[3];
+        if (mx) atomicMax(&stats[0], mx);
+        if (over) atomicAdd(&stats[1], over);
+    }
+}
+static hipError_t launch_group_bounds_stats(const u64* keys, u32 n, u32 n_groups, u64 g0, int gshift, u32* bounds, u32 cap, u32* stats,
+                                            hipStream_t stream) {
+    group_bounds_stats_kernel<<<(n_groups + 1 + 254) / 255, 256, 0, stream>>>(keys, n, n_groups, g0, gshift, bounds, cap, stats);
+    return hipGetLastError();
 }
 // CTX_KIND >= 0 (with PACKED): also write the scan's per-entry {id, suppression context} word (entry_ctx_kernel's output
 // for inactive_below = 0) while key and box code are at hand -- the separate streaming kernel is then not needed
@@ -2518,16 +2570,16 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr,
-                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true) {
+                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true, u32 epoch = 0) {
     // n: extent of the input (tiles are cut from it); n_out: records that exist (== n without holes)
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     if (!blockfill) n_out = n;
     if (stable)
         radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
     else
         radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, false><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out);
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
     return hipGetLastError();
 }
 
@@ -2536,7 +2588,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
                       const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies,
-                      int unstable_first) {
+                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init) {
     static const bool no_unstable = getenv("BP_NO_UNSTABLE_PASS") != nullptr;  // A/B switch
     if (no_unstable) unstable_first = 0;
     *result_buf = 0;
@@ -2555,16 +2607,35 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     hipError_t e;
 
     if (mark) mark(mark_ctx, class_hist);
-    e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(extent, np), stream);
-    if (e != hipSuccess) return e;
-    if (ready_hist) {  // the producer of the records already counted the digits of this plan
-        hist_reduce_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist);
+    // status words: tagged per launch when the caller keeps an epoch counter for this workspace (epoch_io; the words of
+    // earlier launches then need no zero-fill), zero-filled otherwise
+    u32 epoch0 = 0;
+    if (epoch_io) {
+        if (*epoch_io + (u32)np >= ST_EPOCH_MASK) {  // tags wrap: start over on a clean workspace
+            e = hipMemsetAsync(workspace, 0, workspace_bytes, stream);
+            if (e != hipSuccess) return e;
+            *epoch_io = 0;
+        }
+        epoch0 = *epoch_io + 1u;
+        *epoch_io += (u32)np;
     } else {
+        e = hipMemsetAsync(workspace, 0, radix_workspace_bytes(extent, np), stream);
+        if (e != hipSuccess) return e;
+    }
+    DevScalars init = {};
+    if (sc_init) init = *sc_init;
+    if (ready_hist) {  // the producer of the records already counted the digits of this plan
+        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0);
+    } else {
+        if (epoch_io) {  // the counting kernel adds into the histogram
+            e = hipMemsetAsync(hist, 0, (size_t)np * RS_BINS * sizeof(u64), stream);
+            if (e != hipSuccess) return e;
+        }
         radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
             (const u64*)keys0, vals0, extent, plan, hist, blockfill);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>(nullptr, 0, hist, bin_base, counters, sc, init, sc_init ? 1 : 0);
     }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    radix_binbase_kernel<<<np, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (mark) mark(mark_ctx, -1);
 
@@ -2585,15 +2656,16 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
             const bool holes = blockfill && p == 0;  // only the first pass sees the block-structured input
             e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, holes ? extent : n,
                                             ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream, nullptr, nullptr,
-                                            holes ? blockfill : nullptr, n, !(unstable_first && p == 0));
+                                            holes ? blockfill : nullptr, n, !(unstable_first && p == 0), epoch0 ? epoch0 + (u32)p : 0u);
         } else if (plan.from_val[p]) {
-            e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream);
+            e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
+                                          nullptr, nullptr, nullptr, 0, true, epoch0 ? epoch0 + (u32)p : 0u);
         } else {
             // box_in (bytes in the records' CURRENT order) can only be gathered by the very first pass; the codes are
             // split off again by the last pass, which must be a key pass
             e = launch_onesweep<u64, u32>(kb[cur], kb[cur ^ 1], vb[cur], vb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
                                           p == 0 ? box_in : nullptr, p == np - 1 ? box_out : nullptr, nullptr, 0,
-                                          !(unstable_first && p == 0));
+                                          !(unstable_first && p == 0), epoch0 ? epoch0 + (u32)p : 0u);
         }
         if (e != hipSuccess) return e;
         if (mark) mark(mark_ctx, -1);
@@ -3325,19 +3397,6 @@ constexpr int GRP_THREADS = GRP_THREADS_MACRO, GRP_CAP = 4096, GRP_ITEMS = GRP_C
 constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
 constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;
 constexpr u32 GRP_SUB = 4;  // sub-bins per id by the top bits of the second id (fast path)  // larger groups than this are not attempted
-// bounds[t] = first index whose (pair >> gshift) is >= g0 + t, for t = 0 .. n_groups
-__global__ __launch_bounds__(256) void group_bounds_kernel(const u64* __restrict__ in, u32 n, u32 n_groups, u32 g0, int gshift,
-                                                           u32* __restrict__ bounds) {
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t > n_groups) return;
-    const u64 key = (u64)g0 + (u64)t;
-    u32 a = 0, b = n;
-    while (a < b) {
-        const u32 mid = a + ((b - a) >> 1);
-        if ((in[mid] >> gshift) < key) a = mid + 1; else b = mid;
-    }
-    bounds[t] = a;
-}
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
                                                                    int gbits, int sshift, uint2* __restrict__ out, DevScalars* sc,
                                                                    const u32* __restrict__ stats, u32 abort_over) {
@@ -3487,12 +3546,10 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
                                uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max) {
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
-    group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
-    if (stats) {  // stats[0] = largest group, stats[1] = pairs in groups above the capacity; a quarter of all pairs there: bail out
-        hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRP_CAP, stats);
-    }
+    // stats (two words of the freshly reset scalars): [0] = largest group, [1] = pairs in groups above the capacity; a
+    // quarter of all pairs there: the finish bails out
+    hipError_t e = launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream);
+    if (e != hipSuccess) return e;
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
     int bits = 0;
     while (bits < 32 && (second_max >> bits) != 0) ++bits;
@@ -3672,10 +3729,8 @@ hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_gro
     // counts: n_groups + 1 words; counts[n_groups] = 0 so that the exclusive scan leaves the total there
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 4 || gbits > GRD_MAX_BITS) return hipErrorInvalidValue;
-    group_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)in, (u32)n, n_groups, g0, 32 + gbits, bounds);
-    hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
+    hipError_t e = launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRD_CAP, stats, stream);
     if (e != hipSuccess) return e;
-    tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)GRD_CAP, stats);
     e = hipMemsetAsync(counts + n_groups, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     int bits = 0;  // second ids lie in [second_lo, second_hi]
@@ -3718,13 +3773,7 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
                                 uint32_t* stats, hipStream_t stream) {
     if (m == 0 || n_groups == 0) return hipSuccess;
     if (m >= 0xFFFFFFFFull) return hipErrorInvalidValue;
-    tgroup_bounds_kernel<<<(n_groups + 1 + 255) / 256, 256, 0, stream>>>((const u64*)keys, (u32)m, n_groups, (u64)g0, gshift, bounds);
-    if (stats) {
-        hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        tgroup_stats_kernel<<<std::min<unsigned>(256u, (n_groups + 255) / 256), 256, 0, stream>>>(bounds, n_groups, (u32)TGRP_CAP, stats);
-    }
-    return hipGetLastError();
+    return launch_group_bounds_stats((const u64*)keys, (u32)m, n_groups, (u64)g0, gshift, bounds, (u32)TGRP_CAP, stats, stream);
 }
 bool tgroup_composite_fits(int gshift, int id_bits) {
     static const bool disabled = getenv("BP_NO_TGROUP_COMPOSITE") != nullptr;  // A/B switch

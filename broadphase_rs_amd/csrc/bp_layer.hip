@@ -109,11 +109,13 @@ struct bp_layer {
     uint32_t grp_off_dups = 0;          // the same for the grouped finish of pairs that may repeat
     int grp_next_dups = 0;              // that finish ran last frame on groups of 2^this ids: the scan counts the digits of its plan
     bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
-    // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (tgrp_stats) allow it
+    // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (grp_max of the scalars) allow it
     bool tgrp_ok = false, tgrp_known = false;
     uint32_t tgrp_probe = 0;
-    DevBuf tgrp_bounds, tgrp_stats;
-    HostBuf h_tstats;
+    DevBuf tgrp_bounds;
+    void* radix_ws_seen = nullptr;      // the radix workspace allocation whose status words carry launch tags (radix_ws_tagged)
+    size_t radix_ws_seen_cap = 0;
+    uint32_t radix_epoch = 0;
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
     // extend without a host round trip between its kernels: what the previous extend into the empty layer produced
     // predicts what the next one needs
@@ -298,6 +300,19 @@ int sc_fetch(bp_layer* L, DevScalars* out) {  // D2H + sync
     if (out->err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     if (out->err & KERR_COUNT_OVERFLOW)
         return fail(L, BP_ERR_TOO_LARGE, "an object expands to more than 2^20 cells (min_depth too high for its size)");
+    return BP_OK;
+}
+
+// the radix workspace with launch-tagged status words (radix_sort's epoch_io): zero-filled once per allocation
+int radix_ws_tagged(bp_layer* L, size_t bytes, uint32_t** epoch) {
+    BP_TRY(ensure_dev(L, L->radix_ws, bytes));
+    if (L->radix_ws.p != L->radix_ws_seen || L->radix_ws.cap != L->radix_ws_seen_cap) {
+        HIP_TRY(L, hipMemsetAsync(L->radix_ws.p, 0, L->radix_ws.cap, L->stream));
+        L->radix_ws_seen = L->radix_ws.p;
+        L->radix_ws_seen_cap = L->radix_ws.cap;
+        L->radix_epoch = 0;
+    }
+    *epoch = &L->radix_epoch;
     return BP_OK;
 }
 
@@ -739,7 +754,7 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     if (!already_synced) BP_TRY(sync_stream(L));
     const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
-    L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
+    L->tgrp_ok = sc.grp_max <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
     if (sc.err & KERR_SEGMENT_TOO_LONG) {
         L->tgrp_ok = false;
         L->cur = L->sort_pend.src;
@@ -784,17 +799,13 @@ int sort_tree(bp_layer* L, bool defer_check) {
             BP_TRY(ensure_dev(L, L->ids[other], L->m * sizeof(uint32_t)));
             const bool packed_in = L->ids_packed;
             const bool ride = packed_in || (L->box_valid && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0);
-            BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, gp.plan.n_passes)));
+            uint32_t* ws_epoch = nullptr;
+            BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(L->m, gp.plan.n_passes), &ws_epoch));
             BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
-            BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
-            BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->d_sort_sc, sizeof(DevScalars)));
-            BP_TRY(ensure_host(L, L->h_sort_sc, 2 * sizeof(DevScalars)));
-            {   // the sort's own scalars (slot 1 of the host buffer is the upload source, slot 0 receives the result)
-                DevScalars* up = (DevScalars*)L->h_sort_sc.p + 1;
-                *up = neutral_scalars();
-                HIP_TRY(L, hipMemcpyAsync(L->d_sort_sc.p, up, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
-            }
+            BP_TRY(ensure_host(L, L->h_sort_sc, sizeof(DevScalars)));
+            // the sort's own scalars, reset by the sort's first kernel
+            const DevScalars ssc_init = neutral_scalars();
             DevScalars* const d_ssc = (DevScalars*)L->d_sort_sc.p;
             int res = 0;
             uint64_t* kb[2] = {(uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p};
@@ -805,7 +816,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
                                   hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES,
-                                  /*unstable_first=*/1));  // the finish kernel orders every group by (key, id, position)
+                                  /*unstable_first=*/1, ws_epoch, &ssc_init));  // the finish kernel orders every group by (key, id, position)
             const int src = res ? other : L->cur, dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             // the finish has key and box code at hand: it also writes the scan's per-entry context words
@@ -815,17 +826,16 @@ int sort_tree(bp_layer* L, bool defer_check) {
             {
                 ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
-                                                (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
+                                                (uint32_t*)L->tgrp_bounds.p, group_stats_words(d_ssc), L->stream));
                 HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
                                                 (const uint32_t*)L->tgrp_bounds.p, gp.gshift, ride ? 1 : 0, (uint64_t*)L->keys[dst].p,
                                                 (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
                                                 d_ssc, L->stream, with_ctx ? L->kind : -1,
-                                                with_ctx ? (uint64_t*)L->idctx.p : nullptr, (const uint32_t*)L->tgrp_stats.p,
+                                                with_ctx ? (uint64_t*)L->idctx.p : nullptr, group_stats_words(d_ssc),
                                                 (uint32_t)(L->m / 4),
                                                 // ids distinct (the codes ride in them): the composite-key kernel may run
                                                 (ride && L->ids_distinct) ? std::max(1, 32 - __builtin_clz(L->id_or | 1u)) : 0));
             }
-            HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
             HIP_TRY(L, hipMemcpyAsync(L->h_sort_sc.p, L->d_sort_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
             L->cur = dst;
@@ -878,12 +888,9 @@ int sort_tree(bp_layer* L, bool defer_check) {
             const bool probe = group_able && (!L->tgrp_known || (++L->tgrp_probe & 15u) == 0);
             if (probe) {
                 BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
-                BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
-                BP_TRY(ensure_host(L, L->h_tstats, 2 * sizeof(uint32_t)));
                 ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[dst].p, L->m, gp.n_groups, gp.g0, gp.gshift,
-                                                (uint32_t*)L->tgrp_bounds.p, (uint32_t*)L->tgrp_stats.p, L->stream));
-                HIP_TRY(L, hipMemcpyAsync(L->h_tstats.p, L->tgrp_stats.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+                                                (uint32_t*)L->tgrp_bounds.p, group_stats_words((DevScalars*)L->d_sc.p), L->stream));
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             BP_TRY(sync_stream(L));
@@ -893,7 +900,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 L->tgrp_known = true;
                 // switched on only with a margin (80 % of the capacity): a scene hovering at the limit must not flip the
                 // plan every frame -- each flip costs the digit counts encode_emit made for the other plan
-                L->tgrp_ok = ((const uint32_t*)L->h_tstats.p)[0] <= (uint32_t)(tgroup_capacity() * 4 / 5);
+                L->tgrp_ok = sc.grp_max <= (uint32_t)(tgroup_capacity() * 4 / 5);
             }
             if (sc.err & KERR_SEGMENT_TOO_LONG) {
                 // a group of equal key prefix is longer than the LDS window (heavily clustered input):
@@ -1041,22 +1048,23 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     uint64_t* bufs[2] = {buf0, nullptr};
     BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
     bufs[1] = (uint64_t*)L->pairs[1].p;
-    BP_TRY(sc_reset(L));
     {
         const size_t extent = holes ? L->raw_extent : n;
-        BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
+        uint32_t* ws_epoch = nullptr;
+        BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(extent, plan.n_passes), &ws_epoch));
+        const DevScalars sc_init = neutral_scalars();  // the scalars are reset by the sort's first kernel
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
                               holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), 1,
-                              /*unstable_first=*/1));  // distinct pairs, finished by (first id, second id) in LDS
+                              /*unstable_first=*/1, ws_epoch, &sc_init));  // distinct pairs, finished by (first id, second id) in LDS
     }
     BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
     if (n_groups) {
         BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
         ProfScope ps(L, BP_K_DEDUP);
-        BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
         HIP_TRY(L, launch_group_finish(bufs[res], n, n_groups, first_range[0] >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
-                                       (DevScalars*)L->d_sc.p, L->stream, (uint32_t*)L->tgrp_stats.p, (uint32_t)(varying & 0xFFFFFFFFull)));
+                                       (DevScalars*)L->d_sc.p, L->stream, group_stats_words((DevScalars*)L->d_sc.p),
+                                       (uint32_t)(varying & 0xFFFFFFFFull)));
     } else {
         ProfScope ps(L, BP_K_DEDUP);
         HIP_TRY(L, launch_segment_finish(bufs[res], n, (uint32_t*)L->out_pairs.p, (DevScalars*)L->d_sc.p, L->stream));
@@ -1102,21 +1110,21 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
             BP_TRY(ensure_dev(L, partner, n * sizeof(uint64_t)));
             uint64_t* bufs[2] = {buf0, (uint64_t*)partner.p};
             int res = 0;
-            BP_TRY(sc_reset(L));
             const size_t extent = holes ? L->raw_extent : n;
-            BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, gplan.n_passes)));
+            uint32_t* ws_epoch = nullptr;
+            BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(extent, gplan.n_passes), &ws_epoch));
+            const DevScalars sc_init = neutral_scalars();  // the scalars are reset by the sort's first kernel
             HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, gplan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
                                   holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, gplan, holes), 1,
-                                  /*unstable_first=*/1));  // equal pairs are interchangeable; the finish orders by (first, second)
+                                  /*unstable_first=*/1, ws_epoch, &sc_init));  // equal pairs are interchangeable; the finish orders by (first, second)
             BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
-            BP_TRY(ensure_dev(L, L->tgrp_stats, 2 * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->block_sums, ((size_t)n_groups + 1) * sizeof(unsigned long long)));
             {
                 ProfScope ps(L, BP_K_DEDUP);
                 HIP_TRY(L, launch_group_finish_dups(bufs[res], n, n_groups, first_range[0] >> gb, gb, (uint32_t*)L->grp_bounds.p, bufs[res ^ 1],
                                                     (unsigned long long*)L->block_sums.p, (DevScalars*)L->d_sc.p, L->stream,
-                                                    (uint32_t*)L->tgrp_stats.p, first_range[0], first_range[1]));
+                                                    group_stats_words((DevScalars*)L->d_sc.p), first_range[0], first_range[1]));
             }
             {
                 ProfScope ps(L, BP_K_MISC);
@@ -1650,9 +1658,9 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->tgrp_stats);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
-    free_host(L->h_shards); free_host(L->h_tstats); free_host(L->h_sort_sc);
+    free_host(L->h_shards); free_host(L->h_sort_sc);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
