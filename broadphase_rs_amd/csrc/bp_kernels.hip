@@ -552,7 +552,8 @@ __global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __res
     u64 v;
     if (copies) {
         v = 0;
-        for (int c = 0; c < n_copies; ++c) v += copies[(size_t)c * (SX_HIST_MAX * 256) + k];
+#pragma unroll 8
+        for (int c = 0; c < n_copies; ++c) v += copies[(size_t)c * (SX_HIST_MAX * 256) + k];  // independent loads in flight
         hist[k] = v;
     } else {
         v = hist[k];

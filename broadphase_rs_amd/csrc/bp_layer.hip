@@ -293,8 +293,13 @@ int sc_reset(bp_layer* L) {
     HIP_TRY(L, hipMemcpyAsync(L->d_sc.p, h, sizeof(DevScalars), hipMemcpyHostToDevice, L->stream));
     return BP_OK;
 }
-int sc_fetch(bp_layer* L, DevScalars* out) {  // D2H + sync
-    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+// the scalars' device / host buffers carry the expanding scan's shard cursors behind them, so that ONE copy brings both back
+constexpr size_t SC_SHARDS_OFF = 256, SC_BLOCK_BYTES = SC_SHARDS_OFF + 3 * SX_SHARDS * sizeof(uint64_t);
+static_assert(sizeof(DevScalars) <= SC_SHARDS_OFF, "scalars block layout");
+uint64_t* sc_shards_dev(bp_layer* L) { return (uint64_t*)((char*)L->d_sc.p + SC_SHARDS_OFF); }
+const uint64_t* sc_shards_host(bp_layer* L) { return (const uint64_t*)((const char*)L->h_sc.p + SC_SHARDS_OFF); }
+int sc_fetch(bp_layer* L, DevScalars* out, bool with_shards = false) {  // D2H + sync
+    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, with_shards ? SC_BLOCK_BYTES : sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
     BP_TRY(sync_stream(L));
     *out = *(DevScalars*)L->h_sc.p;
     if (out->err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
@@ -1347,8 +1352,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             const size_t out_blocks = cap / SX_BLOCK;
             const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
             BP_TRY(ensure_dev(L, L->blockfill, out_blocks * sizeof(uint32_t)));
-            BP_TRY(ensure_dev(L, L->shards, shard_bytes));
-            BP_TRY(ensure_host(L, L->h_shards, shard_bytes));
+            uint64_t* const d_shards = sc_shards_dev(L);  // behind the scalars: one copy fetches both
             const bool count_digits = allow_holes && hist_plan && scan_can_count(*hist_plan);
             const bool count_owners = allow_holes && !count_digits && owner_n >= 0 && owner_n <= 15;
             L->owner_hist_valid = false;
@@ -1358,27 +1362,26 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             if (no_prepare) {
                 BP_TRY(sc_reset(L));
                 HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
-                HIP_TRY(L, hipMemsetAsync(L->shards.p, 0, shard_bytes, L->stream));
+                HIP_TRY(L, hipMemsetAsync(d_shards, 0, shard_bytes, L->stream));
                 if (count_digits || count_owners)
                     HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
             } else
             HIP_TRY(L, launch_scan_prepare((DevScalars*)L->d_sc.p, neutral_scalars(), (uint32_t*)L->blockfill.p, out_blocks,
-                                           (uint64_t*)L->shards.p, 3 * SX_SHARDS,
+                                           d_shards, 3 * SX_SHARDS,
                                            (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
                                            SX_HIST_MAX * RS_BINS, L->stream));
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds, L->filt_shape,
-                                              (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, (uint64_t*)L->shards.p,
+                                              (uint64_t*)L->pairs[0].p, out_blocks, (uint32_t*)L->blockfill.p, d_shards,
                                               (uint64_t*)L->big_list.p,
                                               (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
                                               (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
                                               (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
                                               count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1));
             }
-            HIP_TRY(L, hipMemcpyAsync(L->h_shards.p, L->shards.p, shard_bytes, hipMemcpyDeviceToHost, L->stream));
             DevScalars sc;
-            BP_TRY(sc_fetch(L, &sc));
+            BP_TRY(sc_fetch(L, &sc, /*with_shards=*/true));
             {
                 bool redone = false;
                 BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));
@@ -1388,7 +1391,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 expand = false;
                 continue;
             }
-            const uint64_t* sh = (const uint64_t*)L->h_shards.p;
+            const uint64_t* sh = sc_shards_host(L);
             uint64_t kmax = 0, total = 0, examined = 0;
             for (int i = 0; i < SX_SHARDS; ++i) {
                 kmax = std::max<uint64_t>(kmax, sh[i]);
@@ -1632,8 +1635,8 @@ int bp_layer_create(bp_layer_t** out, int index_kind, uint32_t min_depth, size_t
     if (!g.ok) { delete L; return fail(nullptr, BP_ERR_NO_DEVICE, "hipSetDevice failed"); }
     e = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete L; return fail(nullptr, BP_ERR_HIP, "hipStreamCreateWithFlags", e); }
-    int rc = ensure_dev(L, L->d_sc, sizeof(DevScalars));
-    if (rc == BP_OK) rc = ensure_host(L, L->h_sc, sizeof(DevScalars));
+    int rc = ensure_dev(L, L->d_sc, SC_BLOCK_BYTES);
+    if (rc == BP_OK) rc = ensure_host(L, L->h_sc, SC_BLOCK_BYTES);
     if (rc == BP_OK && index_capacity) {
         rc = ensure_dev(L, L->keys[0], index_capacity * sizeof(uint64_t));
         if (rc == BP_OK) rc = ensure_dev(L, L->ids[0], index_capacity * sizeof(uint32_t));
