@@ -315,7 +315,9 @@ int radix_ws_tagged(bp_layer* L, size_t bytes, uint32_t** epoch) {
         HIP_TRY(L, hipMemsetAsync(L->radix_ws.p, 0, L->radix_ws.cap, L->stream));
         L->radix_ws_seen = L->radix_ws.p;
         L->radix_ws_seen_cap = L->radix_ws.cap;
-        L->radix_epoch = 0;
+        // test switch: start the launch counter just below the point where the 30-bit tags wrap (tests/test_gpu_parity.py)
+        static const char* start = getenv("BP_RADIX_EPOCH_START");
+        L->radix_epoch = start ? (uint32_t)strtoul(start, nullptr, 0) : 0u;
     }
     *epoch = &L->radix_epoch;
     return BP_OK;

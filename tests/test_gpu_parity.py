@@ -542,6 +542,41 @@ def test_grouped_finish_of_pairs_that_repeat(density, cluster):
         gpu.clear(); gpu.extend(sysb, bounds, ids)
 
 
+def test_frames_of_changing_size_share_one_radix_workspace():
+    """the sorts tag their look-back status words with a per-layer launch counter instead of zero-filling the workspace:
+    frames of very different sizes on ONE layer (tile counts change, the status arrays of different passes overlap
+    the leftovers of earlier launches, the workspace is reallocated when it grows) must all match the oracle"""
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    for frame, n in enumerate([60000, 3000, 250000, 60000, 900, 250000, 20000, 20000]):
+        sysb, bounds, ids = scenes.gen_boxes(n, seed=100 + frame)
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+        gpu.par_sort(); ref.sort()
+        assert_tree_equal(gpu, ref, "frame %d (%d objects)" % (frame, n))
+        assert_pairs_equal(gpu.par_scan(), ref.scan(), "frame %d (%d objects)" % (frame, n))
+
+
+def test_status_word_tags_wrap_around():
+    """a fresh process whose launch counter starts 20 launches below the 30-bit wrap: the sorts of the next frames cross
+    it (the workspace is zero-filled once at the wrap) and still match the oracle"""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, oracle, broadphase_rs_amd as bp\n"
+        "from broadphase_rs_amd import scenes\n"
+        "gpu = bp.Layer(bp.Index64_3D, 0)\n"
+        "for f in range(12):\n"
+        "    sysb, b, ids = scenes.gen_boxes(40000 + 9000 * (f % 3), seed=f)\n"
+        "    ref = oracle.OracleLayer(2, 0); gpu.clear(); gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)\n"
+        "    got = np.array(gpu.par_scan()); exp = ref.scan()\n"
+        "    assert got.shape == exp.shape and np.array_equal(got, exp), f\n"
+        "print('ok')\n")
+    env = dict(os.environ, BP_RADIX_EPOCH_START=str((1 << 30) - 1 - 20))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def _clustered_scene(n, n_cluster, seed, frac):
     """uniform scene whose first n_cluster objects are squeezed into a cube of `frac` of the system side"""
     sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
