@@ -1487,6 +1487,10 @@ struct WaveStage {
     u32 k_left;
     u32* hist;     // LDS, workgroup-wide: SX_HIST_MAX x 256 digit counters
     u64 examined;  // candidates this wave tested (wave-uniform)
+    // OWNER (multi-GPU): the pairs per owner of the first id are counted here, once per block -- a ballot per owner and
+    // quarter block, one LDS add per owner (an LDS atomic per pushed pair on <= 16 counters serialised the wave's lanes
+    // on a few addresses: the shard scan took 0.83 ms instead of 0.43)
+    template <bool OWNER = false>
     __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
         __builtin_amdgcn_wave_barrier();
         if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
@@ -1498,14 +1502,24 @@ struct WaveStage {
         const u64 g = next_k * SX_SHARDS + shard;
         ++next_k;
         --k_left;
-        if (g < p.out_blocks) {  // capacity is checked by the host afterwards (from the cursors)
+        const bool fits = g < p.out_blocks;  // capacity is checked by the host afterwards (from the cursors)
 #pragma unroll
-            for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
-                const u32 k2 = q * 64u + (u32)lane_id();
-                if (k2 < count) p.out[g * SX_BLOCK + k2] = buf[half * SX_BLOCK + k2];
+        for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+            const u32 k2 = q * 64u + (u32)lane_id();
+            const bool valid = k2 < count;
+            const u64 pair = buf[half * SX_BLOCK + k2];
+            if (valid && fits) p.out[g * SX_BLOCK + k2] = pair;
+            if (OWNER) {
+                const u32 first = (u32)(pair >> 32);
+                u32 o = 0;
+                for (int i = 0; i < p.owner_n; ++i) o += first >= p.owner_bounds[i] ? 1u : 0u;  // wave-uniform trip counts
+                for (int r = 0; r <= p.owner_n; ++r) {
+                    const u32 c = (u32)__popcll(__ballot(valid && o == (u32)r));
+                    if (c && lane_id() == 0) __hip_atomic_fetch_add(&hist[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-            if (lane_id() == 0) p.blockfill[g] = count;
         }
+        if (fits && lane_id() == 0) p.blockfill[g] = count;
         __builtin_amdgcn_wave_barrier();
     }
     template <bool OWNER>
@@ -1520,12 +1534,6 @@ struct WaveStage {
                 __hip_atomic_fetch_add(&hist[q * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (OWNER) {
-            u32 o = 0;
-#pragma unroll
-            for (int i = 0; i < 15; ++i) o += (i < p.owner_n && first >= p.owner_bounds[i]) ? 1u : 0u;
-            __hip_atomic_fetch_add(&hist[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
     }
     template <bool OWNER = false>
     __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
@@ -1538,7 +1546,7 @@ struct WaveStage {
         }
         const u32 before = wp / SX_BLOCK;
         wp += n;
-        if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
+        if (wp / SX_BLOCK != before) write_block<OWNER>(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
     }
     // two candidates per lane (<= 128 pairs per call: still at most one half of the ring completes)
     template <bool OWNER = false>
@@ -1557,11 +1565,12 @@ struct WaveStage {
         }
         const u32 before = wp / SX_BLOCK;
         wp += n;
-        if (wp / SX_BLOCK != before) write_block(p, before & 1u, SX_BLOCK);
+        if (wp / SX_BLOCK != before) write_block<OWNER>(p, before & 1u, SX_BLOCK);
     }
+    template <bool OWNER = false>
     __device__ __forceinline__ void finish(const ExpandParams& p) {
         const u32 rem = wp & (SX_BLOCK - 1u);
-        if (rem) write_block(p, (wp / SX_BLOCK) & 1u, rem);
+        if (rem) write_block<OWNER>(p, (wp / SX_BLOCK) & 1u, rem);
         if (wp && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)wp);
         if (examined && lane_id() == 0) atomicAdd(&p.shards[2 * SX_SHARDS + shard], examined);
     }
@@ -1777,7 +1786,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         __builtin_amdgcn_wave_barrier();
     }
     if (GEN == 1) return;
-    st.finish(p);
+    st.template finish<OWNER>(p);
     sx_hist_flush(s_hist, p);
 }
 
@@ -1829,7 +1838,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
         }
     }
     if (GEN == 1) return;
-    st.finish(p);
+    st.template finish<OWNER>(p);
     sx_hist_flush(s_hist, p);
 }
 
