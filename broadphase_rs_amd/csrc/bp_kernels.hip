@@ -10,6 +10,7 @@
 #include "bp_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace bp {
 namespace {
@@ -613,7 +614,10 @@ template <> struct StageBytes<NoVal> { static constexpr size_t value = 0; };
 #endif
 // STABLE = false: records of equal digit may leave a tile in any order (one returning LDS atomic per record instead of the
 // mask-match rounds).  Valid for the FIRST pass of any LSD sort that does not rely on the input order of equal keys.
-template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool STABLE = true>
+// FEW: the digit takes a handful of values (multi-GPU bucketing by owner, <= 17 buckets): a wave ranks a round by walking
+// the distinct digits it holds (first-lane broadcast + ballot), since per-digit LDS words would have all 64 lanes on a few
+// addresses.  Stable.
+template <typename K, typename V, int THREADS, int ITEMS, typename DigitFn, bool STABLE = true, bool FEW = false>
 __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                                     const V* __restrict__ vals_in, V* __restrict__ vals_out,
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
@@ -685,7 +689,27 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     // replace an 8-ballot match.  The masks alias the (not yet used) staging buffer.
     u64* s_mask = reinterpret_cast<u64*>(s_stage) + (size_t)w * RS_BINS;
     const u64 lanebit = 1ull << lane;
-    if constexpr (!STABLE && sizeof(s_cnt[0][0]) == 4) {   // (16-bit counters have no native LDS atomic: stable rounds then)
+    if constexpr (FEW) {
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const bool valid = (vmask >> r) & 1u;
+            const u32 dg = digit(key[r]);
+            u64 todo = __ballot(valid);
+            u32 pos = 0;
+            while (todo) {  // wave-uniform: one trip per distinct digit of the round
+                const int leader = __builtin_ctzll(todo);
+                const u32 d0 = (u32)__builtin_amdgcn_readlane((int)dg, leader);
+                const u64 m = __ballot(valid && dg == d0);
+                const u32 cnt = s_cnt[w][d0];  // same address for the whole wave: a broadcast read
+                if (valid && dg == d0) pos = cnt + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                __builtin_amdgcn_wave_barrier();
+                if (lane == leader) s_cnt[w][d0] = cnt + (u32)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~m;
+            }
+            packed[r] = dg | (pos << 8);
+        }
+    } else if constexpr (!STABLE && sizeof(s_cnt[0][0]) == 4) {   // (16-bit counters have no native LDS atomic: stable rounds then)
         // all RS_ITEMS atomics of a lane are independent: they issue back to back, one LDS round trip for the lot
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
@@ -2580,10 +2604,17 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr,
-                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true, u32 epoch = 0) {
+                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true, u32 epoch = 0, bool few = false) {
     // n: extent of the input (tiles are cut from it); n_out: records that exist (== n without holes)
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     if (!blockfill) n_out = n;
+    if constexpr (!std::is_same<DigitFn, ShiftDigit>::value) {  // the bucketing passes (few buckets); radix digits never take this route
+        if (few) {
+            radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
+                ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
+            return hipGetLastError();
+        }
+    }
     if (stable)
         radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
             ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
@@ -2713,7 +2744,9 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
     if ((e = hipGetLastError()) != hipSuccess) return e;
     radix_binbase_kernel<<<1, RS_BINS, 0, stream>>>(hist, bin_base);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr, blockfill, n_out);
+    static const bool no_few = getenv("BP_NO_FEW_RANKING") != nullptr;  // A/B switch
+    return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr, blockfill, n_out,
+                                            true, 0, !no_few);
 }
 
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
