@@ -542,6 +542,24 @@ def test_grouped_finish_of_pairs_that_repeat(density, cluster):
         gpu.clear(); gpu.extend(sysb, bounds, ids)
 
 
+@pytest.mark.parametrize("density", [0.001, 0.012])
+def test_dense_large_ids_take_the_duplicate_tolerant_grouped_finish(density):
+    """distinct ids >= 2^27 that are DENSE (an offset id space): no box codes, so the raw stream repeats pairs, and the
+    first-id range is narrow enough for the grouped finish -- group keys, sub-bins of the second id and the output all
+    work relative to the smallest id.  The denser scene needs narrower groups (more pairs per id)"""
+    n = 100000 if density < 0.01 else 40000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=77, density=density)
+    big = (ids + np.uint32((1 << 27) + 12345)).astype(np.uint32)
+    gpu, ref = both(2, 0)
+    gpu.extend(sysb, bounds, big); ref.extend(sysb, bounds, big)
+    exp = ref.scan()
+    for frame in range(3):
+        assert_pairs_equal(np.array(gpu.par_scan()), exp, "dense ids >= 2^27, frame %d" % frame)
+        st = gpu.stats()
+        assert st["raw_pairs"] > st["pairs"] == len(exp)
+        gpu.clear(); gpu.extend(sysb, bounds, big)
+
+
 def test_frames_of_changing_size_share_one_radix_workspace():
     """the sorts tag their look-back status words with a per-layer launch counter instead of zero-filling the workspace:
     frames of very different sizes on ONE layer (tile counts change, the status arrays of different passes overlap
