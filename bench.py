@@ -291,6 +291,18 @@ def main():
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         if int(agree.item()) == 0:
             sharded = None
+        if sharded is not None:  # one untimed step through the engine: an error on any rank sends every rank to the other engine
+            try:
+                sharded.clear()
+                sharded.extend(sysb, d_bounds, d_ids)
+                sharded.par_scan_device(args.pair_order)
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("rank %d: C sharded engine failed its first step (%s): using torch.distributed\n" % (rank, e))
+                ok = 0
+            agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 0:
+                sharded = None
     if sharded is not None:
         engine_name = "c-abi (include/bp_sharded.h), RCCL bound by the library"
 
