@@ -381,6 +381,7 @@ int sfail(bp_sharded* s, int code, const std::string& what) {
     } while (0)
 #define G_TRY(s, call)                                                                  \
     do {                                                                                \
+        ++(s)->info.round_trips_exchanges;                                              \
         int rc__ = (call);                                                              \
         if (rc__ != BP_OK) return sfail((s), rc__, (s)->group->err);                    \
     } while (0)
@@ -550,7 +551,15 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         s->info.stage_ms[stage] += std::chrono::duration<float, std::milli>(now - t_prev).count();
         t_prev = now;
     };
-    auto finish = [&]() { s->info.stage_ms[7] = std::chrono::duration<float, std::milli>(clk::now() - t_begin).count(); };
+    bp_stats st0_local, st0_shard;
+    (void)bp_layer_stats(s->local, &st0_local);
+    (void)bp_layer_stats(s->shard, &st0_shard);
+    auto finish = [&]() {
+        s->info.stage_ms[7] = std::chrono::duration<float, std::milli>(clk::now() - t_begin).count();
+        bp_stats a, b;
+        if (bp_layer_stats(s->local, &a) == BP_OK && bp_layer_stats(s->shard, &b) == BP_OK)
+            s->info.round_trips_layers = (uint32_t)((a.host_syncs - st0_local.host_syncs) + (b.host_syncs - st0_shard.host_syncs));
+    };
 
     // ---- 2. cell histogram + facts of every rank in ONE small all-gather ------------------------------------------------
     std::vector<uint64_t> hist(n_cells + 1, 0);

@@ -26,7 +26,8 @@ EXPORTS = [
 class _Info(C.Structure):
     _fields_ = [("entries_local", C.c_uint64), ("entries_shard", C.c_uint64), ("coarse", C.c_uint64), ("raw_pairs", C.c_uint64),
                 ("raw_pairs_recv", C.c_uint64), ("pairs", C.c_uint64), ("id_lo", C.c_uint32), ("id_hi", C.c_uint32),
-                ("box_codes", C.c_uint32), ("pair_order", C.c_uint32), ("stage_ms", C.c_float * 8)]
+                ("box_codes", C.c_uint32), ("pair_order", C.c_uint32), ("stage_ms", C.c_float * 8),
+                ("round_trips_layers", C.c_uint32), ("round_trips_exchanges", C.c_uint32)]
 
 
 _bound = False

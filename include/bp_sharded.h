@@ -90,6 +90,10 @@ typedef struct bp_sharded_info {
      * owner, 2 exchange of entries and boundary keys, 3 commit into the shard layer, 4 shard sort + scan (+ bucketing of
      * the pairs by owner), 5 exchange of pairs, 6 sort (+ dedup) of this rank's pairs, 7 the whole call */
     float stage_ms[8];
+    /* host round trips of the last bp_sharded_par_scan on this rank (each costs a launch -> completion -> host latency that
+     * no amount of GPUs shortens): stream synchronisations of the rank's two layers, and exchanges / collectives waited for */
+    uint32_t round_trips_layers;
+    uint32_t round_trips_exchanges;
 } bp_sharded_info;
 int bp_sharded_last_info(const bp_sharded_t *sh, bp_sharded_info *out);
 /* the rank's shard layer (sort / scan target), e.g. for bp_layer_stats; owned by the handle */

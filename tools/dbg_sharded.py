@@ -15,7 +15,7 @@ for f in range(6):
         sh.shard_layer.profile_enable(True); sh.shard_layer.profile_reset()
     sh.clear(); sh.extend(sysb, db, di); out = sh.par_scan_device()
 torch.cuda.synchronize()
-print(len(out), sh.last["stage_ms"])
+print(len(out), sh.last["stage_ms"], "round trips: layers", sh.last["round_trips_layers"], "exchanges", sh.last["round_trips_exchanges"])
 for k, (ms, cnt) in sh.shard_layer.profile().items():
     if cnt:
         print("%-14s %8.3f ms/frame  %5.1f regions/frame" % (k, ms / 2, cnt / 2))
