@@ -40,8 +40,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the configs[1] (1 M objects) sub-record")
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
-    ap.add_argument("--pair-order", choices=["global", "local"], default="global",
-                    help="VARIANT: 'local' leaves every rank's pairs where they were found (set-equal, not the sorted partition)")
+    ap.add_argument("--pair-order", choices=["global", "local"], default="local",
+                    help="N > 1: 'local' (default, north_star's design: boundary keys are exchanged, every rank returns the sorted "
+                         "duplicate-free pairs of its Morton range; the union is the reference's set) or 'global' (pairs exchanged by "
+                         "first-id range: the ranks' lists concatenate to the reference's sorted list).  The other order is timed as a sub-record")
+    ap.add_argument("--one-order", action="store_true", help="N > 1: skip the sub-record of the other pair order")
     ap.add_argument("--aabb-filter", action="store_true",
                     help="variant (not the headline metric): par_scan_filtered with the built-in device AABB narrow phase")
     return ap.parse_args()
@@ -79,6 +82,14 @@ def list_hash_numpy(pairs):
         return [int(len(p)), int(p.sum(dtype=np.uint64)), int((p * w).sum(dtype=np.uint64))]
 
 
+def set_hash_numpy(pairs):
+    """order-INDEPENDENT fingerprint of a pair set: (count, sum p, sum p * p) mod 2^64"""
+    import numpy as np
+    p = (pairs[:, 0].astype(np.uint64) << np.uint64(32)) | pairs[:, 1].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return [int(len(p)), int(p.sum(dtype=np.uint64)), int((p * p).sum(dtype=np.uint64))]
+
+
 def list_hash_torch(t):
     """the same fingerprint of a device-resident (n, 2) int32 view, with torch ops (int64 arithmetic wraps mod 2^64)"""
     import torch
@@ -87,6 +98,14 @@ def list_hash_torch(t):
     p = (a << 32) | b
     w = torch.arange(p.numel(), dtype=torch.int64, device=p.device) * 2 + 1
     return [int(p.numel()), int(p.sum().item()) & M64, int((p * w).sum().item()) & M64]
+
+
+def set_hash_torch(t):
+    import torch
+    a = t[:, 0].to(torch.int64) & 0xFFFFFFFF
+    b = t[:, 1].to(torch.int64) & 0xFFFFFFFF
+    p = (a << 32) | b
+    return [int(p.numel()), int(p.sum().item()) & M64, int((p * p).sum().item()) & M64]
 
 
 def cpu_baseline(n_objects, seed):
@@ -99,6 +118,7 @@ def cpu_baseline(n_objects, seed):
     threads = usable_cpus(oracle.lib().orc_hw_threads())
     rows = {}
     list_hash = None
+    set_hash = None
     # "tuned": min_depth = smallest natural depth of the scene, so indices/results are unchanged
     # but par_scan_impl can actually split (src/layer.rs:533-546); "default": min_depth = 0, where
     # level_mask(0) == 0 makes the reference's scan one serial sweep (only the sorts are parallel).
@@ -116,13 +136,14 @@ def cpu_baseline(n_objects, seed):
         rows[name] = {"pairs": int(len(pairs)), "seconds": dt, "pairs_per_s": len(pairs) / dt}
         if md == 0:
             list_hash = list_hash_numpy(pairs)
+            set_hash = set_hash_numpy(pairs)
         del lay, pairs
     best = max(rows.values(), key=lambda r: r["pairs_per_s"])
     return {"value": best["pairs_per_s"] / 1e6, "unit": "Mpairs/s", "cores": threads, "kind": "port",
             "sample": "gen_boxes(%d objects, density 0.001, seed %d): clear+extend+par_sort+par_scan, OpenMP "
                       "C restatement with the reference's structure; rows: %s" % (
                           n_objects, seed, json.dumps({k: round(v["pairs_per_s"] / 1e6, 3) for k, v in rows.items()})),
-            "rows": rows, "list_hash": list_hash}
+            "rows": rows, "list_hash": list_hash, "set_hash": set_hash}
 
 
 # one kernel per class on the default path (bp_kernel_class of include/bp_layer.h) -> (kernel name, SURVEY 8(d) bytes per launch)
@@ -223,6 +244,7 @@ def main():
         # in-run parity: the device list's fingerprint against the CPU row's (same scene, same seed)
         gpu_hash = list_hash_torch(r["out"].as_torch()) if r["n_pairs"] else [0, 0, 0]
         line["list_hash"] = gpu_hash
+        line["set_hash"] = set_hash_torch(r["out"].as_torch()) if r["n_pairs"] else [0, 0, 0]
         del r["out"]
         if not args.no_1m and args.objects != 1_000_000 and not args.aabb_filter:
             r1 = run_single(bp, scenes, torch, np, dev, local_rank, 1_000_000, args.seed, 5, 50, detail=False)
@@ -306,71 +328,94 @@ def main():
     if sharded is not None:
         engine_name = "c-abi (include/bp_sharded.h), RCCL bound by the library"
 
-        def step():
+        def step(order):
             sharded.clear()
             sharded.extend(sysb, d_bounds, d_ids)
-            return sharded.par_scan_device(args.pair_order)
+            return sharded.par_scan_device(order)
     else:
         engine_name = "python (broadphase_rs_amd/dist.py) over torch.distributed"
-        sharded = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=args.pair_order)
+        layers = {}
 
-        def step():
-            sharded.clear()
-            sharded.extend(sysb, d_bounds, d_ids)
-            return sharded.par_scan_device()
+        def step(order):
+            if order not in layers:
+                layers[order] = bpd.ShardedLayer(bp.Index64_3D, 0, device=local_rank, n_global=n_global, pair_order=order)
+            lay = layers[order]
+            lay.clear()
+            lay.extend(sysb, d_bounds, d_ids)
+            return lay.par_scan_device()
 
     def barrier():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    n_pairs_local = len(out)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    c = torch.tensor([n_pairs_local], dtype=torch.int64, device=dev)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    n_pairs = int(c.item())
-    # fingerprint of the global list = per-rank fingerprints combined with the ranks' list offsets (rank order = list order)
-    h = list_hash_torch(out.as_torch()) if n_pairs_local else [0, 0, 0]
-    hv = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in h], dtype=torch.int64, device=dev)
-    parts = [torch.empty_like(hv) for _ in range(world)]
-    dist.all_gather(parts, hv)
-    if rank == 0:
-        cnt = s1 = s2 = 0
+    def measure(order):
+        """W warm-up + K timed steps of one pair order -> record (rank 0) with the job's pair count and fingerprints"""
+        for _ in range(args.warmup):
+            out = step(order)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(order)
+        barrier()
+        dt = time.perf_counter() - t0
+        n_pairs_local = len(out)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # fingerprints: the ordered one of the concatenated list (per-rank fingerprints combined with the ranks' list offsets,
+        # rank order = list order) and the order-independent one of the union
+        h = list_hash_torch(out.as_torch()) if n_pairs_local else [0, 0, 0]
+        hs = set_hash_torch(out.as_torch()) if n_pairs_local else [0, 0, 0]
+        hv = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in h + hs], dtype=torch.int64, device=dev)
+        parts = [torch.empty_like(hv) for _ in range(world)]
+        dist.all_gather(parts, hv)
+        cnt = s1 = s2 = q2 = 0
         for pr in parts:
-            k, a, b = [int(v) & M64 for v in pr.tolist()]
-            s2 = (s2 + b + 2 * cnt * a) & M64      # sum p (2 (i + cnt) + 1) = local + 2 cnt sum p
-            s1 = (s1 + a) & M64
+            k, a_, b_, _, _, c_ = [int(v) & M64 for v in pr.tolist()]
+            s2 = (s2 + b_ + 2 * cnt * a_) & M64      # sum p (2 (i + cnt) + 1) = local + 2 cnt sum p
+            s1 = (s1 + a_) & M64
+            q2 = (q2 + c_) & M64
             cnt += k
-        st = sharded.shard_layer.stats()
-        ms_per_step = dt / args.steps * 1e3
+        info = sharded.last if hasattr(sharded, "last") else layers[order].last
+        route = info.get("pair_order", order) if isinstance(info, dict) else order
+        return {"pair_order": route, "ms_per_step": dt / args.steps * 1e3, "pairs_total": cnt, "value": cnt / (dt / args.steps),
+                "pairs_this_rank": n_pairs_local, "list_hash": [cnt, s1, s2] if route == "global" else None, "set_hash": [cnt, s1, q2],
+                "stages": info}
+
+    main_rec = measure(args.pair_order)
+    other = "global" if args.pair_order == "local" else "local"
+    other_rec = None if args.one_order else measure(other)
+    if rank == 0:
+        shard_stats = (sharded.shard_layer if hasattr(sharded, "shard_layer") else layers[args.pair_order].shard_layer).stats() \
+            if (hasattr(sharded, "shard_layer") or layers) else {}
+        order_note = {
+            "local": "every rank returns the sorted duplicate-free pairs found in its own Morton range (boundary keys all-gathered, no pair "
+                     "crosses the wire): the ranks' lists are disjoint and their union is the reference's set (set_hash = the single-GPU one)",
+            "global": "raw pairs move to the owner of their first-id range: the ranks' lists, concatenated in rank order, ARE the reference's "
+                      "sorted list (list_hash = the single-GPU one)"}
         line = {
-            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if args.pair_order == "global" else
-                      "VARIANT (not the headline metric): pairs left on the rank that found them (set-equal, unsorted across ranks)",
-            "value": n_pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak",
+            "value": main_rec["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("configs[3]: %d Index64_3D uniform-random AABBs in total over %d GPUs (gen_boxes recipe, sharded by "
-                                    "object index), per-GPU extend, Morton-range exchange, sort + scan, pair exchange by id range"
-                                    % (n_global, world)) if strong else
+                                    "object index), per-GPU extend, Morton-range exchange of entries + all-gather of boundary keys, "
+                                    "shard sort + scan" % (n_global, world)) if strong else
                                    "%d Index64_3D uniform-random AABBs per GPU x %d GPUs (one %d-object scene)" % (n, world, n_global),
-                       "objects_per_gpu": n, "objects_total": n_global, "entries_rank0_shard": st["entries"], "pairs_rank0": n_pairs_local,
-                       "pairs_total": n_pairs, "parallelism": "morton-range shards x%d, RCCL all-to-all + all-gather of boundary keys" % world,
-                       "engine": engine_name},
+                       "objects_per_gpu": n, "objects_total": n_global, "entries_rank0_shard": shard_stats.get("entries"),
+                       "pairs_rank0": main_rec["pairs_this_rank"], "pairs_total": main_rec["pairs_total"],
+                       "pair_order": main_rec["pair_order"], "pair_order_note": order_note[main_rec["pair_order"]],
+                       "parallelism": "morton-range shards x%d over RCCL" % world, "engine": engine_name},
             "roofline": None, "cpu_baseline": None,
-            "objects_per_s": n_global / (dt / args.steps),
-            "list_hash": [cnt, s1, s2],
-            "sharded": sharded.last,
+            "objects_per_s": n_global / (main_rec["ms_per_step"] * 1e-3),
+            "list_hash": main_rec["list_hash"], "set_hash": main_rec["set_hash"],
+            "sharded": main_rec["stages"],
         }
+        if other_rec is not None:
+            line["pair_order_" + other] = {"ms_per_step": other_rec["ms_per_step"], "value": other_rec["value"], "pairs_total": other_rec["pairs_total"],
+                                           "pair_order": other_rec["pair_order"], "note": order_note[other_rec["pair_order"]],
+                                           "list_hash": other_rec["list_hash"], "set_hash": other_rec["set_hash"], "sharded": other_rec["stages"]}
         print(json.dumps(line))
     dist.barrier()
     dist.destroy_process_group()
