@@ -2340,13 +2340,14 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     // the partition pass then needs no histogram read of its own
     const unsigned long long* ready_hist = nullptr;
     if (L->cell_hist_valid && L->cell_hist_depth == split_depth && L->cell_hist_cache.size() == n_cells + 1) {
-        unsigned long long* h = (unsigned long long*)L->h_raw.p;
+        // upload source: the second half of h_raw (the first half receives the bucket sizes back below: no wait in between)
+        BP_TRY(ensure_host(L, L->h_raw, 512 * sizeof(unsigned long long)));
+        unsigned long long* h = (unsigned long long*)L->h_raw.p + 256;
         std::memset(h, 0, 256 * sizeof(unsigned long long));
         for (size_t c = 0; c < n_cells; ++c) h[lut[c] < n_dest ? lut[c] : 0] += L->cell_hist_cache[c];
         h[n_dest] += L->cell_hist_cache[n_cells];  // coarse entries
         BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
         HIP_TRY(L, hipMemcpyAsync(L->pair_hist.p, h, 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, L->stream));
-        BP_TRY(sync_stream(L));  // h_raw is reused below
         ready_hist = (const unsigned long long*)L->pair_hist.p;
     }
     const unsigned long long* d_hist = nullptr;

@@ -550,6 +550,12 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         const clk::time_point now = clk::now();
         s->info.stage_ms[stage] += std::chrono::duration<float, std::milli>(now - t_prev).count();
         t_prev = now;
+        if (getenv("BP_SHARDED_DEBUG")) {
+            bp_stats a, b;
+            (void)bp_layer_stats(s->local, &a); (void)bp_layer_stats(s->shard, &b);
+            fprintf(stderr, "stage %d: syncs local %llu shard %llu exchanges %u\n", stage, (unsigned long long)a.host_syncs,
+                    (unsigned long long)b.host_syncs, s->info.round_trips_exchanges);
+        }
     };
     bp_stats st0_local, st0_shard;
     (void)bp_layer_stats(s->local, &st0_local);
