@@ -686,24 +686,22 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     const uint32_t n_bounds = (uint32_t)(G - 1);
     for (int r = 0; r + 1 < G; ++r) bounds[r] = (uint32_t)std::min<uint64_t>(span * (uint64_t)(r + 1), 0xFFFFFFFFull);
     const int emit_coarse = rank == 0 ? 1 : 0;
-    if (pair_order == BP_PAIRS_LOCAL && pack && all_known) {
+    // LOCAL order: possible while every shard suppresses its duplicates at the source -- box codes known for every entry and
+    // ids provably distinct, facts every rank holds alike, so the route is decided without another exchange
+    static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // the layers' measurement switch
+    if (pair_order == BP_PAIRS_LOCAL && pack && all_known && (uf.flags & BP_FACT_IDS_DISTINCT) && !no_source_dedup) {
         const uint32_t* dp = nullptr;
         size_t np = 0;
         int unique = 0;
         L_TRY(s, s->shard, bp_layer_par_scan_shard_device(s->shard, d_s, emit_coarse, &dp, &np, &unique));
         lap(4);
-        std::vector<int64_t> u1(1, unique ? 0 : 1), uall(G);
-        G_TRY(s, grp_allgather_i64(g, rank, u1.data(), 1, uall.data()));
-        bool all_unique = true;
-        for (int r = 0; r < G; ++r) all_unique = all_unique && uall[r] == 0;
-        if (all_unique) {
-            s->d_out = dp; s->n_out = np;
-            s->info.raw_pairs = np; s->info.pairs = np; s->info.id_lo = 0; s->info.id_hi = (uint32_t)max_id; s->info.pair_order = BP_PAIRS_LOCAL;
-            *d_pairs = dp; *n_pairs = np;
-            finish();
-            return BP_OK;
-        }
-        // a shard could not vouch for uniqueness after all: take the exchange route (re-scans)
+        if (!unique && n_recv + n_coarse != 0)  // cannot happen with these facts; the other ranks have already taken this route
+            return sfail(s, BP_ERR_KERNEL, "the shard scan did not suppress its duplicates although every box code is known");
+        s->d_out = dp; s->n_out = np;
+        s->info.raw_pairs = np; s->info.pairs = np; s->info.id_lo = 0; s->info.id_hi = (uint32_t)max_id; s->info.pair_order = BP_PAIRS_LOCAL;
+        *d_pairs = dp; *n_pairs = np;
+        finish();
+        return BP_OK;
     }
     std::vector<uint64_t> pcounts(G, 0);
     const uint64_t* d_grouped = nullptr;
