@@ -2313,7 +2313,8 @@ int bp_layer_partition_entries_device(bp_layer_t* L, uint32_t split_depth, const
 }
 
 int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth, const uint8_t* lut, size_t n_cells, uint32_t n_dest,
-                                             int pack_box, uint64_t* counts, const uint64_t** d_keys, const uint32_t** d_ids) {
+                                             int flags, uint64_t* counts, const uint64_t** d_keys, const uint32_t** d_ids) {
+    const int pack_box = flags & BP_PARTITION_PACK_BOX;
     if (!L || !lut || !counts || !d_keys || !d_ids) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: null argument");
     const KindInfo ki = kind_info(L->kind);
     if (split_depth == 0 || split_depth > ki.axis_bits || n_cells != ((size_t)1 << (ki.dim * split_depth)) || n_cells > 4096 ||
@@ -2349,6 +2350,7 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
         BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
         HIP_TRY(L, hipMemcpyAsync(L->pair_hist.p, h, 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, L->stream));
         ready_hist = (const unsigned long long*)L->pair_hist.p;
+        for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = h[i];  // the bucket sizes ARE these sums
     }
     const unsigned long long* d_hist = nullptr;
     {
@@ -2358,6 +2360,9 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
                                      L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, &d_hist, L->stream,
                                      (pack_box && !already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr, ready_hist));
     }
+    // enqueue only: the bucket sizes are known from the histogram, the caller orders whatever reads the buckets behind this
+    // layer's stream (bp_layer_stream) itself, and nobody waits here
+    if ((flags & BP_PARTITION_ENQUEUE_ONLY) && ready_hist) return BP_OK;
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));

@@ -292,7 +292,8 @@ Xfer xfer_allgatherv(int W, int rank, const void* send, const uint64_t* sizes, s
     return x;
 }
 // max_msg_bytes: the largest single message of ANY rank in ANY of the transfers (every rank passes the same value)
-int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg_bytes) {
+// wait = false: only enqueued on the group's stream; the caller orders its consumers behind that stream
+int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg_bytes, bool wait = true) {
     const RcclApi* a = rccl_api();
     const int W = g->world;
     const uint64_t rounds = std::max<uint64_t>(1, (max_msg_bytes + CHUNK_BYTES - 1) / CHUNK_BYTES);
@@ -315,7 +316,7 @@ int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg
         }
         RCCL_TRY(g, a->GroupEnd());
     }
-    GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (wait) GHIP_TRY(g, hipStreamSynchronize(g->stream));
     return BP_OK;
 }
 
@@ -350,6 +351,7 @@ uint64_t varying_bits(uint64_t lo, uint64_t hi) {  // mask of the bits that can 
 }  // namespace
 
 struct bp_sharded {
+    hipEvent_t chain_ev = nullptr;  // orders the group's stream behind the local layer's (entry exchange after the partition pass)
     bp_group* group = nullptr;
     int rank = 0, world = 1, kind = BP_INDEX64_3D, device = 0;
     uint32_t split_depth = 3;
@@ -491,6 +493,7 @@ int bp_sharded_destroy(bp_sharded_t* s) {
     (void)hipSetDevice(s->device);
     if (s->d_recv_pairs) (void)hipFree(s->d_recv_pairs);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->chain_ev) (void)hipEventDestroy(s->chain_ev);
     delete s;
     return BP_OK;
 }
@@ -604,7 +607,19 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     std::vector<uint64_t> counts(G + 1, 0);
     const uint64_t* d_keys = nullptr;
     const uint32_t* d_ids = nullptr;
-    L_TRY(s, s->local, bp_layer_partition_entries_packed_device(s->local, d_s, lut.data(), n_cells, (uint32_t)G, pack ? 1 : 0, counts.data(), &d_keys, &d_ids));
+    // RCCL: the partition pass, the exchange and the shard's kernels are chained by events (partition on the local layer's
+    // stream -> exchange on the group's stream -> shard layer's stream); the host waits for none of them
+    const bool chained = g->kind == GRP_RCCL && !getenv("BP_SHARDED_SYNC_EXCHANGE");
+    L_TRY(s, s->local, bp_layer_partition_entries_packed_device(s->local, d_s, lut.data(), n_cells, (uint32_t)G,
+                                                                (pack ? BP_PARTITION_PACK_BOX : 0) | (chained ? BP_PARTITION_ENQUEUE_ONLY : 0),
+                                                                counts.data(), &d_keys, &d_ids));
+    if (chained) {
+        void* local_stream = nullptr;
+        L_TRY(s, s->local, bp_layer_stream(s->local, &local_stream));
+        if (!s->chain_ev && hipEventCreateWithFlags(&s->chain_ev, hipEventDisableTiming) != hipSuccess) return sfail(s, BP_ERR_HIP, "hipEventCreate failed");
+        if (hipEventRecord(s->chain_ev, (hipStream_t)local_stream) != hipSuccess || hipStreamWaitEvent(g->stream, s->chain_ev, 0) != hipSuccess)
+            return sfail(s, BP_ERR_HIP, "could not order the exchange behind the partition pass");
+    }
     lap(1);
     // cm[src][dst] entries go from src to dst, cm[src][G] = src's boundary keys: every rank derives the whole matrix from
     // the gathered histograms and the table (no second exchange of counts)
@@ -638,7 +653,12 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
             xs.push_back(xfer_allgatherv(G, rank, d_keys + n_fine, coarse_sizes.data(), sizeof(uint64_t), sk + n_recv));
             xs.push_back(xfer_allgatherv(G, rank, d_ids + n_fine, coarse_sizes.data(), sizeof(uint32_t), si + n_recv));
         }
-        G_TRY(s, grp_exchange_rccl(g, xs, max_msg * sizeof(uint64_t)));
+        G_TRY(s, grp_exchange_rccl(g, xs, max_msg * sizeof(uint64_t), /*wait=*/!chained));
+        if (chained) {  // the shard's kernels read what arrives; the local layer's next frame reuses what is being sent
+            --s->info.round_trips_exchanges;  // nobody waited
+            L_TRY(s, s->shard, bp_layer_wait_stream(s->shard, (void*)g->stream));
+            L_TRY(s, s->local, bp_layer_wait_stream(s->local, (void*)g->stream));
+        }
     } else {
         G_TRY(s, grp_alltoallv(g, rank, d_keys, send_counts.data(), recv_counts.data(), sizeof(uint64_t), sk, max_msg, s->stream));
         G_TRY(s, grp_alltoallv(g, rank, d_ids, send_counts.data(), recv_counts.data(), sizeof(uint32_t), si, max_msg, s->stream));

@@ -208,9 +208,13 @@ int bp_layer_partition_entries_device(bp_layer_t *layer, uint32_t split_depth, c
 /* *can: bit 0 = this layer's ids can carry their box codes (ids < 2^27, distinct, id-ordered),
  * bit 1 = every box code of the layer is known */
 int bp_layer_can_pack_box(const bp_layer_t *layer, int *can);
-/* as above, with the box code of every entry packed into bits 27..31 of its id (pack_box != 0) */
+/* as above; flags: BP_PARTITION_PACK_BOX = the box code of every entry packed into bits 27..31 of its id;
+ * BP_PARTITION_ENQUEUE_ONLY = when the bucket sizes follow from the cell histogram the layer has just reported
+ * (bp_layer_cell_histogram at the same depth), return as soon as the pass is enqueued: counts are filled from the histogram,
+ * and the caller makes whatever reads the buckets wait for the layer's stream (bp_layer_stream) */
+enum { BP_PARTITION_PACK_BOX = 1, BP_PARTITION_ENQUEUE_ONLY = 2 };
 int bp_layer_partition_entries_packed_device(bp_layer_t *layer, uint32_t split_depth, const uint8_t *lut,
-                                             size_t n_cells, uint32_t n_dest, int pack_box, uint64_t *counts,
+                                             size_t n_cells, uint32_t n_dest, int flags, uint64_t *counts,
                                              const uint64_t **d_keys, const uint32_t **d_ids);
 /* raw pair stream of the shard scan as packed u64 (id << 32 | id_), left in HBM */
 int bp_layer_scan_raw_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
