@@ -168,6 +168,8 @@ hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const ui
                            size_t workspace_bytes, DevScalars* sc, const unsigned long long** d_hist, hipStream_t stream,
                            const uint32_t* blockfill = nullptr, size_t n_out = 0, const unsigned long long* ready_hist = nullptr);
 // entries per cell at split_depth; slot n_cells counts the coarse entries
+// out[k] = sum over c < n_copies of copies[c * n + k]  (the spread-out histograms of encode_emit)
+hipError_t launch_sum_copies(const unsigned long long* copies, int n_copies, uint32_t n, unsigned long long* out, hipStream_t stream);
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                             uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream);
 

@@ -2793,6 +2793,21 @@ hipError_t partition_pairs(const uint64_t* in, uint64_t* out, size_t n, const ui
                                                  (const u64*)ready_hist);
 }
 
+// out[k] = sum over the copies of copies[c * n + k]
+__global__ __launch_bounds__(256) void sum_copies_kernel(const u64* __restrict__ copies, int n_copies, u32 n, u64* __restrict__ out) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    u64 t = 0;
+#pragma unroll 8
+    for (int c = 0; c < n_copies; ++c) t += copies[(size_t)c * n + k];
+    out[k] = t;
+}
+hipError_t launch_sum_copies(const unsigned long long* copies, int n_copies, uint32_t n, unsigned long long* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    sum_copies_kernel<<<(n + 255) / 256, 256, 0, stream>>>((const u64*)copies, n_copies, n, (u64*)out);
+    return hipGetLastError();
+}
+
 hipError_t launch_cell_hist(const uint64_t* keys, size_t m, int cell_shift, uint32_t depth_mask, uint32_t split_depth,
                             uint32_t n_cells, unsigned long long* d_hist, hipStream_t stream) {
     if (m == 0) return hipSuccess;

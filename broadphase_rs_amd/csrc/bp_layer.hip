@@ -73,12 +73,12 @@ struct bp_layer {
 
     // temporaries
     DevBuf in_bounds, in_ids;           // staging for host inputs
-    DevBuf counts, block_sums, aux, skip;
+    DevBuf counts, block_sums, aux, skip, cell_sum;
     DevBuf pairs[2];                    // packed raw pairs (ping-pong for the pair sort)
     DevBuf out_pairs;                   // final interleaved (id, id_) list
     DevBuf radix_ws;
     DevBuf d_sc;                        // DevScalars
-    HostBuf h_sc, h_pairs, h_keys, h_ids, h_raw;
+    HostBuf h_sc, h_pairs, h_keys, h_ids, h_raw, h_cells;
     size_t n_raw = 0, n_pairs = 0;
     bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
     DevBuf idctx, big_list;             // expanding scan: per-entry id << 32 | suppression context; long-range work list
@@ -443,6 +443,15 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
                                       count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth,
                                       (DevScalars*)L->d_sc.p, capacity));
     }
+    // the cell histogram counted on the way (multi-GPU splitter): summed on the device and brought back by THIS round trip,
+    // so that bp_layer_cell_histogram costs none of its own
+    const uint32_t n_cellbins = count_cells ? (1u << (kic.dim * L->cell_fuse_depth)) + 1u : 0u;
+    if (count_cells) {
+        BP_TRY(ensure_dev(L, L->cell_sum, n_cellbins * sizeof(unsigned long long)));
+        BP_TRY(ensure_host(L, L->h_cells, n_cellbins * sizeof(unsigned long long)));
+        HIP_TRY(L, launch_sum_copies((const unsigned long long*)L->cell_hist_dev.p, HIST_COPIES, n_cellbins, (unsigned long long*)L->cell_sum.p, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(L->h_cells.p, L->cell_sum.p, n_cellbins * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
+    }
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));
     const size_t add = (size_t)sc.total;
@@ -466,7 +475,13 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     L->enc_hint.pack = can_pack && !no_emit_pack;
     L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
     if (add == 0) return BP_OK;
-    if (count_cells) L->cell_dev_valid = true;
+    if (count_cells) {
+        L->cell_dev_valid = true;
+        const unsigned long long* hc = (const unsigned long long*)L->h_cells.p;
+        L->cell_hist_cache.assign(hc, hc + n_cellbins);
+        L->cell_hist_depth = L->cell_fuse_depth;
+        L->cell_hist_valid = true;
+    }
     if (pack) { L->ids_packed = true; L->box_valid = false; }
     L->tail_run = false;
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
@@ -1663,8 +1678,8 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds);
-    free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw);
+    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
+    free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
@@ -2266,6 +2281,10 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_cell_histogram: n_cells must be 2^(dim*split_depth) <= 4096");
     DeviceGuard g(L->device);
     const size_t bytes = (n_cells + 1) * sizeof(unsigned long long);
+    if (L->cell_hist_valid && L->cell_hist_depth == split_depth && L->cell_hist_cache.size() == n_cells + 1) {
+        std::memcpy(hist, L->cell_hist_cache.data(), bytes);  // extend brought it back with its own round trip
+        return BP_OK;
+    }
     if (L->cell_dev_valid && L->cell_fuse_depth == split_depth) {  // counted by extend: sum the copies, no kernel
         const size_t all = (size_t)HIST_COPIES * bytes;
         BP_TRY(ensure_host(L, L->h_raw, all));
