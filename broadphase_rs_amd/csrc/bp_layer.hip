@@ -108,7 +108,7 @@ struct bp_layer {
     uint32_t grp_off = 0;               // sorts left for which the grouped pair finish stays off (after a refusal)
     uint32_t grp_off_dups = 0;          // the same for the grouped finish of pairs that may repeat
     int grp_next_dups = 0;              // that finish ran last frame on groups of 2^this ids: the scan counts the digits of its plan
-    bool grp_next = false;              // the last distinct-pair sort used the grouped finish (plan hint for the next scan)
+    bool grp_next = true;               // the last distinct-pair sort used the grouped finish (plan hint for the next scan; a new layer expects it: a wrong guess only makes that sort count its own digits)
     // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (grp_max of the scalars) allow it
     bool tgrp_ok = false, tgrp_known = false;
     uint32_t tgrp_probe = 0;
@@ -1702,7 +1702,7 @@ int bp_layer_wait_stream(bp_layer_t* L, void* producer_stream) {
 int bp_layer_reset_plan_hints(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
     L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
-    L->grp_next = false; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
+    L->grp_next = true; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
     L->enc_hint.valid = false;
     return BP_OK;
 }
