@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Size-independent property check at sizes the oracle cannot follow (needs a GPU):
-   python tools/check_large.py <objects>   -> sorted tree, strictly increasing pair list, idempotent scan"""
+   python tools/check_large.py <objects> [powerlaw]  -> sorted tree, strictly increasing pair list, idempotent scan, and a
+   checksum line: run it again with BP_NO_EXPAND_SCAN=1 BP_NO_GROUP_FINISH=1 BP_NO_SEGMENT_FINISH=1 (per-entry ancestor walk,
+   full-width sorts: other kernels end to end) and compare"""
 import os
 import sys
 import time
@@ -14,7 +16,8 @@ from broadphase_rs_amd import scenes
 
 n = int(sys.argv[1])
 t0 = time.time()
-sysb, bounds, ids = scenes.gen_boxes(n, seed=1)
+powerlaw = len(sys.argv) > 2 and sys.argv[2] == "powerlaw"   # BASELINE configs[4]: Pareto(alpha = 2.5) sizes, deep stacks
+sysb, bounds, ids = scenes.gen_boxes_powerlaw(n, seed=1, alpha=2.5) if powerlaw else scenes.gen_boxes(n, seed=1)
 print("generated %d objects in %.1fs" % (n, time.time() - t0), flush=True)
 tb, ti = torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda()
 del bounds
@@ -46,4 +49,5 @@ print("objects %d entries %d raw %d pairs %d scan %.1f ms | tree sorted %s, pair
       "idempotent %s, tree passes %d pair passes %d" % (n, m, st["raw_pairs"], st["pairs"], dt * 1e3, ok_tree, ok_pairs, ok_self,
                                                     checksum == checksum2 and len(out) == len(out2), st["tree_sort_passes"],
                                                     st["pair_sort_passes"]))
+print("CHECKSUM objects %d%s pairs %d sum %d" % (n, " powerlaw" if powerlaw else "", st["pairs"], checksum))
 assert ok_tree and ok_pairs and ok_self and checksum == checksum2
