@@ -9,6 +9,7 @@
 #include "bp_kernels.h"
 #include "bp_device.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -3795,11 +3796,15 @@ hipError_t launch_group_finish_dups(const uint64_t* in, size_t n, uint32_t n_gro
     while (bits < 32 && ((second_hi - second_lo) >> bits) != 0) ++bits;
     const int sub_bits = 10 - gbits;
     const int sshift = bits > sub_bits ? bits - sub_bits : 0;
-    static bool lds_set = false;
-    if (!lds_set) {
+    // more dynamic LDS than a kernel gets by default: raised once per DEVICE (the attribute belongs to the device's copy of the kernel)
+    static std::atomic<unsigned long long> lds_set_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(lds_set_mask.load(std::memory_order_acquire) & bit)) {
         e = hipFuncSetAttribute((const void*)group_finish_dups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRD_LDS_BYTES);
         if (e != hipSuccess) return e;
-        lds_set = true;
+        lds_set_mask.fetch_or(bit, std::memory_order_release);
     }
     group_finish_dups_kernel<<<n_groups, GRD_THREADS, GRD_LDS_BYTES, stream>>>((const u64*)in, bounds, g0, gbits, sshift, second_lo, (uint2*)tmp, (u64*)counts, sc, stats);
     return hipGetLastError();
