@@ -180,3 +180,26 @@ def test_c_sharded_single_rank_rccl_group(self_send, monkeypatch):
     assert got.shape == expect.shape and np.array_equal(got, expect)
     del sh
     g.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["local", "global"])
+def test_c_sharded_rccl_frames_of_changing_scenes(order):
+    """the RCCL route chains the partition pass, the entry exchange and the shard's kernels by stream events (nobody waits on
+    the host in between) and reuses every buffer from frame to frame: frames of different scenes and sizes on ONE handle,
+    each compared with the oracle's list of that frame's scene"""
+    import oracle
+    g = sharded.Group.rccl(0, 1, sharded.Group.unique_id(), 0)
+    sh = sharded.CShardedLayer(g, 0, bp.Index64_3D, device=0, id_count=0)
+    for frame, (n, seed) in enumerate([(90000, 1), (4000, 2), (150000, 3), (150000, 4), (700, 5), (90000, 6)]):
+        sysb, bounds, ids = scenes.gen_boxes(n, seed=seed) if frame % 2 == 0 else scenes.gen_boxes_powerlaw(n, seed=seed, alpha=2.0)
+        sh.clear()
+        sh.extend(sysb, bounds, ids)
+        got = sh.par_scan(order)
+        ref = oracle.OracleLayer(2, 0)
+        ref.extend(sysb, bounds, ids)
+        expect = ref.scan()
+        assert got.shape == expect.shape and np.array_equal(got, expect), "frame %d" % frame   # one rank: local order = the whole list
+        assert sh.last["round_trips_exchanges"] <= (1 if order == "local" else 3), sh.last
+    del sh
+    g.destroy()
