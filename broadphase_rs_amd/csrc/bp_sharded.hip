@@ -173,8 +173,9 @@ int grp_allgather_i64(bp_group* g, int rank, const int64_t* mine, size_t n, int6
 
 // all-to-all-v of a device buffer that is already grouped by destination: send_counts[d] elements go to rank d,
 // recv_counts[s] arrive from rank s (rank order in `recv`); max_msg = the largest single message of ANY rank (elements)
+// wait = false (RCCL only): enqueued on the group's stream, the caller orders its consumers behind that stream
 int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_counts, const uint64_t* recv_counts, size_t elem,
-                  void* recv, uint64_t max_msg, hipStream_t local_stream) {
+                  void* recv, uint64_t max_msg, hipStream_t local_stream, bool wait = true) {
     const int W = g->world;
     std::vector<uint64_t> soff(W + 1, 0), roff(W + 1, 0);
     for (int r = 0; r < W; ++r) { soff[r + 1] = soff[r] + send_counts[r]; roff[r + 1] = roff[r] + recv_counts[r]; }
@@ -213,7 +214,7 @@ int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_
         }
         RCCL_TRY(g, a->GroupEnd());
     }
-    GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (wait) GHIP_TRY(g, hipStreamSynchronize(g->stream));
     return BP_OK;
 }
 
@@ -753,7 +754,13 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         }
         s->recv_cap = want;
     }
-    G_TRY(s, grp_alltoallv(g, rank, d_grouped, pcounts.data(), precv.data(), sizeof(uint64_t), s->d_recv_pairs, pmax, s->stream));
+    // (the bucketing pass has been waited for -- its sizes were needed for the all-gather above -- so the group's stream may start
+    // at once; the shard's sort is ordered behind the exchange by an event)
+    G_TRY(s, grp_alltoallv(g, rank, d_grouped, pcounts.data(), precv.data(), sizeof(uint64_t), s->d_recv_pairs, pmax, s->stream, /*wait=*/!chained));
+    if (chained) {
+        --s->info.round_trips_exchanges;
+        L_TRY(s, s->shard, bp_layer_wait_stream(s->shard, (void*)g->stream));
+    }
     lap(5);
     const uint64_t lo = rank == 0 ? 0 : bounds[rank - 1];
     const uint64_t hi_raw = rank == G - 1 ? max_id : (uint64_t)bounds[rank] - 1;
