@@ -467,7 +467,7 @@ def single_gpu_line(args, r, np):
         "metric": "candidate pairs/sec at 10M Index64_3D AABBs; achieved HBM GB/s vs peak" if not args.aabb_filter else
                   "VARIANT (not the headline metric): box-overlapping pairs/sec with the device AABB narrow phase fused into the scan",
         "value": n_pairs / (ms_per_step * 1e-3), "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,  # the N = 1 point of either curve
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": ("%s%dM Index64_3D uniform-random AABBs, single MI355X (gen_boxes recipe, density 0.001, "
                                 "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
