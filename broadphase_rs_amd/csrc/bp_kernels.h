@@ -99,8 +99,11 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
 
 // exclusive scan of per-block sums (in place), grand total -> sc->total; if aux != nullptr its n
 // partials are folded into *sc as well (single workgroup, no atomics)
+// init (with aux): *sc starts from *init before the partials are folded in (no separate reset); zero_a / zero_b: 64-bit arrays
+// zero-filled by the same launch (the histograms the following emit kernel adds into)
 hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const DevScalars* init = nullptr, unsigned long long* zero_a = nullptr,
+                                  size_t n_a = 0, unsigned long long* zero_b = nullptr, size_t n_b = 0);
 
 // OR/AND/depth-mask reduction over an existing tree (set_tree / append_entries)
 hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, DevScalars* sc,

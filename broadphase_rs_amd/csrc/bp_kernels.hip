@@ -369,8 +369,14 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
     }
     return v;
 }
+// Between the count and the emit kernel of an extend this kernel is also where the frame's small resets ride along: *sc starts
+// from `init` (set_init) instead of an H2D copy, and the histograms the emit kernel adds into are zero-filled here (zero_a / zero_b).
 __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __restrict__ sums, size_t n,
-                                                                     const BlockAux* __restrict__ aux, DevScalars* sc) {
+                                                                     const BlockAux* __restrict__ aux, DevScalars* sc, DevScalars init,
+                                                                     int set_init, u64* __restrict__ zero_a, u32 n_a, u64* __restrict__ zero_b,
+                                                                     u32 n_b) {
+    for (u32 k = threadIdx.x; k < n_a; k += SBS_THREADS) zero_a[k] = 0ull;
+    for (u32 k = threadIdx.x; k < n_b; k += SBS_THREADS) zero_b[k] = 0ull;
     __shared__ u64 s_wave[SBS_THREADS / 64];
     __shared__ u64 s_carry;
     __shared__ u64 r_kor[SBS_THREADS / 64], r_kand[SBS_THREADS / 64];
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __res
         }
         __syncthreads();
         if (threadIdx.x == 0) {
+            if (set_init) *sc = init;
             for (int k = 0; k < SBS_THREADS / 64; ++k) {
                 sc->key_or |= r_kor[k]; sc->key_and &= r_kand[k]; sc->depth_mask |= r_dm[k]; sc->flags |= r_fl[k];
                 sc->err |= r_er[k]; sc->n_invalid += r_inv[k]; sc->id_or |= r_ior[k]; sc->id_and &= r_iand[k];
@@ -2541,8 +2548,13 @@ static unsigned resident_blocks(Kern kernel, int threads) {
 }
 
 hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
-                                  hipStream_t stream) {
-    scan_block_sums_kernel<<<1, SBS_THREADS, 0, stream>>>(sums, n, aux, sc);
+                                  hipStream_t stream, const DevScalars* init, unsigned long long* zero_a, size_t n_a,
+                                  unsigned long long* zero_b, size_t n_b) {
+    if (n_a >= 0xFFFFFFFFull || n_b >= 0xFFFFFFFFull || (init && !aux)) return hipErrorInvalidValue;
+    DevScalars iv = {};
+    if (init) iv = *init;
+    scan_block_sums_kernel<<<1, SBS_THREADS, 0, stream>>>(sums, n, aux, sc, iv, init ? 1 : 0, (u64*)zero_a, zero_a ? (u32)n_a : 0u,
+                                                          (u64*)zero_b, zero_b ? (u32)n_b : 0u);
     return hipGetLastError();
 }
 

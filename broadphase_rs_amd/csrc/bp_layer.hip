@@ -415,16 +415,10 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     const KindInfo kic = kind_info(L->kind);
     const bool count_cells = L->cell_fuse_depth > 0 && kic.dim * L->cell_fuse_depth <= 9;
     const size_t cell_bytes = count_cells ? (size_t)HIST_COPIES * (((size_t)1 << (kic.dim * L->cell_fuse_depth)) + 1) * sizeof(unsigned long long) : 0;
-    if (count_cells) {
-        BP_TRY(ensure_dev(L, L->cell_hist_dev, cell_bytes));
-        HIP_TRY(L, hipMemsetAsync(L->cell_hist_dev.p, 0, cell_bytes, L->stream));
-    }
-    if (count_digits) {
-        BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
-        HIP_TRY(L, hipMemsetAsync(L->tree_hist.p, 0, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
-    }
+    // the histograms encode_emit adds into and the scalars are reset by scan_block_sums (between count and emit): no fills, no H2D copy
+    if (count_cells) BP_TRY(ensure_dev(L, L->cell_hist_dev, cell_bytes));
+    if (count_digits) BP_TRY(ensure_dev(L, L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
-    BP_TRY(sc_reset(L));
     {
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, (uint32_t*)L->counts.p,
@@ -432,7 +426,11 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     }
     {
         ProfScope ps(L, BP_K_MISC);
-        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
+        const DevScalars init = neutral_scalars();
+        HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
+                                          &init, count_digits ? (unsigned long long*)L->tree_hist.p : nullptr,
+                                          (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS,
+                                          count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, cell_bytes / sizeof(unsigned long long)));
     }
     {
         ProfScope ps(L, BP_K_ENCODE);
