@@ -549,12 +549,17 @@ __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __res
     bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
 }
 
+#ifndef RS_CUR_STRIDE
+#define RS_CUR_STRIDE 1040  // u32 words between two groups of 16 bin cursors (4160 bytes): the groups spread over memory channels
+#endif
+constexpr u32 RS_CUR_STRIDE_WORDS = RS_CUR_STRIDE;
+constexpr int RS_TICKETS = 1;  // ticket counters per pass
 // The front end of a sort in one launch (blockIdx.x = pass): digit counts (summed over the producer's copies, or already
 // in `hist`), their exclusive prefix = the bins' bases, the pass's tile ticket back to zero and -- optionally -- the
 // scalars the sort's kernels report into reset to `sc_init`.
 __global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
                                                                 u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
-                                                                DevScalars sc_init, int set_sc) {
+                                                                DevScalars sc_init, int set_sc, u32* __restrict__ cursors = nullptr) {
     __shared__ u64 s_wave[RS_BINS / 64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     const size_t k = (size_t)blockIdx.x * RS_BINS + threadIdx.x;
@@ -573,8 +578,14 @@ __global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __res
     u64 base = 0;
     for (int q = 0; q < w; ++q) base += s_wave[q];
     bin_base[k] = base + incl - v;
+    // radix_claim_kernel (first pass): the bins' line and fragment cursors start from zero
+    if (cursors && blockIdx.x == 0) {
+        const u32 slot = (threadIdx.x >> 4) * RS_CUR_STRIDE_WORDS + (threadIdx.x & 15u);
+        cursors[slot] = 0u;
+        cursors[16 * RS_CUR_STRIDE_WORDS + slot] = 0u;
+    }
     if (threadIdx.x == 0) {
-        counters[blockIdx.x] = 0;
+        for (int j = 0; j < RS_TICKETS; ++j) counters[blockIdx.x * RS_TICKETS + j] = 0;
         if (set_sc && blockIdx.x == 0) *sc = sc_init;
     }
 }
@@ -880,6 +891,357 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
                     vals_out[g] = v;
                 }
             }
+        }
+    }
+}
+
+// =================================================================================================
+// first radix pass with line-aligned stores (radix_claim_kernel)
+//
+// What bounds a radix pass on this part is the SHAPE of its stores (tools/micro/scatter_bw.hip, MI355X): runs of whole,
+// aligned 128-byte lines scattered at random are written at 5.3 TB/s (5.2 TB/s beside a read stream of the same volume) --
+// the same runs shifted by 8 bytes at 2.0 TB/s (256-byte runs) to 3.1 TB/s (1 KB runs): every run then starts and ends
+// with a partial line.  A one-sweep tile leaves 256 runs of ~32 records at whatever offset the previous tile's run ended;
+// about half of all records sit in a partial line.
+//
+// The FIRST pass of a sort that a finishing kernel completes has no order to preserve among records of equal digit --
+// neither inside a tile nor across tiles.  So:
+//   * no chain at all: a tile CLAIMS its share of every bin from the bin's cursor with one returning atomic (16 cursors
+//     per 64-byte line, the lines a few KB apart so that they spread over memory channels);
+//   * it claims and writes WHOLE, ALIGNED LINES only (16 records): workgroups are persistent (one per CU, 1024 threads,
+//     static tile assignment) and carry the records that do not fill a line -- at most 15 per bin -- in LDS to their next
+//     tile.  Per bin the aligned interior of its output range is handed out line by line, upwards; what the workgroups
+//     still carry at the end is claimed record by record from a second cursor that fills the ragged head of the range and
+//     then the range from its END downwards -- lines and records add up to the bin's size, so the two fronts meet exactly.
+//     Should the lines claimed for a bin exceed its interior (by at most ONE line over the whole launch), that line's
+//     records are claimed from the second cursor as well;
+//   * the next tile's keys are loaded into the (then dead) key registers as soon as the current tile sits in LDS, the
+//     payload at the top of its tile.
+// The order this pass leaves inside a bin depends on timing; the sort's result does not (the finish orders every tie).
+// =================================================================================================
+#ifndef RS_CUR_STRIDE
+#define RS_CUR_STRIDE 1040  // u32 words between two groups of 16 bin cursors (4160 bytes)
+#endif
+constexpr int RC_THREADS = 1024, RC_ITEMS = 8, RC_TILE = RC_THREADS * RC_ITEMS, RC_WAVES = RC_THREADS / 64;
+constexpr int RC_LINE = 16;                                    // records per 128-byte line of keys
+constexpr int RC_CARRY_MAX = RS_BINS * (RC_LINE - 1);          // records a workgroup can carry between tiles
+constexpr int RC_STAGE = RC_TILE + RC_CARRY_MAX;               // a tile's records + the carried ones
+constexpr int RC_OUT_ITERS = (RC_STAGE + RC_THREADS - 1) / RC_THREADS;
+constexpr size_t SW_CURSOR_WORDS = 16 * (size_t)RS_CUR_STRIDE;  // one set of 256 cursors
+__host__ __device__ __forceinline__ u32 sw_cursor_slot(u32 d) { return (d >> 4) * (u32)RS_CUR_STRIDE + (d & 15u); }
+static_assert(RC_TILE == 8192, "the pass kernels share the tile size (holes, workspace)");
+
+struct ClaimArgs {
+    const u64* keys_in; u64* keys_out;
+    const void* vals_in; void* vals_out;
+    size_t n;               // extent of the input (tiles are cut from it)
+    size_t n_out;           // records that exist (== n without holes)
+    int shift;              // this pass's digit
+    const u64* bin_base;    // [256] exclusive prefix of the digit counts
+    u32* line_cur;          // [sw_cursor_slot] lines claimed per bin (zero at launch)
+    u32* frag_cur;          // [sw_cursor_slot] fragment records claimed per bin (zero at launch)
+    const uint8_t* box_in;
+    const u32* blockfill;
+    u32 n_tiles;
+};
+
+// Bin b's output range [B, E): the aligned interior starts at A and holds I whole lines, handed out upwards from A.  What
+// does not leave in whole lines (a workgroup's final remainders, a line claimed beyond the interior) is claimed record by
+// record: slot q of the bin -> the head fragment [B, A) first, then DOWNWARDS from E - 1.  Lines and records add up to
+// the bin's size, so the two fronts meet exactly (records may end in interior lines no workgroup filled).
+struct BinGeom {
+    u32 B, E, A, I, head;
+};
+__device__ __forceinline__ BinGeom bin_geom(const u64* __restrict__ bin_base, u32 b, u32 n_out, u32 a0) {
+    BinGeom g;
+    g.B = (u32)bin_base[b];
+    g.E = b + 1u < (u32)RS_BINS ? (u32)bin_base[b + 1u] : n_out;
+    g.A = g.B + ((a0 - g.B) & (u32)(RC_LINE - 1));  // first position >= B whose address is line-aligned
+    if (g.A < g.E) { g.I = (g.E - g.A) / RC_LINE; g.head = g.A - g.B; }
+    else { g.A = g.E; g.I = 0; g.head = g.E - g.B; }
+    return g;
+}
+__device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.head ? g.B + q : g.E - 1u - (q - g.head); }
+
+#ifndef SW_EXP
+#define SW_EXP 0  // timing experiments (results are WRONG): 1 no key stores
+#endif
+template <typename V>
+__global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
+    typedef u64 K;
+    constexpr int T = RC_THREADS, ITEMS = RC_ITEMS, TILE = RC_TILE;
+    constexpr bool HAS_VAL = StageBytes<V>::value != 0;
+    static_assert((64 * ITEMS) % HOLE_BLOCK == 0 && TILE % HOLE_BLOCK == 0, "waves must not straddle blocks");
+    constexpr int WAVE_BLOCKS = 64 * ITEMS / (int)HOLE_BLOCK;
+    __shared__ __attribute__((aligned(16))) K s_stage[RC_STAGE];
+    __shared__ __attribute__((aligned(16))) K s_carry[RS_BINS][RC_LINE];
+    __shared__ u32 s_carry_v[HAS_VAL ? RS_BINS : 1][RC_LINE];
+    __shared__ uint2 s_pa_tb[RS_BINS];  // .x: stage slot of a bin's first NEW record when it leaves with a line, .y: ... when it stays (both minus the rank offset)
+    __shared__ int s_pt[RS_BINS];       // new records of rank < s_pt leave with a line, the others stay (tail region of the stage)
+    __shared__ u32 s_cnt[2][RS_BINS];  // a tile's digit counts; double-buffered: the other tile's copy is zeroed meanwhile (no barrier at the top of a tile)
+    __shared__ u32 s_c0[RS_BINS], s_keep[RS_BINS], s_ko[RS_BINS], s_glob[RS_BINS], s_lim[RS_BINS];
+    __shared__ u32 s_ws[RC_WAVES];
+    __shared__ u32 s_over;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const ShiftDigit digit{a.shift};
+    const K* __restrict__ keys_in = a.keys_in;
+    K* __restrict__ keys_out = a.keys_out;
+    const V* __restrict__ vals_in = (const V*)a.vals_in;
+    V* __restrict__ vals_out = (V*)a.vals_out;
+    const size_t n = a.n;
+    const u32 n_out = (u32)a.n_out, n_tiles = a.n_tiles;
+    const u32 wbase = (u32)w * (64 * ITEMS) + (u32)lane;
+    // position p of the output is line-aligned <=> p = a0 (mod 16)
+    const u32 a0 = (u32)(0u - (u32)((size_t)keys_out / sizeof(K))) & (u32)(RC_LINE - 1);
+    // (addresses are formed from copies the optimiser cannot see through: hoisted out of the tile loop as loop invariants,
+    // the per-lane pointers and offsets of every phase cost more registers than the tile's records)
+    auto opaque = [](u32 v) { asm volatile("" : "+v"(v)); return v; };
+
+    // owner threads (one per bin): the bin's aligned interior
+    u32 own_A = 0, own_I = 0;
+    if (tid < RS_BINS) {
+        const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
+        own_A = g.A; own_I = g.I;
+        s_lim[tid] = g.A + g.I * RC_LINE;
+        s_c0[tid] = 0u; s_keep[tid] = 0u; s_cnt[0][tid] = 0u; s_cnt[1][tid] = 0u;
+    }
+    if (tid == 0) s_over = 0u;
+
+    K key[ITEMS];
+    u32 vmask = 0;  // bit r: record r of this lane exists
+    auto fetch = [&](u32 tile) {  // load the keys of a tile (the previous tile's are dead)
+        vmask = 0;
+        if (tile >= n_tiles) return;
+        const u32 wb = opaque(wbase);
+        const size_t base = (size_t)tile * TILE;
+        const u32 tile_n = (u32)((n - base) < (size_t)TILE ? (n - base) : (size_t)TILE);
+        // block-structured input: the fills of the wave's blocks first (wave-uniform, and OLDER than the key loads, so that
+        // waiting for them does not wait for the keys); the keys of a hole are read like any other slot (the slots exist)
+        // and masked out afterwards
+        u32 fill[WAVE_BLOCKS];
+        if (a.blockfill) {
+            const size_t blk0 = (size_t)uniform_u32((u32)((base + (size_t)w * (64 * ITEMS)) / HOLE_BLOCK));
+            const size_t n_blk = (n + HOLE_BLOCK - 1) / HOLE_BLOCK;
+#pragma unroll
+            for (int q = 0; q < WAVE_BLOCKS; ++q) fill[q] = blk0 + q < n_blk ? a.blockfill[blk0 + q] : 0u;
+        }
+        const K* __restrict__ src = keys_in + base + wb;
+        if (tile_n == (u32)TILE) {  // every tile but the last
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) key[r] = src[r * 64];
+            vmask = (1u << ITEMS) - 1u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                const bool valid = wb + (u32)r * 64u < tile_n;
+                vmask |= valid ? (1u << r) : 0u;
+                key[r] = valid ? src[r * 64] : (K)0;
+            }
+        }
+        if (a.blockfill) {
+            const u32 in_block = wb & (HOLE_BLOCK - 1u);  // (wb + r * 64) % HOLE_BLOCK = in_block + (r * 64) % HOLE_BLOCK
+            u32 keep = 0;
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) keep |= (in_block + (u32)((r * 64) % (int)HOLE_BLOCK)) < fill[r * 64 / (int)HOLE_BLOCK] ? (1u << r) : 0u;
+            vmask &= keep;
+        }
+    };
+    u32 tile = (u32)blockIdx.x;
+    fetch(tile);
+    u32 own_keep = 0;  // owner: records of its bin the workgroup carries into the next tile
+    __syncthreads();
+
+    for (u32 it = 0; tile < n_tiles; tile += (u32)gridDim.x, ++it) {
+        const u32 cur_vmask = vmask;
+        const size_t base = (size_t)tile * TILE;
+        u32* const cnt_cur = s_cnt[it & 1u];
+
+        // payload of THIS tile: in flight under the ranking
+        V val[HAS_VAL ? ITEMS : 1];
+        if constexpr (HAS_VAL) {
+            const V* __restrict__ vsrc = vals_in + base + opaque(wbase);
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                if ((cur_vmask >> r) & 1u) val[r] = vsrc[r * 64];
+            }
+            if constexpr (sizeof(V) == 4) {
+                if (a.box_in) {  // pack the box codes into the payload
+                    const uint8_t* __restrict__ bsrc = a.box_in + base + opaque(wbase);
+#pragma unroll
+                    for (int r = 0; r < ITEMS; ++r) {
+                        if ((cur_vmask >> r) & 1u) val[r] |= (V)box_to_packed(bsrc[r * 64]) << BOX_ID_BITS;
+                    }
+                }
+            }
+        }
+
+        // ---- rank: one counter per digit for the whole tile, one returning LDS atomic per record ----------------
+        u32 rk[ITEMS / 2];  // two 16-bit fields each: the record's rank among the tile's records of its digit, later its stage slot
+#pragma unroll
+        for (int q = 0; q < ITEMS / 2; ++q) rk[q] = 0u;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const u32 dg = digit(key[r]);
+            u32 old = 0;
+            if ((cur_vmask >> r) & 1u) old = (u32)__hip_atomic_fetch_add(&cnt_cur[dg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rk[r >> 1] |= old << ((r & 1) * 16);
+        }
+        __syncthreads();
+
+        // ---- per bin: carried + new records -> whole lines that leave now (claimed from the bin's cursor) + the rest ----
+        u32 c0 = 0, nl = 0, keep = 0, l0 = 0, packed = 0;
+        if (tid < RS_BINS) {
+            c0 = own_keep;  // what the previous tile left of this bin
+            s_c0[tid] = c0;
+            const u32 c = c0 + cnt_cur[tid];
+            s_cnt[(it & 1u) ^ 1u][tid] = 0u;  // the next tile's counters (last touched a whole tile ago)
+            nl = c / RC_LINE; keep = c % RC_LINE;
+            packed = (nl << 16) | keep;
+            if (nl) l0 = atomicAdd(a.line_cur + sw_cursor_slot((u32)tid), nl);  // consumed after the tile sits in LDS
+        }
+        u32 tot;
+        const u32 ex = block_excl_scan_u32<T>(packed, s_ws, tot);
+        const u32 f_total = (tot >> 16) * RC_LINE;  // records leaving with this tile
+        u32 foff = 0;
+        if (tid < RS_BINS) {
+            foff = (ex >> 16) * RC_LINE;
+            const u32 koff = ex & 0xFFFFu;
+            s_pa_tb[tid] = make_uint2(foff + c0, f_total + koff + c0 - nl * RC_LINE);
+            s_pt[tid] = (int)(nl * RC_LINE) - (int)c0;
+            s_keep[tid] = keep; s_ko[tid] = koff;
+            own_keep = keep;
+        }
+        __syncthreads();
+
+        // ---- stage: [lines of bin 0 | lines of bin 1 | ... | rest of bin 0 | rest of bin 1 | ...] ----------------------
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if ((cur_vmask >> r) & 1u) {
+                const u32 dg = digit(key[r]);
+                const u32 rank = (rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+                const uint2 pt2 = s_pa_tb[dg];
+                const u32 pos = ((int)rank < s_pt[dg] ? pt2.x : pt2.y) + rank;
+                rk[r >> 1] = (rk[r >> 1] & ~(0xFFFFu << ((r & 1) * 16))) | (pos << ((r & 1) * 16));
+                s_stage[pos] = key[r];
+            }
+        }
+        // the records carried in: in front of their bin's new ones (oldest first)
+#pragma unroll
+        for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+            const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE, cb = s_c0[b];
+            if (i < cb) {
+                const uint2 pt2 = s_pa_tb[b];
+                const u32 dest = (s_pt[b] + (int)cb >= RC_LINE ? pt2.x : pt2.y) - cb + i;
+                s_stage[dest] = s_carry[b][i];
+            }
+        }
+        // the next tile's keys: in flight under this tile's stores
+        fetch(tile + (u32)gridDim.x);
+
+        // ---- the claimed lines' positions --------------------------------------------------------------------------
+        bool over = false;  // owner: its claim reaches beyond the bin's interior (at most one line per bin and launch)
+        if (tid < RS_BINS) {
+            s_glob[tid] = own_A + l0 * RC_LINE - foff;
+            over = nl != 0 && l0 + nl > own_I;
+            if (over) s_over = 1u;
+        }
+        __syncthreads();
+
+        // ---- stream the lines out: 16 consecutive threads write one aligned 128-byte line ----------------------------
+        const bool any_over = s_over != 0u;
+        u32 odg[HAS_VAL ? (RC_OUT_ITERS + 3) / 4 : 1];  // the written records' digits, one byte each (payload phase)
+        const u32 otid = opaque((u32)tid);
+#pragma unroll
+        for (int k = 0; k < RC_OUT_ITERS; ++k) {
+            const u32 li = (u32)k * T + otid;
+            if constexpr (HAS_VAL) { if (k % 4 == 0) odg[k / 4] = 0u; }
+            if (li < f_total) {
+                const K kk = s_stage[li];
+                const u32 dg = digit(kk);
+                if constexpr (HAS_VAL) odg[k / 4] |= dg << (8 * (k % 4));
+                const u32 g = s_glob[dg] + li;
+                if (!any_over || g < s_lim[dg]) {
+                    if (SW_EXP != 1) keys_out[g] = kk;
+                }
+            }
+            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // a line beyond the interior: its records fill fragment slots instead (rare: the owner moves them alone)
+        u32 over_q = 0, over_at = 0;
+        if (over) {
+            const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
+            const u32 first = l0 > own_I ? l0 : own_I;  // first line index beyond the interior
+            over_at = foff + (first - l0) * RC_LINE;
+            const u32 cnt = (l0 + nl - first) * RC_LINE;
+            over_q = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), cnt);
+            for (u32 i = 0; i < cnt; ++i) keys_out[frag_pos(g, over_q + i)] = s_stage[over_at + i];
+        }
+        // what stays: back into the carry slots
+#pragma unroll
+        for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+            const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE;
+            if (i < s_keep[b]) s_carry[b][i] = s_stage[f_total + s_ko[b] + i];
+        }
+        if constexpr (HAS_VAL) {
+            __syncthreads();  // everyone is done with the keys in the stage
+            V* stage_v = reinterpret_cast<V*>(s_stage);
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                if ((cur_vmask >> r) & 1u) stage_v[(rk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu] = val[r];
+            }
+#pragma unroll
+            for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+                const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE, cb = s_c0[b];
+                if (i < cb) {
+                    const uint2 pt2 = s_pa_tb[b];
+                    const u32 dest = (s_pt[b] + (int)cb >= RC_LINE ? pt2.x : pt2.y) - cb + i;
+                    stage_v[dest] = (V)s_carry_v[b][i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RC_OUT_ITERS; ++k) {
+                const u32 li = (u32)k * T + otid;
+                if (li < f_total) {
+                    const u32 dg = (odg[k / 4] >> (8 * (k % 4))) & 0xFFu;
+                    const u32 g = s_glob[dg] + li;
+                    if (!any_over || g < s_lim[dg]) vals_out[g] = stage_v[li];
+                }
+                if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (over) {
+                const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
+                const u32 first = l0 > own_I ? l0 : own_I;
+                const u32 cnt = (l0 + nl - first) * RC_LINE;
+                for (u32 i = 0; i < cnt; ++i) vals_out[frag_pos(g, over_q + i)] = stage_v[over_at + i];
+            }
+#pragma unroll
+            for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+                const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE;
+                if (i < s_keep[b]) s_carry_v[b][i] = (u32)stage_v[f_total + s_ko[b] + i];
+            }
+        }
+        if (any_over) {  // (uniform) the flag is per tile
+            __syncthreads();
+            if (tid == 0) s_over = 0u;
+        }
+    }
+
+    // ---- what the workgroup still carries: into the fragment slots of its bin -------------------------------------------
+    __syncthreads();
+    if (tid < RS_BINS) {
+        s_keep[tid] = own_keep;
+        if (own_keep) s_glob[tid] = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), own_keep);
+    }
+    __syncthreads();
+    for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+        const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE;
+        if (i < s_keep[b]) {
+            const BinGeom g = bin_geom(a.bin_base, b, n_out, a0);
+            const u32 pos = frag_pos(g, s_glob[b] + i);
+            keys_out[pos] = s_carry[b][i];
+            if constexpr (HAS_VAL) vals_out[pos] = (V)s_carry_v[b][i];
         }
     }
 }
@@ -2593,7 +2955,8 @@ RadixPlan make_radix_plan(unsigned long long key_varying, int use_ids, unsigned 
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// tile geometry: 512 threads x 16 records (8192-record tiles, 2 workgroups per CU)
+
+// tile geometry of radix_onesweep_kernel: 512 threads x 16 records (8192-record tiles, 2 workgroups per CU)
 #ifndef RS_THREADS_MACRO
 #define RS_THREADS_MACRO 512
 #endif
@@ -2604,14 +2967,27 @@ constexpr int RS_THREADS_DEF = RS_THREADS_MACRO, RS_ITEMS_DEF = RS_ITEMS_MACRO;
 static size_t rs_tile_size() { return (size_t)RS_THREADS_DEF * RS_ITEMS_DEF; }
 static size_t rs_num_tiles(size_t n) { return (n + rs_tile_size() - 1) / rs_tile_size(); }
 
+// Workspace of one sort: a header of FIXED size (laid out for RS_MAX_PASSES passes whatever the plan, so that the region
+// behind it only ever holds launch-tagged status words, even when sorts of different pass counts share the workspace):
+// [hist: 12 x 256 u64][bin_base: 12 x 256 u64][tile tickets: 12 u32, padded][line cursors | fragment cursors of the
+// claiming first pass] -- then [status: passes x tiles x 256 u64]
+static size_t rs_header_bytes() {
+    return 2 * (size_t)RS_MAX_PASSES * RS_BINS * sizeof(u64) + align_up((size_t)RS_MAX_PASSES * RS_TICKETS * sizeof(u32), 256) +
+           align_up(2 * SW_CURSOR_WORDS * sizeof(u32), 256);
+}
 size_t radix_workspace_bytes(size_t n, int n_passes) {
     const size_t np = (size_t)(n_passes > 0 ? n_passes : 1);
-    size_t b = 0;
-    b += np * RS_BINS * sizeof(u64);                      // hist
-    b += np * RS_BINS * sizeof(u64);                      // bin_base
-    b += align_up(np * sizeof(u32), 256);                 // tile counters
-    b += np * rs_num_tiles(n) * RS_BINS * sizeof(u64);    // status
-    return align_up(b, 256);
+    return align_up(rs_header_bytes() + np * rs_num_tiles(n) * RS_BINS * sizeof(u64), 256);
+}
+
+// the claiming first pass (radix_claim_kernel): one persistent workgroup per CU
+template <typename V>
+static hipError_t launch_claim(const ClaimArgs& a, hipStream_t stream) {
+    static_assert(RC_TILE == RS_THREADS_DEF * RS_ITEMS_DEF, "the pass kernels share the tile size (holes, workspace)");
+    static const unsigned resident = resident_blocks(radix_claim_kernel<V>, RC_THREADS);
+    const unsigned grid = a.n_tiles < resident ? a.n_tiles : resident;
+    radix_claim_kernel<V><<<grid, RC_THREADS, 0, stream>>>(a);
+    return hipGetLastError();
 }
 
 template <typename K, typename V, typename DigitFn>
@@ -2653,12 +3029,19 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     if (extent >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (radix_workspace_bytes(extent, np) > workspace_bytes) return hipErrorInvalidValue;
     unsigned char* ws = (unsigned char*)workspace;
+    if (np > RS_MAX_PASSES) return hipErrorInvalidValue;
     u64* hist = (u64*)ws;
-    u64* bin_base = hist + (size_t)np * RS_BINS;
-    u32* counters = (u32*)(bin_base + (size_t)np * RS_BINS);
-    u64* status = (u64*)((unsigned char*)counters + align_up((size_t)np * sizeof(u32), 256));
+    u64* bin_base = hist + (size_t)RS_MAX_PASSES * RS_BINS;
+    u32* counters = (u32*)(bin_base + (size_t)RS_MAX_PASSES * RS_BINS);
+    u32* cursors = (u32*)((unsigned char*)counters + align_up((size_t)RS_MAX_PASSES * RS_TICKETS * sizeof(u32), 256));
+    u64* status = (u64*)(ws + rs_header_bytes());
     const size_t tiles = rs_num_tiles(extent);
     hipError_t e;
+    // the first pass of a sort that a finishing kernel completes: radix_claim_kernel (line-aligned stores, no chain) when the
+    // input is large enough for its persistent workgroups to amortise their final partial lines; BP_RADIX_CLAIM=0: off
+    static const bool claim_off = getenv("BP_RADIX_CLAIM") != nullptr && atoi(getenv("BP_RADIX_CLAIM")) == 0;
+    static const size_t claim_min_tiles = getenv("BP_RADIX_CLAIM_MIN_TILES") ? (size_t)atoll(getenv("BP_RADIX_CLAIM_MIN_TILES")) : 256;
+    const bool claim = !claim_off && unstable_first && !plan.from_val[0] && tiles >= claim_min_tiles && !(np == 1 && box_out);
 
     if (mark) mark(mark_ctx, class_hist);
     // status words: tagged per launch when the caller keeps an epoch counter for this workspace (epoch_io; the words of
@@ -2679,7 +3062,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     DevScalars init = {};
     if (sc_init) init = *sc_init;
     if (ready_hist) {  // the producer of the records already counted the digits of this plan
-        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0);
+        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
+                                                         claim ? cursors : nullptr);
     } else {
         if (epoch_io) {  // the counting kernel adds into the histogram
             e = hipMemsetAsync(hist, 0, (size_t)np * RS_BINS * sizeof(u64), stream);
@@ -2688,7 +3072,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
             (const u64*)keys0, vals0, extent, plan, hist, blockfill);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>(nullptr, 0, hist, bin_base, counters, sc, init, sc_init ? 1 : 0);
+        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>(nullptr, 0, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
+                                                         claim ? cursors : nullptr);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (mark) mark(mark_ctx, -1);
@@ -2705,8 +3090,19 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         if (mark) mark(mark_ctx, class_sort);  // one timed region per pass = per kernel launch
         const u64* bb = bin_base + (size_t)p * RS_BINS;
         u64* st = status + (size_t)p * tiles * RS_BINS;
-        u32* tc = counters + p;
-        if (!vals0) {
+        u32* tc = counters + (size_t)p * RS_TICKETS;
+        if (claim && p == 0) {
+            const bool holes = blockfill != nullptr;
+            ClaimArgs a;
+            a.keys_in = kb[cur]; a.keys_out = kb[cur ^ 1];
+            a.vals_in = vals0 ? vb[cur] : nullptr; a.vals_out = vals0 ? vb[cur ^ 1] : nullptr;
+            a.n = holes ? extent : n; a.n_out = n;
+            a.shift = plan.shift[p]; a.bin_base = bb;
+            a.line_cur = cursors; a.frag_cur = cursors + SW_CURSOR_WORDS;
+            a.box_in = box_in; a.blockfill = blockfill;
+            a.n_tiles = (u32)rs_num_tiles(a.n);
+            e = vals0 ? launch_claim<u32>(a, stream) : launch_claim<NoVal>(a, stream);
+        } else if (!vals0) {
             const bool holes = blockfill && p == 0;  // only the first pass sees the block-structured input
             e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, holes ? extent : n,
                                             ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream, nullptr, nullptr,

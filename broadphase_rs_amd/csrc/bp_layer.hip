@@ -780,6 +780,9 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
         L->cur = L->sort_pend.src;
         L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
         ++L->epoch;
+        // the first radix pass placed records of equal digit in no particular order: equal keys are no longer in id order,
+        // so the full-width sort must order by id as well
+        L->order_ok = false;
         BP_TRY(sort_tree_full(L, L->sort_pend.ride));
         L->ids_packed = false;
         BP_TRY(ensure_unpacked(L));
@@ -926,6 +929,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 // a group of equal key prefix is longer than the LDS window (heavily clustered input):
                 // finish with the full-width sort, starting from the partially sorted (still packed) data
                 L->cur = src;
+                L->order_ok = false;  // the unstable first pass has shuffled equal keys: sort by id as well
                 BP_TRY(sort_tree_full(L, ride));
             } else {
                 L->cur = dst;
