@@ -3039,8 +3039,11 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     hipError_t e;
     // the first pass of a sort that a finishing kernel completes: radix_claim_kernel (line-aligned stores, no chain) when the
     // input is large enough for its persistent workgroups to amortise their final partial lines; BP_RADIX_CLAIM=0: off
-    static const bool claim_off = getenv("BP_RADIX_CLAIM") != nullptr && atoi(getenv("BP_RADIX_CLAIM")) == 0;
-    static const size_t claim_min_tiles = getenv("BP_RADIX_CLAIM_MIN_TILES") ? (size_t)atoll(getenv("BP_RADIX_CLAIM_MIN_TILES")) : 256;
+    // (the two switches are read per sort, so that the tests can force the kernel onto small inputs)
+    const char* const claim_env = getenv("BP_RADIX_CLAIM");
+    const char* const claim_min_env = getenv("BP_RADIX_CLAIM_MIN_TILES");
+    const bool claim_off = claim_env != nullptr && atoi(claim_env) == 0;
+    const size_t claim_min_tiles = claim_min_env ? (size_t)atoll(claim_min_env) : 256;
     const bool claim = !claim_off && unstable_first && !plan.from_val[0] && tiles >= claim_min_tiles && !(np == 1 && box_out);
 
     if (mark) mark(mark_ctx, class_hist);

@@ -637,6 +637,46 @@ def test_grouped_tree_sort_over_frames(kind):
         assert passes[1] < passes[0] and passes[2] == passes[1], passes     # part of its square empty: groups too uneven)
 
 
+@pytest.mark.parametrize("kind", [2, 1, 0])
+def test_claiming_first_radix_pass_on_small_and_uneven_inputs(monkeypatch, kind):
+    """the first radix pass of the hot-path sorts (radix_claim_kernel: whole aligned lines claimed from per-bin cursors,
+    partial lines carried in LDS, ragged range ends filled record by record) normally serves inputs of >= 2 M records;
+    forced onto small ones, every frame's tree and pair list must still equal the oracle's -- uniform frames (grouped
+    finishes), clustered frames (nearly all records of a tile in a few bins: long claims, lines beyond a bin's interior),
+    frames arriving in two extends and sparse ids (other digit plans)"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    n = 70000
+    dim = KINDS[kind].dim
+
+    def cut(scene):
+        sysb, b, ids = scene
+        if dim == 2:
+            return np.ascontiguousarray(sysb[:, :2]), np.ascontiguousarray(b[:, [0, 1, 3, 4]]), ids
+        return scene
+    uniform = make_scene(kind, n, seed=51)
+    sparse = (uniform[0], uniform[1], (uniform[2].astype(np.uint64) * np.uint64(17)).astype(np.uint32))
+    frames = [uniform, uniform, cut(_clustered_scene(n, 5000, 53, 0.004)), uniform] + \
+             ([cut(_clustered_scene(n, 30000, 54, 0.0005))] if kind == 2 else []) + [sparse, make_scene(kind, 33333, seed=55), uniform]
+    gpu, ref = both(kind, 0)
+    for f, (sysb, bounds, ids) in enumerate(frames):
+        gpu.clear(); ref.clear()
+        if f % 3 == 1:                                     # the frame arrives in two extends
+            h = len(ids) // 3
+            gpu.extend(sysb, bounds[:h], ids[:h]); ref.extend(sysb, bounds[:h], ids[:h])
+            gpu.extend(sysb, bounds[h:], ids[h:]); ref.extend(sysb, bounds[h:], ids[h:])
+        else:
+            gpu.extend(sysb, bounds, ids); ref.extend(sysb, bounds, ids)
+        if f % 2 == 0:
+            gpu.par_sort(); ref.sort()
+            assert_tree_equal(gpu, ref, "claiming pass, frame %d" % f)
+        assert_pairs_equal(np.array(gpu.par_scan()), ref.scan(), "claiming pass, scan of frame %d" % f)
+    # the same with the kernel switched off: the one-tile-per-workgroup pass everywhere
+    monkeypatch.setenv("BP_RADIX_CLAIM", "0")
+    gpu.clear(); ref.clear()
+    gpu.extend(*uniform); ref.extend(*uniform)
+    assert_pairs_equal(np.array(gpu.par_scan()), ref.scan(), "claiming pass switched off")
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list

@@ -18,11 +18,13 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-__global__ void fill_pairs(u64* k, size_t n, u32 ids, u64 seed) {
+__global__ void fill_pairs(u64* k, size_t n, u32 ids, u64 seed, u32 skew) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         u64 x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
         x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; x *= 0x94D049BB133111EBull; x ^= x >> 29;
-        const u32 a = (u32)(x % ids), b = (u32)((x >> 32) % ids);
+        u32 a = (u32)(x % ids);
+        const u32 b = (u32)((x >> 32) % ids);
+        if (skew && (x >> 60) != 0) a = (a & 0xFFu) | (skew << 8);  // 15 of 16 records share the sorted bits: one bin takes almost everything
         k[i] = ((u64)a << 32) | b;
     }
 }
@@ -59,8 +61,13 @@ static void mark(void* ctx, int c) {
 
 static void run(const char* name, size_t n, bool with_vals, u32 ids, int shift0, int reps, hipStream_t s) {
     u64 *k0, *k1, *chk; u32 *v0 = nullptr, *v1 = nullptr;
-    CK(hipMalloc(&k0, n * 8)); CK(hipMalloc(&k1, n * 8)); CK(hipMalloc(&chk, 64));
-    if (with_vals) { CK(hipMalloc(&v0, n * 4)); CK(hipMalloc(&v1, n * 4)); }
+    // BP_BENCH_SHIFT=k: the output buffers start k records into their allocation (line alignment of the claiming pass)
+    const size_t shift = getenv("BP_BENCH_SHIFT") ? (size_t)atoi(getenv("BP_BENCH_SHIFT")) : 0;
+    const u32 skew = getenv("BP_BENCH_SKEW") ? (u32)atoi(getenv("BP_BENCH_SKEW")) : 0u;
+    CK(hipMalloc(&k0, (n + 64) * 8)); CK(hipMalloc(&k1, (n + 64) * 8)); CK(hipMalloc(&chk, 64));
+    if (with_vals) { CK(hipMalloc(&v0, (n + 64) * 4)); CK(hipMalloc(&v1, (n + 64) * 4)); }
+    u64* const k0_alloc = k0; u64* const k1_alloc = k1; u32* const v0_alloc = v0; u32* const v1_alloc = v1;
+    k1 += shift; if (with_vals) v1 += shift;
     bp::RadixPlan plan; memset(&plan, 0, sizeof plan);
     plan.n_passes = 2; plan.shift[0] = shift0; plan.shift[1] = shift0 + 8;
     const size_t wsb = bp::radix_workspace_bytes(n, 2);
@@ -70,7 +77,7 @@ static void run(const char* name, size_t n, bool with_vals, u32 ids, int shift0,
     const bool verify = getenv("BP_BENCH_NOVERIFY") == nullptr;
     double tot[3] = {0, 0, 0};
     for (int r = 0; r < reps + 1; ++r) {
-        fill_pairs<<<2048, 256, 0, s>>>(k0, n, ids, 12345 + r);
+        fill_pairs<<<2048, 256, 0, s>>>(k0, n, ids, 12345 + r, skew);
         if (with_vals) fill_ids<<<2048, 256, 0, s>>>(v0, n);
         u64 before[4] = {0, 0, 0, 0}, after[4] = {0, 0, 0, 0};
         if (verify) {
@@ -106,8 +113,8 @@ static void run(const char* name, size_t n, bool with_vals, u32 ids, int shift0,
     const double bytes = (double)n * (with_vals ? 24.0 : 16.0);
     printf("%-6s n %zu  prepare %.1f us  pass0 %.1f us (%.2f TB/s)  pass1 %.1f us (%.2f TB/s)%s\n", name, n, tot[0] / reps * 1e3, tot[1] / reps * 1e3,
            bytes / (tot[1] / reps * 1e-3) / 1e12, tot[2] / reps * 1e3, bytes / (tot[2] / reps * 1e-3) / 1e12, verify ? "  verified" : "  NOT verified");
-    CK(hipFree(k0)); CK(hipFree(k1)); CK(hipFree(chk)); CK(hipFree(ws)); CK(hipFree(sc));
-    if (with_vals) { CK(hipFree(v0)); CK(hipFree(v1)); }
+    CK(hipFree(k0_alloc)); CK(hipFree(k1_alloc)); CK(hipFree(chk)); CK(hipFree(ws)); CK(hipFree(sc));
+    if (with_vals) { CK(hipFree(v0_alloc)); CK(hipFree(v1_alloc)); }
 }
 
 int main(int argc, char** argv) {
