@@ -81,10 +81,13 @@ constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit 
 inline size_t enc_blocks(size_t n) { return (n + (size_t)ENC_THREADS * ENC_ROUNDS - 1) / ((size_t)ENC_THREADS * ENC_ROUNDS); }
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
-                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, uint32_t* counts,
+                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, void* recs,
                                unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream);
+// recs: ENC_REC_BYTES per object -- what the emit pass needs of it (first cell per axis, depth, cells per axis), so that
+// launch_encode_emit neither reads the bounds again nor repeats the quantisation
+constexpr size_t ENC_REC_BYTES = 16;
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
-                              uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
+                              uint32_t min_depth, const void* recs, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
                               unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0, DevScalars* sc_guard = nullptr,

@@ -125,11 +125,21 @@ __device__ __forceinline__ void range_or_and(u32 lo, u32 n, u32& o, u32& a) {
     a = lo & ~low;
 }
 
+// Per-object record the count pass leaves for the emit pass (which then neither reads the bounds again nor repeats the
+// divisions): x, y, z = first cell per axis; w = depth | cells on axis 0 / 1 / 2 (1 or 2) at bits 8 / 10 / 12 | ENC_REC_OK.
+// ENC_REC_SLOW instead: more than 2 cells on some axis (min_depth forced it) -- x = entry count, the emit pass recomputes
+// the object from its bounds.  w == 0: no entries (outside the system bounds, or refused as too large).
+enum : u32 { ENC_REC_OK = 1u << 16, ENC_REC_SLOW = 1u << 17 };
+__device__ __forceinline__ u32 enc_rec_count(const uint4& r) {
+    if (r.w & ENC_REC_OK) return ((r.w >> 8) & 3u) * ((r.w >> 10) & 3u) * ((r.w >> 12) & 3u);
+    return (r.w & ENC_REC_SLOW) ? r.x : 0u;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                   const u32* __restrict__ ids, size_t n,
                                                                   u32 min_depth, int have_prev, u32 prev_id,
-                                                                  u32* __restrict__ counts, u64* __restrict__ block_sums,
+                                                                  uint4* __restrict__ recs, u64* __restrict__ block_sums,
                                                                   BlockAux* __restrict__ aux, DevScalars* sc) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
     __shared__ u32 s_sum[ENC_THREADS / 64], s_dm[ENC_THREADS / 64], s_fl[ENC_THREADS / 64], s_er[ENC_THREADS / 64],
@@ -138,7 +148,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
     __shared__ u64 s_kor[ENC_THREADS / 64], s_kand[ENC_THREADS / 64];
     // ENC_ROUNDS blocks of ENC_THREADS objects per workgroup: a quarter of the partials for scan_block_sums to fold
     u32 cnt = 0, dmask = 0, flags = 0, err = 0, inv = 0, ior = 0, iand = 0xFFFFFFFFu, imax = 0, imin = 0xFFFFFFFFu;
-    u64 kor = 0, kand = ~0ull;
+    // OR / AND of every index value of the workgroup's objects, without enumerating cells and without spreading per object:
+    // the Morton spread is bitwise (it distributes over OR and AND, and the axes' lanes are disjoint), so the coordinates
+    // are accumulated per axis -- as top-AXIS_BITS coordinates, whatever the object's depth -- and spread once at the end
+    u32 co[3] = {0, 0, 0}, ca[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, dor = 0, dand = 0xFFFFFFFFu;
     for (int round = 0; round < ENC_ROUNDS; ++round) {
         const size_t i = ((size_t)blockIdx.x * ENC_ROUNDS + round) * ENC_THREADS + threadIdx.x;
         if (i >= n) break;
@@ -160,26 +173,38 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
         if (!c.valid) inv += 1;
         const u32 c_cnt = c.count;
         cnt += c_cnt;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
         if (c_cnt > 0) {
-            if (c.n[0] > 2 || c.n[1] > 2 || c.n[2] > 2) flags |= EXT_BOX_UNKNOWN;
+            const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
+            if (!boxy) flags |= EXT_BOX_UNKNOWN;
             dmask |= 1u << c.depth;
             ior |= id;
             iand &= id;
-            // OR / AND over this object's index values without enumerating its cells
-            u32 o[3] = {0, 0, 0}, a[3] = {0, 0, 0};
-#pragma unroll
-            for (u32 ax = 0; ax < DIM; ++ax) range_or_and(c.lo[ax], c.n[ax], o[ax], a[ax]);
             const u32 up = AB - c.depth;
-            u64 mo = spread_bits<DIM>((u64)o[0] << up) | (spread_bits<DIM>((u64)o[1] << up) << 1);
-            u64 ma = spread_bits<DIM>((u64)a[0] << up) | (spread_bits<DIM>((u64)a[1] << up) << 1);
-            if (DIM == 3) {
-                mo |= spread_bits<DIM>((u64)o[2] << up) << 2;
-                ma |= spread_bits<DIM>((u64)a[2] << up) << 2;
+#pragma unroll
+            for (u32 ax = 0; ax < DIM; ++ax) {
+                u32 o, a;
+                range_or_and(c.lo[ax], c.n[ax], o, a);
+                co[ax] |= o << up;
+                ca[ax] &= a << up;
             }
-            kor |= (mo << DB) | c.depth;
-            kand &= (ma << DB) | c.depth;
+            dor |= c.depth;
+            dand &= c.depth;
+            rec = boxy ? make_uint4(c.lo[0], c.lo[1], c.lo[2], c.depth | (c.n[0] << 8) | (c.n[1] << 10) | (c.n[2] << 12) | ENC_REC_OK)
+                       : make_uint4(c_cnt, 0u, 0u, ENC_REC_SLOW);
         }
-        counts[i] = c_cnt;
+        recs[i] = rec;
+    }
+    u64 kor = 0, kand = ~0ull;
+    if (dmask != 0) {  // this thread saw at least one entry
+        u64 mo = spread_bits<DIM>((u64)co[0]) | (spread_bits<DIM>((u64)co[1]) << 1);
+        u64 ma = spread_bits<DIM>((u64)ca[0]) | (spread_bits<DIM>((u64)ca[1]) << 1);
+        if (DIM == 3) {
+            mo |= spread_bits<DIM>((u64)co[2]) << 2;
+            ma |= spread_bits<DIM>((u64)ca[2]) << 2;
+        }
+        kor = (mo << DB) | dor;
+        kand = (ma << DB) | dand;
     }
     // workgroup reduction -> one BlockAux + one block sum per workgroup (no atomics)
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
@@ -221,10 +246,17 @@ struct DigitCount {
     u32 cell_depth, n_cells, depth_mask;
 };
 
+// spread_bits<DIM>((c + 1) << up) from m = spread_bits<DIM>(c << up): an addition in the dilated number (the bits between
+// the lane's bits are filled with ones so that the carry runs through them)
+template <int DIM> __device__ __forceinline__ u64 dilated_next(u64 m, u32 up) {
+    constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
+    return ((m | ~LANE) + (1ull << (DIM * up))) & LANE;
+}
+
 template <int KIND, bool CELLS>
 __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
-                                                                 const u32* __restrict__ counts,
+                                                                 const uint4* __restrict__ recs,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                  uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
@@ -233,7 +265,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     // no box byte is written: the first pass of the tree sort then has no byte stream to gather
     // sc_guard / capacity (launch without a host round trip after the count pass): sc_guard->total is the entry total the
     // block-sum scan left on the device; beyond `capacity` entries nothing is written and KERR_ENCODE_OVERFLOW is set
-    constexpr u32 DIM = KT<KIND>::DIM;
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
     if (sc_guard && sc_guard->total > capacity) {  // grid-uniform
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc_guard->err, (u32)KERR_ENCODE_OVERFLOW);
         return;
@@ -267,7 +299,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
         if (blk * ENC_THREADS >= n) break;  // workgroup-uniform
         const size_t i = blk * ENC_THREADS + threadIdx.x;
-        const u32 cnt = i < n ? counts[i] : 0u;
+        const uint4 rec = i < n ? recs[i] : make_uint4(0u, 0u, 0u, 0u);
+        const u32 cnt = enc_rec_count(rec);
         u32 total;
         const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);
         const size_t this_base = round_base;
@@ -285,22 +318,41 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             }
         };
         if (cnt != 0) {
-            const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
             const u32 id = ids[i];
             u32 local = excl;
-            if (c.depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
-                put(local, 0ull, id, 0u);  // box code 0 packs to 0
-                count_digits(0ull);
-            } else {
-                const bool boxy = c.n[0] <= 2 && c.n[1] <= 2 && c.n[2] <= 2;
-                // z outer, y, x inner: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
+            if (rec.w & ENC_REC_OK) {
+                const u32 depth = rec.w & 0xFFu;
+                if (depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
+                    put(local, 0ull, id, 0u);  // box code 0 packs to 0
+                    count_digits(0ull);
+                } else {
+                    // at most two cells per axis: both Morton lanes of every axis once per object (the second from the first by
+                    // a dilated increment), an entry is then two ORs; cells in z outer, y, x inner order: src/geom.rs:271-297
+                    // (2-D: y outer, x inner: src/geom.rs:213-231)
+                    const u32 up = AB - depth;
+                    const u32 s0 = ((rec.w >> 8) & 3u) - 1u, s1 = ((rec.w >> 10) & 3u) - 1u, s2 = DIM == 3 ? ((rec.w >> 12) & 3u) - 1u : 0u;
+                    u64 mx[2], my[2], mz[2];
+                    mx[0] = spread_bits<DIM>((u64)rec.x << up); mx[1] = dilated_next<DIM>(mx[0], up);
+                    my[0] = spread_bits<DIM>((u64)rec.y << up) << 1; my[1] = dilated_next<DIM>(my[0] >> 1, up) << 1;
+                    mz[0] = 0; mz[1] = 0;
+                    if (DIM == 3) { mz[0] = spread_bits<DIM>((u64)rec.z << up) << 2; mz[1] = dilated_next<DIM>(mz[0] >> 2, up) << 2; }
+                    for (u32 e = 0; e < cnt; ++e) {
+                        const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
+                        const u64 key = (((x ? mx[1] : mx[0]) | (y ? my[1] : my[0]) | (z ? mz[1] : mz[0])) << DB) | (u64)depth;
+                        const u32 tx = s0 ? 1u + x : 0u, ty = s1 ? 1u + y : 0u, tz = s2 ? 1u + z : 0u;
+                        const u32 code = tx | (ty << 2) | (tz << 4);
+                        put(local, key, pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id, code);
+                        count_digits(key);
+                        ++local;
+                    }
+                }
+            } else {  // more than two cells on some axis (min_depth forced it): from the bounds, cell by cell
+                const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
                 for (u32 z = 0; z < c.n[2]; ++z)
                     for (u32 y = 0; y < c.n[1]; ++y)
                         for (u32 x = 0; x < c.n[0]; ++x) {
                             const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
-                            const u32 tx = c.n[0] == 1 ? 0u : 1u + x, ty = c.n[1] == 1 ? 0u : 1u + y, tz = c.n[2] == 1 ? 0u : 1u + z;
-                            const u32 code = boxy ? (tx | (ty << 2) | (tz << 4)) : (u32)BOX_UNKNOWN;
-                            put(local, key, pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id, code);
+                            put(local, key, pack_box ? (id | (box_to_packed((u32)BOX_UNKNOWN) << BOX_ID_BITS)) : id, (u32)BOX_UNKNOWN);
                             count_digits(key);
                             ++local;
                         }
@@ -2850,17 +2902,17 @@ inline unsigned grid_for(size_t n, int threads, unsigned cap) {
     }
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
-                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, uint32_t* counts,
+                               uint32_t min_depth, int have_prev_id, uint32_t prev_id, void* recs,
                                unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     BP_DISPATCH_KIND(kind, (encode_count_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, have_prev_id,
-                                                                                  prev_id, counts, block_sums, aux, sc)));
+                                                                                  prev_id, (uint4*)recs, block_sums, aux, sc)));
     return hipGetLastError();
 }
 
 hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
-                              uint32_t min_depth, const uint32_t* counts, const unsigned long long* block_offs,
+                              uint32_t min_depth, const void* recs, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
                               uint32_t cell_depth, DevScalars* sc_guard, size_t capacity) {
@@ -2886,10 +2938,10 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
         }
     }
     if (dc.cell_hist) {
-        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
+        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     } else {
-        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, counts,
+        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
                                                                                         block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     }
     return hipGetLastError();

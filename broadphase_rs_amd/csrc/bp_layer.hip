@@ -398,7 +398,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     size_t capacity = std::min(L->keys[L->cur].cap / sizeof(uint64_t), L->ids[L->cur].cap / sizeof(uint32_t));
     if (!pack) capacity = std::min(capacity, L->box[L->cur].cap);
     const size_t nb = enc_blocks(n);
-    BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->counts, n * ENC_REC_BYTES));
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
     BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
     // the digit plan the coming tree sort will most likely take (it verifies: a different plan only costs its own histogram)
@@ -421,7 +421,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     {
         ProfScope ps(L, BP_K_ENCODE);
-        HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, (uint32_t*)L->counts.p,
+        HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, L->counts.p,
                                        (unsigned long long*)L->block_sums.p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
     }
     {
@@ -434,7 +434,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     }
     {
         ProfScope ps(L, BP_K_ENCODE);
-        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
+        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, L->counts.p,
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L), cur_ids(L),
                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p, L->stream, count_digits ? &hist_plan : nullptr,
                                       count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0,
@@ -511,14 +511,14 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
         if (done) return BP_OK;
     }
     const size_t nb = enc_blocks(n);
-    BP_TRY(ensure_dev(L, L->counts, n * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->counts, n * ENC_REC_BYTES));
     BP_TRY(ensure_dev(L, L->block_sums, nb * sizeof(unsigned long long)));
     BP_TRY(ensure_dev(L, L->aux, nb * sizeof(BlockAux)));
     BP_TRY(sc_reset(L));
     {
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, L->have_ids ? 1 : 0, L->max_id,
-                                       (uint32_t*)L->counts.p, (unsigned long long*)L->block_sums.p,
+                                       L->counts.p, (unsigned long long*)L->block_sums.p,
                                        (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
     }
     {
@@ -571,7 +571,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     }
     {
         ProfScope ps(L, BP_K_ENCODE);
-        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, (const uint32_t*)L->counts.p,
+        HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, L->counts.p,
                                       (const unsigned long long*)L->block_sums.p, cur_keys(L) + L->m, cur_ids(L) + L->m,
                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p + L->m, L->stream,
                                       count_digits ? &hist_plan : nullptr,
