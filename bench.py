@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-objects", type=int, default=10_000_000, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the configs[1] (1 M objects) sub-record")
+    ap.add_argument("--no-moving", action="store_true", help="skip the moving-scene sub-record")
+    ap.add_argument("--moving-frames", type=int, default=20)
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
     ap.add_argument("--pair-order", choices=["global", "local"], default="local",
                     help="N > 1: 'local' (default, north_star's design: boundary keys are exchanged, every rank returns the sorted "
@@ -217,6 +219,70 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     return res
 
 
+def moving_frame(torch, base, size, side, frame, seed):
+    """frame `frame` of the moving scene: every box displaced by a seeded jitter of up to +-0.5 of its own size per axis
+    (relative to its rest position, so the density stays the recipe's), kept inside the system bounds"""
+    g = torch.Generator(device=base.device)
+    g.manual_seed(seed * 1000003 + frame)
+    jit = (torch.rand((base.shape[0], 3), generator=g, device=base.device, dtype=torch.float32) - 0.5) * size
+    mn = torch.minimum(torch.clamp(base[:, :3] + jit, min=0.0), side - size)
+    return torch.cat([mn, mn + size], dim=1).contiguous()
+
+
+def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_last):
+    """the reference's frame loop moves its objects (examples/main.rs:410-418, 508-511): the same n objects, re-placed every
+    frame -> entries per object, group sizes and digit plans drift, so the plan hints of the previous frame are predictions
+    again.  The displacement runs on the device OUTSIDE the timed region (torch ops); every frame is timed on its own."""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
+    base = torch.from_numpy(bounds).to(dev)
+    size = (base[:, 3:] - base[:, :3]).contiguous()
+    side = float(sysb[1][0])
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
+
+    def step(cur):
+        layer.clear()
+        layer.extend(sysb, cur, d_ids)
+        layer.par_sort()
+        return layer.scan_device()
+
+    for f in range(2):                                   # the layer's first frames (allocations, plan probing) are not the subject
+        out = step(moving_frame(torch, base, size, side, f, seed))
+    torch.cuda.synchronize()
+    st0 = layer.stats()
+    times, pairs = [], []
+    cur = None
+    for f in range(2, 2 + frames):
+        cur = moving_frame(torch, base, size, side, f, seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = step(cur)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        pairs.append(len(out))
+    st1 = layer.stats()
+    rec = {"workload": "the same %d objects, every frame re-placed by a seeded jitter of +-0.5 x its size per axis (device-side, outside "
+                       "the timed region); %d frames, each timed on its own (clear+extend+par_sort+par_scan)" % (n, frames),
+           "frames": frames, "ms_per_step": sum(times) / len(times), "ms_min": min(times), "ms_max": max(times),
+           "pairs_mean": sum(pairs) / len(pairs), "value": sum(pairs) / (sum(times) * 1e-3), "unit": "pairs/s",
+           "host_syncs_per_step": (st1["host_syncs"] - st0["host_syncs"]) / frames,
+           "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs")},
+           "plan_events_note": "extend_reruns: extends launched on the previous frame's sizes that had to run again; *_plan_flips: sorts "
+                               "whose grouped-finish plan differs from the previous frame's; sort_repairs: deferred tree-sort checks that "
+                               "failed (full-width re-sort + second scan)"}
+    if check_last:                                       # the last frame against the CPU restatement on the same boxes
+        import oracle  # checker only
+        ref = oracle.OracleLayer(oracle.INDEX64_3D, 0)
+        ref.extend(sysb, cur.cpu().numpy(), ids)
+        threads = usable_cpus(oracle.lib().orc_hw_threads())
+        ref.par_sort(threads)
+        exp = ref.par_scan(threads)
+        rec["last_frame_parity"] = list_hash_numpy(exp) == (list_hash_torch(out.as_torch()) if len(out) else [0, 0, 0])
+    else:
+        rec["last_frame_parity"] = None
+    return rec
+
+
 def main():
     args = parse()
     import numpy as np
@@ -254,6 +320,9 @@ def main():
                                  "cold_frame_ms": r1["cold_frame_ms"], "host_syncs_per_step": r1["host_syncs_per_step"],
                                  "tree_sort_passes": r1["stats"]["tree_sort_passes"], "pair_sort_passes": r1["stats"]["pair_sort_passes"]}
             del r1
+        if not args.no_moving and not args.aabb_filter:
+            line["moving"] = run_moving(bp, scenes, torch, np, dev, local_rank, args.objects, args.seed, args.moving_frames,
+                                        check_last=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and not args.aabb_filter:
             cb = cpu_baseline(args.cpu_objects, args.seed)
             line["cpu_baseline"] = cb

@@ -331,17 +331,27 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                     // (2-D: y outer, x inner: src/geom.rs:213-231)
                     const u32 up = AB - depth;
                     const u32 s0 = ((rec.w >> 8) & 3u) - 1u, s1 = ((rec.w >> 10) & 3u) - 1u, s2 = DIM == 3 ? ((rec.w >> 12) & 3u) - 1u : 0u;
-                    u64 mx[2], my[2], mz[2];
-                    mx[0] = spread_bits<DIM>((u64)rec.x << up); mx[1] = dilated_next<DIM>(mx[0], up);
-                    my[0] = spread_bits<DIM>((u64)rec.y << up) << 1; my[1] = dilated_next<DIM>(my[0] >> 1, up) << 1;
-                    mz[0] = 0; mz[1] = 0;
-                    if (DIM == 3) { mz[0] = spread_bits<DIM>((u64)rec.z << up) << 2; mz[1] = dilated_next<DIM>(mz[0] >> 2, up) << 2; }
+                    // per axis: the index value's contribution of the first cell and what the second cell changes in it (XOR)
+                    const u64 m0 = spread_bits<DIM>((u64)rec.x << up), m1 = spread_bits<DIM>((u64)rec.y << up);
+                    const u64 dx = (m0 ^ dilated_next<DIM>(m0, up)) << DB, dy = (m1 ^ dilated_next<DIM>(m1, up)) << (DB + 1);
+                    u64 key0 = ((m0 | (m1 << 1)) << DB) | (u64)depth, dz = 0;
+                    if (DIM == 3) {
+                        const u64 m2 = spread_bits<DIM>((u64)rec.z << up);
+                        key0 |= m2 << (DB + 2);
+                        dz = (m2 ^ dilated_next<DIM>(m2, up)) << (DB + 2);
+                    }
+                    // box code of the first cell (ternary, the form that rides in the id) and what a step on each axis adds
+                    const u32 t0 = s0 + 3u * s1 + 9u * s2, idp = pack_box ? id : 0u;
                     for (u32 e = 0; e < cnt; ++e) {
                         const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
-                        const u64 key = (((x ? mx[1] : mx[0]) | (y ? my[1] : my[0]) | (z ? mz[1] : mz[0])) << DB) | (u64)depth;
-                        const u32 tx = s0 ? 1u + x : 0u, ty = s1 ? 1u + y : 0u, tz = s2 ? 1u + z : 0u;
-                        const u32 code = tx | (ty << 2) | (tz << 4);
-                        put(local, key, pack_box ? (id | (box_to_packed(code) << BOX_ID_BITS)) : id, code);
+                        const u64 key = key0 ^ (x ? dx : 0ull) ^ (y ? dy : 0ull) ^ (z ? dz : 0ull);
+                        const u32 packed = t0 + x + 3u * y + 9u * z;  // tx + 3 ty + 9 tz with t = 0 (one cell) or 1 + step
+                        if (pack_box) {
+                            if (staged) { s_key[local] = key; s_id[local] = idp | (packed << BOX_ID_BITS); }
+                            else { keys_out[this_base + local] = key; ids_out[this_base + local] = idp | (packed << BOX_ID_BITS); }
+                        } else {
+                            put(local, key, id, box_from_packed(packed));
+                        }
                         count_digits(key);
                         ++local;
                     }

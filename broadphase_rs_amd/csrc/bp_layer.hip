@@ -457,6 +457,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack)) {
         // the prediction failed: remember the truth for the next frame and redo this one on the plain path
         L->enc_hint.entries = add; L->enc_hint.n = n; L->enc_hint.pack = can_pack;
+        ++L->stats.extend_reruns;
         return BP_OK;
     }
     L->stats.objects_invalid += sc.n_invalid;
@@ -774,8 +775,11 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     if (!already_synced) BP_TRY(sync_stream(L));
     const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+    const bool tgrp_before = L->tgrp_ok;
     L->tgrp_ok = sc.grp_max <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
+    if ((sc.err & KERR_SEGMENT_TOO_LONG) || L->tgrp_ok != tgrp_before) ++L->stats.tree_plan_flips;
     if (sc.err & KERR_SEGMENT_TOO_LONG) {
+        ++L->stats.sort_repairs;
         L->tgrp_ok = false;
         L->cur = L->sort_pend.src;
         L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
@@ -923,7 +927,9 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 L->tgrp_known = true;
                 // switched on only with a margin (80 % of the capacity): a scene hovering at the limit must not flip the
                 // plan every frame -- each flip costs the digit counts encode_emit made for the other plan
+                const bool tgrp_before = L->tgrp_ok;
                 L->tgrp_ok = sc.grp_max <= (uint32_t)(tgroup_capacity() * 4 / 5);
+                if (L->tgrp_ok != tgrp_before) ++L->stats.tree_plan_flips;
             }
             if (sc.err & KERR_SEGMENT_TOO_LONG) {
                 // a group of equal key prefix is longer than the LDS window (heavily clustered input):
@@ -1064,6 +1070,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     // after a refusal (uneven groups) the grouped finish stays off for the next 16 distinct-pair sorts of this layer
     if (L->grp_off) --L->grp_off;
     const uint32_t n_groups = (first_range && !L->grp_off) ? group_finish_groups(n, varying, first_range[0], first_range[1]) : 0u;
+    if (L->grp_next != (n_groups != 0)) ++L->stats.pair_plan_flips;
     L->grp_next = n_groups != 0;  // the next scan counts its digit histograms for the plan this frame used
     const RadixPlan plan = n_groups ? make_radix_plan(hi_var & 0xFFFFFF0000000000ull, 0, 0) : make_radix_plan(hi_var, 0, 0);
     if (!segment_finish_enabled() || n < 2 || plan.n_passes == 0) return sort_unique_pairs_in(L, buf0, n, varying, true, holes);
@@ -1099,7 +1106,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group / segment did not fit its window: sort all 64 bits instead
         L->grp_next = false;
-        if (n_groups) L->grp_off = 16;
+        if (n_groups) { L->grp_off = 16; ++L->stats.pair_plan_flips; }
         return sort_unique_pairs_in(L, bufs[res], n, varying, true);
     }
     L->n_pairs = n;

@@ -58,7 +58,8 @@ class _Stats(C.Structure):
                 ("raw_pairs", C.c_uint64), ("pairs", C.c_uint64), ("raw_candidates", C.c_uint64),
                 ("tree_sort_passes", C.c_uint32),
                 ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32),
-                ("host_syncs", C.c_uint64)]
+                ("host_syncs", C.c_uint64), ("extend_reruns", C.c_uint32), ("tree_plan_flips", C.c_uint32),
+                ("pair_plan_flips", C.c_uint32), ("sort_repairs", C.c_uint32)]
 
 
 FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)

@@ -264,6 +264,12 @@ typedef struct bp_stats {
     uint32_t depth_mask;      /* bit d set <=> some entry has depth d                   */
     uint32_t flags;           /* bit0: key-only stable sort valid, bit1: ids distinct   */
     uint64_t host_syncs;      /* stream synchronisations since create (each is a host round trip) */
+    /* plan events since create: what a scene that CHANGES from frame to frame costs beyond the steady state (every one of
+     * them only costs time, never changes a result) */
+    uint32_t extend_reruns;   /* extends launched on predicted sizes that had to run again on the plain path          */
+    uint32_t tree_plan_flips; /* tree sorts whose plan (grouped finish on / off) differs from the previous sort's     */
+    uint32_t pair_plan_flips; /* the same for the pair sort's grouped finish                                          */
+    uint32_t sort_repairs;    /* deferred tree-sort checks that failed: full-width re-sort + scan run again           */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 

@@ -677,6 +677,34 @@ def test_claiming_first_radix_pass_on_small_and_uneven_inputs(monkeypatch, kind)
     assert_pairs_equal(np.array(gpu.par_scan()), ref.scan(), "claiming pass switched off")
 
 
+def test_moving_scene_frames_match_the_oracle_frame_by_frame():
+    """the reference's frame loop moves its objects (examples/main.rs:410-418, 508-511): one layer, the same 1 M objects
+    re-placed every frame by a jitter of up to +-0.5 of their size -- entries per object, group sizes and digit plans drift,
+    so what the layer predicted from the previous frame (extend sizes, grouped finishes, deferred sort check) is wrong
+    now and then; every frame's tree and pair list must equal the oracle's on the same boxes"""
+    n = 1000000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=61)
+    size = bounds[:, 3:] - bounds[:, :3]
+    side = np.float32(sysb[1][0])
+    rng = np.random.default_rng(62)
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    ev0 = gpu.stats()
+    for frame in range(4):
+        jit = ((rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * size).astype(np.float32)
+        mn = np.minimum(np.maximum(bounds[:, :3] + jit, np.float32(0)), side - size).astype(np.float32)
+        cur = np.ascontiguousarray(np.concatenate([mn, mn + size], axis=1).astype(np.float32))
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, cur, ids); ref.extend(sysb, cur, ids)
+        assert_tree_equal(gpu, ref, "moving frame %d, extend" % frame)
+        if frame % 2 == 0:
+            gpu.par_sort(); ref.par_sort()
+            assert_tree_equal(gpu, ref, "moving frame %d, par_sort" % frame)
+        assert_pairs_equal(gpu.scan_device().to_numpy(), ref.par_scan(), "moving frame %d, par_scan" % frame)
+    st = gpu.stats()
+    assert st["host_syncs"] > ev0["host_syncs"] and all(k in st for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs"))
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list
