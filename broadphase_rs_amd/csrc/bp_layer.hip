@@ -123,6 +123,11 @@ struct bp_layer {
     // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
     // NEXT host round trip (the scan's) instead of one of their own
     struct { bool on = false; int src = 0; bool ride = false; } sort_pend;
+    // a partition pass that was only enqueued (BP_PARTITION_ENQUEUE_ONLY): its error word, copied behind the pass into
+    // h_part_err, is looked at by the layer's next host round trip (sync_stream)
+    bool part_pend = false;
+    DevBuf d_part_err;
+    HostBuf h_part_err;
     DevBuf d_sort_sc;                   // DevScalars of the tree sort's kernels (the scan re-initialises d_sc)
     HostBuf h_sort_sc;
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
@@ -275,6 +280,11 @@ int sync_stream(bp_layer* L) {
     ++L->stats.host_syncs;
     HIP_TRY(L, hipStreamSynchronize(L->stream));
     prof_collect(L);
+    if (L->part_pend) {  // an enqueue-only partition pass has completed by now: its error word
+        L->part_pend = false;
+        const unsigned err = *(const unsigned*)L->h_part_err.p;
+        if (err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out in the entry partition pass (its buckets were incomplete)");
+    }
     return BP_OK;
 }
 
@@ -1689,7 +1699,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
     free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
-    free_host(L->h_shards); free_host(L->h_sort_sc);
+    free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
@@ -2245,6 +2255,9 @@ int bp_layer_get_facts(const bp_layer_t* L, bp_facts* out) {
 int bp_layer_begin_entries(bp_layer_t* L, size_t m, uint64_t** d_keys, uint32_t** d_ids) {
     if (!L || !d_keys || !d_ids) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_begin_entries: null argument");
     DeviceGuard g(L->device);
+    // the buffers are handed to writers on OTHER streams: a tree sort that was only enqueued (deferred check) may still be
+    // running on this layer's stream -- wait for it before exposing them
+    if (L->sort_pend.on) BP_TRY(sync_stream(L));
     BP_TRY(bp_layer_clear(L));
     BP_TRY(ensure_tree_capacity(L, std::max<size_t>(m, 1)));
     *d_keys = cur_keys(L);
@@ -2348,7 +2361,9 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     if (split_depth == 0 || split_depth > ki.axis_bits || n_cells != ((size_t)1 << (ki.dim * split_depth)) || n_cells > 4096 ||
         n_dest == 0 || n_dest > 255)
         return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: bad split_depth / n_cells / n_dest");
-    if (pack_box && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
+    // (a layer without entries has nothing to pack: a rank whose objects all fell outside the system bounds must not fail here
+    // while its peers wait for it in the exchange)
+    if (pack_box && L->m != 0 && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
     DeviceGuard g(L->device);
     const bool already_packed = pack_box && L->ids_packed;  // extend wrote the codes into the ids: nothing to do
     if (!already_packed) BP_TRY(ensure_unpacked(L));
@@ -2390,7 +2405,16 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     }
     // enqueue only: the bucket sizes are known from the histogram, the caller orders whatever reads the buckets behind this
     // layer's stream (bp_layer_stream) itself, and nobody waits here
-    if ((flags & BP_PARTITION_ENQUEUE_ONLY) && ready_hist) return BP_OK;
+    if ((flags & BP_PARTITION_ENQUEUE_ONLY) && ready_hist) {
+        // nobody waits here, but the pass's error word must not be lost (the next reset of the scalars would overwrite it):
+        // it is copied behind the pass and checked by the layer's next host round trip
+        BP_TRY(ensure_dev(L, L->d_part_err, sizeof(unsigned)));
+        BP_TRY(ensure_host(L, L->h_part_err, sizeof(unsigned)));
+        HIP_TRY(L, hipMemcpyAsync(L->d_part_err.p, &((DevScalars*)L->d_sc.p)->err, sizeof(unsigned), hipMemcpyDeviceToDevice, L->stream));
+        HIP_TRY(L, hipMemcpyAsync(L->h_part_err.p, L->d_part_err.p, sizeof(unsigned), hipMemcpyDeviceToHost, L->stream));
+        L->part_pend = true;
+        return BP_OK;
+    }
     HIP_TRY(L, hipMemcpyAsync(L->h_raw.p, d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));

@@ -36,6 +36,8 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*CommAbort)(rccl_comm) = nullptr;                 // optional
+    int (*CommGetAsyncError)(rccl_comm, int*) = nullptr;   // optional
     const char* (*GetErrorString)(int) = nullptr;
     std::string why;
 };
@@ -58,6 +60,10 @@ RcclApi* rccl_api() {
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        const std::string keep = api.why;  // the two below are optional: their absence is not an error
+        api.CommAbort = (int (*)(rccl_comm))dlsym(api.lib, "ncclCommAbort");
+        api.CommGetAsyncError = (int (*)(rccl_comm, int*))dlsym(api.lib, "ncclCommGetAsyncError");
+        api.why = keep;
     });
     return &api;
 }
@@ -80,7 +86,7 @@ struct bp_group {
     std::condition_variable cv;
     int waiting = 0;
     unsigned long long generation = 0;
-    bool broken = false;                                  // a rank failed inside a collective: everyone bails out
+    bool broken = false;                                  // a rank failed inside a collective: everyone bails out (RCCL: the communicator was aborted)
     std::vector<std::vector<int64_t>> host_slot;          // all-gather of host vectors: slot per rank
     struct Pub { const void* ptr = nullptr; std::vector<uint64_t> offs; uint64_t n = 0; };
     std::vector<Pub> pub;                                 // device buffers published for an exchange
@@ -121,6 +127,44 @@ void local_break(bp_group* g) {
     g->cv.notify_all();
 }
 
+// RCCL: this rank cannot go on with a collective sequence (or a peer did not show up in time).  The communicator is
+// aborted -- transfers in flight with this rank end instead of waiting for it -- and the group refuses further use: the
+// host tears the job down (or builds a new group); the process image is never restarted from here.
+void rccl_poison(bp_group* g) {
+    if (g->kind != GRP_RCCL || g->broken) return;
+    g->broken = true;
+    const RcclApi* a = rccl_api();
+    if (g->comm && a->CommAbort) { (void)a->CommAbort(g->comm); g->comm = nullptr; }
+}
+// wait for the group's stream, but not for ever: a peer that failed between two collectives never posts its side.  Polls the
+// stream and the communicator's asynchronous error state; BP_SHARDED_TIMEOUT_MS (default 60000) bounds the wait.
+int grp_wait(bp_group* g) {
+    const RcclApi* a = rccl_api();
+    static const long timeout_ms = getenv("BP_SHARDED_TIMEOUT_MS") ? atol(getenv("BP_SHARDED_TIMEOUT_MS")) : 60000;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(g->stream);
+        if (q == hipSuccess) return BP_OK;
+        if (q != hipErrorNotReady) { rccl_poison(g); return gfail(g, BP_ERR_HIP, std::string("exchange stream: ") + hipGetErrorString(q)); }
+        if ((++spins & 1023u) == 0) {
+            if (a->CommGetAsyncError && g->comm) {
+                int async = 0;
+                if (a->CommGetAsyncError(g->comm, &async) == 0 && async != 0) {
+                    const std::string why = std::string("RCCL reported an asynchronous error: ") + (a->GetErrorString ? a->GetErrorString(async) : "error");
+                    rccl_poison(g);
+                    return gfail(g, BP_ERR_COMM, why);
+                }
+            }
+            const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > timeout_ms) {
+                rccl_poison(g);
+                return gfail(g, BP_ERR_COMM, "an exchange did not complete within BP_SHARDED_TIMEOUT_MS: a peer rank has failed or left the collective sequence");
+            }
+        }
+    }
+}
+
 // test switch: the part of an exchange that stays on the rank also goes through ncclSend / ncclRecv (a one-rank group
 // then exercises the whole RCCL binding)
 bool self_through_rccl() { return getenv("BP_SHARDED_SELF_SEND") != nullptr; }  // read per call: tests flip it
@@ -131,7 +175,10 @@ constexpr size_t CHUNK_BYTES = 256u << 20;  // per-peer message size cap (RCCL o
         int rc__ = (call);                                                                                  \
         if (rc__ != 0) {                                                                                    \
             const RcclApi* a__ = rccl_api();                                                                \
-            return gfail((g), BP_ERR_COMM, std::string(#call) + ": " + (a__->GetErrorString ? a__->GetErrorString(rc__) : "rccl error")); \
+            const std::string why__ = std::string(#call) + ": " + (a__->GetErrorString ? a__->GetErrorString(rc__) : "rccl error"); \
+            if (in_group__) (void)a__->GroupEnd();  /* never leave the communicator in group mode */        \
+            rccl_poison(g);                                                                                 \
+            return gfail((g), BP_ERR_COMM, why__);                                                          \
         }                                                                                                   \
     } while (0)
 #define GHIP_TRY(g, call)                                                                          \
@@ -151,6 +198,8 @@ int grp_allgather_i64(bp_group* g, int rank, const int64_t* mine, size_t n, int6
         return BP_OK;
     }
     const RcclApi* a = rccl_api();
+    if (g->broken) return gfail(g, BP_ERR_COMM, "the RCCL group was aborted by an earlier failure");
+    bool in_group__ = false;
     const size_t bytes = n * sizeof(int64_t), total = bytes * (size_t)(g->world + 1);
     if (total > g->small_cap) {
         if (g->d_small) (void)hipFree(g->d_small);
@@ -166,7 +215,7 @@ int grp_allgather_i64(bp_group* g, int rank, const int64_t* mine, size_t n, int6
     GHIP_TRY(g, hipMemcpyAsync(d_send, g->h_small, bytes, hipMemcpyHostToDevice, g->stream));
     RCCL_TRY(g, a->AllGather(d_send, d_recv, n, RCCL_INT64, g->comm, g->stream));
     GHIP_TRY(g, hipMemcpyAsync((char*)g->h_small + bytes, d_recv, bytes * (size_t)g->world, hipMemcpyDeviceToHost, g->stream));
-    GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    { const int wrc = grp_wait(g); if (wrc != BP_OK) return wrc; }
     std::memcpy(all, (char*)g->h_small + bytes, bytes * (size_t)g->world);
     return BP_OK;
 }
@@ -197,6 +246,8 @@ int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_
         return BP_OK;
     }
     const RcclApi* a = rccl_api();
+    if (g->broken) return gfail(g, BP_ERR_COMM, "the RCCL group was aborted by an earlier failure");
+    bool in_group__ = false;
     const uint64_t ch = std::max<uint64_t>(1, CHUNK_BYTES / elem);
     const uint64_t rounds = std::max<uint64_t>(1, (max_msg + ch - 1) / ch);
     // the part that stays on this rank is a device copy (about three times the rate of a send to oneself)
@@ -205,6 +256,7 @@ int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_
                                    hipMemcpyDeviceToDevice, g->stream));
     for (uint64_t rd = 0; rd < rounds; ++rd) {
         RCCL_TRY(g, a->GroupStart());
+        in_group__ = true;
         for (int p = 0; p < W; ++p) {
             if (p == rank && !self_through_rccl()) continue;
             const uint64_t s0 = std::min(send_counts[p], rd * ch), s1 = std::min(send_counts[p], (rd + 1) * ch);
@@ -212,9 +264,10 @@ int grp_alltoallv(bp_group* g, int rank, const void* send, const uint64_t* send_
             if (s1 > s0) RCCL_TRY(g, a->Send((const char*)send + (soff[p] + s0) * elem, (s1 - s0) * elem, RCCL_INT8, p, g->comm, g->stream));
             if (r1 > r0) RCCL_TRY(g, a->Recv((char*)recv + (roff[p] + r0) * elem, (r1 - r0) * elem, RCCL_INT8, p, g->comm, g->stream));
         }
+        in_group__ = false;
         RCCL_TRY(g, a->GroupEnd());
     }
-    if (wait) GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (wait) return grp_wait(g);
     return BP_OK;
 }
 
@@ -245,6 +298,8 @@ int grp_allgatherv(bp_group* g, int rank, const void* send, const uint64_t* size
     // RCCL: as a grouped exchange in which every rank sends the same array to every peer (the arrays are small:
     // boundary keys), cut like any other message
     const RcclApi* a = rccl_api();
+    if (g->broken) return gfail(g, BP_ERR_COMM, "the RCCL group was aborted by an earlier failure");
+    bool in_group__ = false;
     std::vector<uint64_t> roff(W + 1, 0);
     for (int r = 0; r < W; ++r) roff[r + 1] = roff[r] + sizes[r];
     const uint64_t ch = std::max<uint64_t>(1, CHUNK_BYTES / elem);
@@ -252,16 +307,17 @@ int grp_allgatherv(bp_group* g, int rank, const void* send, const uint64_t* size
     const uint64_t mine = sizes[rank];
     for (uint64_t rd = 0; rd < rounds; ++rd) {
         RCCL_TRY(g, a->GroupStart());
+        in_group__ = true;
         for (int p = 0; p < W; ++p) {
             const uint64_t s0 = std::min(mine, rd * ch), s1 = std::min(mine, (rd + 1) * ch);
             const uint64_t r0 = std::min(sizes[p], rd * ch), r1 = std::min(sizes[p], (rd + 1) * ch);
             if (s1 > s0) RCCL_TRY(g, a->Send((const char*)send + s0 * elem, (s1 - s0) * elem, RCCL_INT8, p, g->comm, g->stream));
             if (r1 > r0) RCCL_TRY(g, a->Recv((char*)recv + (roff[p] + r0) * elem, (r1 - r0) * elem, RCCL_INT8, p, g->comm, g->stream));
         }
+        in_group__ = false;
         RCCL_TRY(g, a->GroupEnd());
     }
-    GHIP_TRY(g, hipStreamSynchronize(g->stream));
-    return BP_OK;
+    return grp_wait(g);
 }
 
 // Several exchanges in ONE round of grouped sends / receives (one launch latency instead of one per array): the entry
@@ -296,6 +352,8 @@ Xfer xfer_allgatherv(int W, int rank, const void* send, const uint64_t* sizes, s
 // wait = false: only enqueued on the group's stream; the caller orders its consumers behind that stream
 int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg_bytes, bool wait = true) {
     const RcclApi* a = rccl_api();
+    if (g->broken) return gfail(g, BP_ERR_COMM, "the RCCL group was aborted by an earlier failure");
+    bool in_group__ = false;
     const int W = g->world;
     const uint64_t rounds = std::max<uint64_t>(1, (max_msg_bytes + CHUNK_BYTES - 1) / CHUNK_BYTES);
     // what stays on this rank is a device copy (about three times the rate of a send to oneself)
@@ -305,6 +363,7 @@ int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg
                                        x.s_cnt[g->rank] * x.elem, hipMemcpyDeviceToDevice, g->stream));
     for (uint64_t rd = 0; rd < rounds; ++rd) {
         RCCL_TRY(g, a->GroupStart());
+        in_group__ = true;
         for (int p = 0; p < W; ++p) {
             if (p == g->rank && !self_through_rccl()) continue;
             for (const Xfer& x : xs) {
@@ -315,9 +374,10 @@ int grp_exchange_rccl(bp_group* g, const std::vector<Xfer>& xs, uint64_t max_msg
                 if (r1 > r0) RCCL_TRY(g, a->Recv((char*)x.recv + (x.r_off[p] + r0) * x.elem, (r1 - r0) * x.elem, RCCL_INT8, p, g->comm, g->stream));
             }
         }
+        in_group__ = false;
         RCCL_TRY(g, a->GroupEnd());
     }
-    if (wait) GHIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (wait) return grp_wait(g);
     return BP_OK;
 }
 
@@ -374,11 +434,19 @@ int sfail(bp_sharded* s, int code, const std::string& what) {
     g_group_error = what;
     return code;
 }
+// this rank gives up in the middle of the collective sequence: its peers must not wait for it for ever.  LOCAL: the
+// group's barrier is broken (every waiting rank returns BP_ERR_COMM); RCCL: the communicator is aborted and the peers'
+// bounded waits (grp_wait) end.  Failures that every rank sees alike (the gathered status words) return without this.
+void leave_collective(bp_sharded* s) {
+    if (s->world <= 1) return;
+    if (s->group->kind == GRP_LOCAL) local_break(s->group);
+    else rccl_poison(s->group);
+}
 #define L_TRY(s, layer, call)                                                                       \
     do {                                                                                            \
         int rc__ = (call);                                                                          \
         if (rc__ != BP_OK) {                                                                        \
-            if ((s)->group->kind == GRP_LOCAL && (s)->world > 1) local_break((s)->group);           \
+            leave_collective((s));                                                                  \
             return sfail((s), rc__, std::string(#call) + ": " + bp_layer_last_error(layer));        \
         }                                                                                           \
     } while (0)
@@ -386,7 +454,7 @@ int sfail(bp_sharded* s, int code, const std::string& what) {
     do {                                                                                \
         ++(s)->info.round_trips_exchanges;                                              \
         int rc__ = (call);                                                              \
-        if (rc__ != BP_OK) return sfail((s), rc__, (s)->group->err);                    \
+        if (rc__ != BP_OK) { leave_collective((s)); return sfail((s), rc__, (s)->group->err); } \
     } while (0)
 }  // namespace
 
@@ -407,7 +475,8 @@ int bp_group_unique_id(void* out) {
 }
 
 int bp_group_create_local(bp_group_t** out, int world) {
-    if (!out || world < 1 || world > 255) return gfail(nullptr, BP_ERR_INVALID_ARG, "bp_group_create_local: world must be 1..255");
+    if (!out || world < 1 || world > BP_SHARDED_MAX_RANKS)
+        return gfail(nullptr, BP_ERR_INVALID_ARG, "bp_group_create_local: world must be 1..16 (BP_SHARDED_MAX_RANKS)");
     bp_group* g = new (std::nothrow) bp_group();
     if (!g) return BP_ERR_OOM;
     g->kind = GRP_LOCAL;
@@ -419,8 +488,8 @@ int bp_group_create_local(bp_group_t** out, int world) {
 }
 
 int bp_group_create_rccl(bp_group_t** out, int rank, int world, const void* uid, int device) {
-    if (!out || !uid || world < 1 || world > 255 || rank < 0 || rank >= world)
-        return gfail(nullptr, BP_ERR_INVALID_ARG, "bp_group_create_rccl: bad rank / world / id");
+    if (!out || !uid || world < 1 || world > BP_SHARDED_MAX_RANKS || rank < 0 || rank >= world)
+        return gfail(nullptr, BP_ERR_INVALID_ARG, "bp_group_create_rccl: bad rank / world (1..16, BP_SHARDED_MAX_RANKS) / id");
     const RcclApi* a = rccl_api();
     if (!rccl_ok(a)) return gfail(nullptr, BP_ERR_COMM, "RCCL is not available: " + a->why);
     int count = 0;
@@ -466,6 +535,7 @@ int bp_sharded_create(bp_sharded_t** out, bp_group_t* group, int rank, int index
     if (!out || !group || rank < 0 || rank >= group->world || index_kind < 0 || index_kind > 2)
         return gfail(group, BP_ERR_INVALID_ARG, "bp_sharded_create: bad argument");
     if (group->kind == GRP_RCCL && rank != group->rank) return gfail(group, BP_ERR_INVALID_ARG, "bp_sharded_create: rank differs from the group's");
+    if (group->world > BP_SHARDED_MAX_RANKS) return gfail(group, BP_ERR_INVALID_ARG, "bp_sharded_create: more than BP_SHARDED_MAX_RANKS (16) ranks");
     const uint32_t dim = index_kind == BP_INDEX64_3D ? 3u : 2u;
     if (split_depth == 0) split_depth = dim == 3 ? 3u : 4u;
     if (dim * split_depth > 12) return gfail(group, BP_ERR_INVALID_ARG, "bp_sharded_create: split_depth too deep (at most 4096 cells)");
@@ -572,20 +642,46 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     };
 
     // ---- 2. cell histogram + facts of every rank in ONE small all-gather ------------------------------------------------
+    // A rank that fails BEFORE the first exchange still takes part in it: its status word rides with the facts, every rank
+    // reads every rank's status, and all of them return together -- nobody is left waiting in a collective.
     std::vector<uint64_t> hist(n_cells + 1, 0);
-    L_TRY(s, s->local, bp_layer_cell_histogram(s->local, d_s, hist.data(), n_cells));
     bp_facts lf;
-    L_TRY(s, s->local, bp_layer_get_facts(s->local, &lf));
+    std::memset(&lf, 0, sizeof lf);
+    int st_rc = bp_layer_cell_histogram(s->local, d_s, hist.data(), n_cells);
+    std::string st_why = st_rc == BP_OK ? std::string() : std::string("bp_layer_cell_histogram: ") + bp_layer_last_error(s->local);
+    if (st_rc == BP_OK) {
+        st_rc = bp_layer_get_facts(s->local, &lf);
+        if (st_rc != BP_OK) st_why = std::string("bp_layer_get_facts: ") + bp_layer_last_error(s->local);
+    }
+    if (st_rc != BP_OK) std::fill(hist.begin(), hist.end(), 0ull);
     uint64_t m_local = 0;
     for (uint64_t v : hist) m_local += v;
-    enum { F_KOR, F_KAND, F_IOR, F_IAND, F_IMIN, F_IMAX, F_DM, F_FLAGS, F_M, F_N };
+    enum { F_KOR, F_KAND, F_IOR, F_IAND, F_IMIN, F_IMAX, F_DM, F_FLAGS, F_M, F_STATUS, F_IDCOUNT, F_N };
     const size_t vlen = n_cells + 1 + F_N;
     std::vector<int64_t> mine(vlen), all(vlen * (size_t)G);
     for (size_t c = 0; c <= n_cells; ++c) mine[c] = (int64_t)hist[c];
     int64_t* f = mine.data() + n_cells + 1;
     f[F_KOR] = (int64_t)lf.key_or; f[F_KAND] = (int64_t)lf.key_and; f[F_IOR] = lf.id_or; f[F_IAND] = lf.id_and;
     f[F_IMIN] = lf.id_min; f[F_IMAX] = lf.id_max; f[F_DM] = lf.depth_mask; f[F_FLAGS] = lf.flags; f[F_M] = (int64_t)m_local;
+    f[F_STATUS] = st_rc; f[F_IDCOUNT] = (int64_t)s->id_count;
+    if (st_rc != BP_OK) { f[F_IMIN] = 0xFFFFFFFFll; f[F_IMAX] = 0; }  // no ids to speak of
     G_TRY(s, grp_allgather_i64(g, rank, mine.data(), vlen, all.data()));
+    {   // agreement on what every rank brought: all ranks evaluate the same gathered words and take the same exit
+        auto factq = [&](int r, int k) { return all[(size_t)r * vlen + n_cells + 1 + k]; };
+        for (int r = 0; r < G; ++r)
+            if (factq(r, F_STATUS) != BP_OK) {
+                if (r == rank) return sfail(s, st_rc, st_why);
+                return sfail(s, BP_ERR_COMM, "rank " + std::to_string(r) + " failed before the exchange (status " + std::to_string((long long)factq(r, F_STATUS)) + ")");
+            }
+        for (int r = 0; r < G; ++r)
+            if ((uint64_t)factq(r, F_IDCOUNT) != s->id_count)
+                return sfail(s, BP_ERR_INVALID_ARG, "bp_sharded_create: id_count differs between the ranks");
+        if (s->id_count)  // the caller vouched for ids in [0, id_count): a larger one would be mis-sorted silently by the owners' digit plans
+            for (int r = 0; r < G; ++r)
+                if (factq(r, F_IMIN) <= factq(r, F_IMAX) && (uint64_t)factq(r, F_IMAX) >= s->id_count)
+                    return sfail(s, BP_ERR_INVALID_ARG, "an id handed to rank " + std::to_string(r) + " is not below id_count (" +
+                                                            std::to_string((long long)factq(r, F_IMAX)) + " >= " + std::to_string((unsigned long long)s->id_count) + ")");
+    }
     std::vector<uint64_t> hist_all(n_cells, 0);
     for (int r = 0; r < G; ++r)
         for (size_t c = 0; c < n_cells; ++c) hist_all[c] += (uint64_t)all[(size_t)r * vlen + c];
@@ -617,9 +713,14 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     if (chained) {
         void* local_stream = nullptr;
         L_TRY(s, s->local, bp_layer_stream(s->local, &local_stream));
-        if (!s->chain_ev && hipEventCreateWithFlags(&s->chain_ev, hipEventDisableTiming) != hipSuccess) return sfail(s, BP_ERR_HIP, "hipEventCreate failed");
-        if (hipEventRecord(s->chain_ev, (hipStream_t)local_stream) != hipSuccess || hipStreamWaitEvent(g->stream, s->chain_ev, 0) != hipSuccess)
+        if (!s->chain_ev && hipEventCreateWithFlags(&s->chain_ev, hipEventDisableTiming) != hipSuccess) {
+            leave_collective(s);
+            return sfail(s, BP_ERR_HIP, "hipEventCreate failed");
+        }
+        if (hipEventRecord(s->chain_ev, (hipStream_t)local_stream) != hipSuccess || hipStreamWaitEvent(g->stream, s->chain_ev, 0) != hipSuccess) {
+            leave_collective(s);
             return sfail(s, BP_ERR_HIP, "could not order the exchange behind the partition pass");
+        }
     }
     lap(1);
     // cm[src][dst] entries go from src to dst, cm[src][G] = src's boundary keys: every rank derives the whole matrix from
@@ -631,7 +732,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     }
     for (int k = 0; k <= G; ++k)
         if (cm[(size_t)rank * (G + 1) + k] != counts[k]) {
-            if (g->kind == GRP_LOCAL && G > 1) local_break(g);
+            leave_collective(s);
             return sfail(s, BP_ERR_COMM, "partition counts disagree with the cell histogram");
         }
     std::vector<uint64_t> recv_counts(G), coarse_sizes(G), send_counts(G);
@@ -717,7 +818,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         L_TRY(s, s->shard, bp_layer_par_scan_shard_device(s->shard, d_s, emit_coarse, &dp, &np, &unique));
         lap(4);
         if (!unique && n_recv + n_coarse != 0)  // cannot happen with these facts; the other ranks have already taken this route
-            return sfail(s, BP_ERR_KERNEL, "the shard scan did not suppress its duplicates although every box code is known");
+            return sfail(s, BP_ERR_KERNEL, "the shard scan did not suppress its duplicates although every box code is known");  // (no exchange follows on this route)
         s->d_out = dp; s->n_out = np;
         s->info.raw_pairs = np; s->info.pairs = np; s->info.id_lo = 0; s->info.id_hi = (uint32_t)max_id; s->info.pair_order = BP_PAIRS_LOCAL;
         *d_pairs = dp; *n_pairs = np;
@@ -749,7 +850,7 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
         s->d_recv_pairs = nullptr; s->recv_cap = 0;
         const size_t want = (size_t)(n_in + n_in / 8 + 1024) * sizeof(uint64_t);
         if (hipMalloc(&s->d_recv_pairs, want) != hipSuccess) {
-            if (g->kind == GRP_LOCAL && G > 1) local_break(g);
+            leave_collective(s);
             return sfail(s, BP_ERR_OOM, "hipMalloc of the pair receive buffer failed");
         }
         s->recv_cap = want;

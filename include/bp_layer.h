@@ -96,7 +96,13 @@ int bp_layer_extend_device(bp_layer_t *layer, const float *sys_min, const float 
 /* Layer::merge (src/layer.rs:127-138); `other` must live on the same device */
 int bp_layer_merge(bp_layer_t *layer, const bp_layer_t *other);
 
-/* Layer::sort / Layer::par_sort (src/layer.rs:146-165): one implementation, two names */
+/* Layer::sort / Layer::par_sort (src/layer.rs:146-165): one implementation, two names.
+ * Completion is DEFERRED: the call may return with the sort only enqueued on the layer's stream and its validation (does
+ * every prefix group fit the LDS finish?) still open.  Every accessor of the tree (bp_layer_tree*, the scans, queries,
+ * merge, clone, equals) and bp_layer_begin_entries settle it first -- they wait for the stream, read the sort's error word
+ * and, should the check have failed, repair the tree with the full-width sort -- so the deferral is not observable through
+ * this ABI; an error of the sort (BP_ERR_KERNEL) is then reported by THAT call.  Callers that enqueue their own work on
+ * another stream must order it behind bp_layer_stream() themselves. */
 int bp_layer_sort(bp_layer_t *layer);
 int bp_layer_par_sort(bp_layer_t *layer);
 

@@ -38,6 +38,8 @@ typedef struct bp_group bp_group_t;     /* the ranks of one job and their transp
 typedef struct bp_sharded bp_sharded_t; /* one rank's share of a multi-GPU Layer<Index, u32> */
 
 #define BP_UNIQUE_ID_BYTES 128
+/* ranks per group: the owner tables of the pair exchange (first-id ranges) hold 15 bounds; one node has 8 GPUs */
+#define BP_SHARDED_MAX_RANKS 16
 
 /* rank 0: a fresh id for a new RCCL group (ncclGetUniqueId); the host hands the 128 bytes to every rank */
 int bp_group_unique_id(void *out_128_bytes);
@@ -59,7 +61,17 @@ typedef enum bp_pair_order {
 } bp_pair_order;
 
 /* split_depth = 0: the default (3 in 3-D: 512 cells, 4 in 2-D: 256 cells are the units of ownership).
- * id_count: ids are known to lie in [0, id_count) (0: unknown -- the id range is taken from the ranks' own facts) */
+ * id_count: ids are known to lie in [0, id_count) (0: unknown -- the id range is taken from the ranks' own facts).  Every
+ * rank must pass the same value; bp_sharded_par_scan returns BP_ERR_INVALID_ARG on every rank when the values differ or
+ * some rank was handed an id >= id_count (checked on the gathered facts, before anything is exchanged).
+ *
+ * Failure model of the collective calls.  A rank whose own layer calls fail BEFORE the first exchange still takes part in
+ * it: its status word travels with the facts and every rank returns non-zero together.  A rank that fails later leaves the
+ * sequence: LOCAL groups break their barrier (the waiting ranks return BP_ERR_COMM); an RCCL rank aborts its communicator
+ * (ncclCommAbort) and the group refuses further use; its peers' waits on the exchange stream are bounded
+ * (BP_SHARDED_TIMEOUT_MS, default 60000) and poll the communicator's asynchronous error state, so they return
+ * BP_ERR_COMM instead of blocking.  After such a return the group is dead: destroy it and build a new one.  (Work the
+ * layers chain behind an exchange by stream events is bounded by the same exchange.) */
 int bp_sharded_create(bp_sharded_t **out, bp_group_t *group, int rank, int index_kind, uint32_t min_depth,
                       uint32_t split_depth, int device, uint64_t id_count);
 int bp_sharded_destroy(bp_sharded_t *sh);

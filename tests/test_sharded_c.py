@@ -37,6 +37,9 @@ def test_local_group_lifecycle_and_argument_checks_without_a_gpu():
     g.destroy()
     with pytest.raises(bp.BroadphaseError):
         sharded.Group.local(0)
+    with pytest.raises(bp.BroadphaseError):              # BP_SHARDED_MAX_RANKS: the pair exchange's owner tables hold 15 bounds
+        sharded.Group.local(17)
+    sharded.Group.local(16).destroy()
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
@@ -132,6 +135,87 @@ def test_c_sharded_ranks_that_hold_no_entries(world, empty):
     assert len(expect) > 0 and got.shape == expect.shape and np.array_equal(got, expect)
     for r in empty:
         assert results[r][1]["entries_local"] == 0
+
+
+@pytest.mark.gpu
+def test_c_sharded_rank_out_of_bounds_with_unordered_ids_does_not_fail_the_group():
+    """a rank whose objects ALL fall outside the system bounds holds no entries; its ids (unordered here, which forbids the
+    box codes to ride in them) must not make its partition call fail while the peers wait in the exchange"""
+    world = 3
+    parts = [scenes.gen_boxes_shard(world * 30000, r, world, seed=17) for r in range(world)]
+    sysb, b, ids = parts[1]
+    parts[1] = (sysb, b + np.float32(4.0) * np.float32(sysb[1][0]), np.ascontiguousarray(ids[::-1]))
+    results = _run_local_group(parts, world, frames=2)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([np.asarray(results[r][0]).reshape(-1, 2) for r in range(world)], axis=0)
+    assert len(expect) > 0 and got.shape == expect.shape and np.array_equal(got, expect)
+    assert results[1][1]["entries_local"] == 0 and results[0][1]["box_codes"] == 1
+
+
+@pytest.mark.gpu
+def test_c_sharded_ids_above_id_count_are_refused_on_every_rank():
+    """id_count is a promise (ids in [0, id_count)) the owners' digit plans rely on: an id beyond it is found on the gathered
+    facts, before anything is exchanged, and EVERY rank returns BP_ERR_INVALID_ARG -- nobody is left inside a collective"""
+    import torch
+    torch.cuda.init()
+    world = 2
+    parts = [scenes.gen_boxes_shard(world * 20000, r, world, seed=19) for r in range(world)]
+    sysb, b, ids = parts[1]
+    ids = ids.copy(); ids[7] = 5_000_000                 # rank 1 holds an id far above id_count
+    parts[1] = (sysb, b, ids)
+    group = sharded.Group.local(world)
+    errors = [None] * world
+
+    def run(rank):
+        try:
+            sh = sharded.CShardedLayer(group, rank, bp.Index64_3D, device=0, id_count=world * 20000)
+            sh.clear()
+            sh.extend(*parts[rank])
+            sh.par_scan("global")
+        except bp.BroadphaseError as e:
+            errors[rank] = e
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(e is not None and e.status == "BP_ERR_INVALID_ARG" and "id_count" in str(e) for e in errors), errors
+    group.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["global", "local"])
+def test_c_sharded_world8_at_the_true_per_gpu_share_of_10m(order):
+    """BASELINE configs[3] as bench.py --gpus 8 runs it -- 10 M objects in total, 1.25 M per rank, the C engine -- with the 8
+    ranks as threads of one process on one GPU: the concatenated (global order) / merged (local order) lists against the
+    oracle's list of the union scene, element by element"""
+    world, n_total = 8, 10_000_000
+    parts = [scenes.gen_boxes_shard(n_total, r, world, seed=0) for r in range(world)]
+    results = _run_local_group(parts, world, frames=2, pair_order=order, id_count=n_total)
+    expect = _oracle_pairs(parts)
+    if order == "global":
+        got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+        assert got.shape == expect.shape and np.array_equal(got, expect)
+    else:
+        pk = np.sort(np.concatenate([(results[r][0][:, 0].astype(np.uint64) << np.uint64(32)) | results[r][0][:, 1].astype(np.uint64)
+                                     for r in range(world)]))
+        exp = (expect[:, 0].astype(np.uint64) << np.uint64(32)) | expect[:, 1].astype(np.uint64)
+        assert np.array_equal(pk, exp)
+    assert all(results[r][1]["pair_order"] == order for r in range(world))
+
+
+@pytest.mark.gpu
+def test_c_sharded_world8_powerlaw_two_million():
+    """configs[4]'s shape (power-law radii: the heavy tail becomes boundary keys on every rank) at 2 M objects over 8 ranks of
+    the C engine, list-compared with the oracle"""
+    world, n_total = 8, 2_000_000
+    parts = [scenes.gen_boxes_powerlaw_shard(n_total, r, world, seed=23, alpha=2.5) for r in range(world)]
+    results = _run_local_group(parts, world, frames=1, id_count=n_total)
+    expect = _oracle_pairs(parts)
+    got = np.concatenate([results[r][0] for r in range(world)], axis=0)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+    assert sum(results[r][1]["coarse"] for r in range(world)) > 0
 
 
 @pytest.mark.gpu
