@@ -11,6 +11,9 @@
 //!     `&Vec<(ID, ID)>` (`src/layer.rs:449-520`), `LayerBuilder` has the reference's knobs (`:619-696`).
 //! So `examples/main.rs:364-374, 410-459` (`clear -> extend -> par_sort -> par_scan` over
 //! `Bounds<Point2<f32>>`, `Index32_2D`, `with_min_depth(4)`) compiles against this crate by changing the `use`.
+//! With the `serde` feature `Layer`, the index types and `Bounds` serialize exactly like the reference's derives
+//! (`src/layer.rs:41-68`, `src/index.rs:68`, `src/geom.rs:83`), so `data/src/lib.rs:28-49` and
+//! `tests/test_layer.rs:19-124` keep compiling by changing the `use`.
 //! `ID` is `u32`.  Zero-copy access to the result rows is offered next to the reference's
 //! signature: `par_scan_rows() -> &[Pair]` (`#[repr(C)]`, the ABI's own layout).
 //!
@@ -18,6 +21,9 @@
 //! (`include/broadphase/layer.hpp`) has the same shape and IS built and run on the GPU:
 //! `tests/cpp/test_facade.cpp` ends with the example's frame loop written against it call for call.
 extern crate cgmath;
+#[cfg(feature = "serde")]
+#[macro_use]
+extern crate serde;
 
 use cgmath::{Array, EuclideanSpace, Point2, Point3, Vector2, Vector3};
 use std::cell::{Cell, UnsafeCell};
@@ -58,6 +64,8 @@ extern "C" {
                                   n: *mut usize) -> c_int;
     fn bp_layer_tree(layer: *mut BpLayer, keys: *mut *const u64, ids: *mut *const u32, m: *mut usize,
                      sorted: *mut c_int) -> c_int;
+    fn bp_layer_set_tree(layer: *mut BpLayer, min_depth: u32, keys: *const u64, ids: *const u32, m: usize, sorted: c_int) -> c_int;
+    fn bp_layer_min_depth(layer: *const BpLayer, min_depth: *mut u32) -> c_int;
     fn bp_layer_test_box_batch(layer: *mut BpLayer, sys_min: *const f32, sys_max: *const f32, boxes: *const f32,
                                n_queries: usize, has_max_depth: c_int, max_depth: u32, rows: *mut *const u32,
                                n_rows: *mut usize) -> c_int;
@@ -143,6 +151,7 @@ fn gather_axis(m: u64, axis_bits: u32, dim: u32) -> u32 {
 macro_rules! index_common {
     ($name:ident, $prim:ty, $dim:expr, $depth_bits:expr, $axis_bits:expr) => {
         #[derive(Clone, Copy, Default, Eq, Ord, PartialEq, PartialOrd, Hash)]
+        #[cfg_attr(feature = "serde", derive(Deserialize, Serialize))]  // src/index.rs:68: a newtype over the raw value
         #[repr(transparent)]
         pub struct $name(pub(crate) $prim);
 
@@ -251,6 +260,7 @@ impl SpatialIndex for Index64_3D {
 // Bounds<Point> (src/geom.rs:84-133): inclusive min / max over any cgmath point type
 // ---------------------------------------------------------------------------------------------------
 #[derive(Copy, Clone, Debug, PartialEq)]
+#[cfg_attr(feature = "serde", derive(Deserialize, Serialize))]  // src/geom.rs:83
 pub struct Bounds<Point> {
     pub min: Point,
     pub max: Point,
@@ -483,6 +493,78 @@ impl<Index: SpatialIndex> PartialEq for Layer<Index, u32> {
     }
 }
 impl<Index: SpatialIndex> Eq for Layer<Index, u32> {}
+
+// ---------------------------------------------------------------------------------------------------
+// serde (feature "serde"): the reference derives Serialize / Deserialize on Layer with every temporary skipped
+// (`src/layer.rs:41-68`), so the serialized form is exactly `min_depth: u32` + `tree: (Vec<(Index, ID)>, bool)` -- what
+// `data/src/lib.rs:28-49` stores in a BR_SCENE and what `tests/test_layer.rs:19-40` loads and compares.  Here the tree
+// lives in HBM: it is read through `bp_layer_tree` and written back through `bp_layer_set_tree`.
+// ---------------------------------------------------------------------------------------------------
+#[cfg(feature = "serde")]
+mod serde_impl {
+    use super::*;
+    use serde::de::{self, Deserialize, Deserializer, MapAccess, SeqAccess, Visitor};
+    use serde::ser::{Serialize, SerializeStruct, Serializer};
+
+    impl<Index> Serialize for Layer<Index, u32>
+    where
+        Index: SpatialIndex + Serialize,
+    {
+        fn serialize<S: Serializer>(&self, serializer: S) -> Result<S::Ok, S::Error> {
+            let mut min_depth = 0u32;
+            check(unsafe { bp_layer_min_depth(self.handle, &mut min_depth) }, self.handle);
+            let (mut k, mut i, mut m, mut sorted) = (std::ptr::null(), std::ptr::null(), 0usize, 0 as c_int);
+            check(unsafe { bp_layer_tree(self.handle, &mut k, &mut i, &mut m, &mut sorted) }, self.handle);
+            let (keys, ids) = unsafe { (std::slice::from_raw_parts(k, m), std::slice::from_raw_parts(i, m)) };
+            let tree: (Vec<(Index, u32)>, bool) =
+                (keys.iter().zip(ids.iter()).map(|(&key, &id)| (Index::from_raw(key), id)).collect(), sorted != 0);
+            let mut st = serializer.serialize_struct("Layer", 2)?;
+            st.serialize_field("min_depth", &min_depth)?;
+            st.serialize_field("tree", &tree)?;
+            st.end()
+        }
+    }
+
+    impl<'de, Index> Deserialize<'de> for Layer<Index, u32>
+    where
+        Index: SpatialIndex + Deserialize<'de>,
+    {
+        fn deserialize<D: Deserializer<'de>>(deserializer: D) -> Result<Self, D::Error> {
+            struct LayerVisitor<Index>(std::marker::PhantomData<Index>);
+            fn build<Index: SpatialIndex>(min_depth: u32, tree: (Vec<(Index, u32)>, bool)) -> Layer<Index, u32> {
+                let mut layer: Layer<Index, u32> = LayerBuilder::new().with_min_depth(min_depth).build();
+                let keys: Vec<u64> = tree.0.iter().map(|e| e.0.raw()).collect();
+                let ids: Vec<u32> = tree.0.iter().map(|e| e.1).collect();
+                check(unsafe { bp_layer_set_tree(layer.handle, min_depth, keys.as_ptr(), ids.as_ptr(), keys.len(), tree.1 as c_int) },
+                      layer.handle);
+                layer.touched();
+                layer
+            }
+            impl<'de, Index: SpatialIndex + Deserialize<'de>> Visitor<'de> for LayerVisitor<Index> {
+                type Value = Layer<Index, u32>;
+                fn expecting(&self, f: &mut std::fmt::Formatter) -> std::fmt::Result { f.write_str("struct Layer") }
+                fn visit_seq<A: SeqAccess<'de>>(self, mut seq: A) -> Result<Self::Value, A::Error> {  // bincode: positional
+                    let min_depth: u32 = seq.next_element()?.ok_or_else(|| de::Error::invalid_length(0, &self))?;
+                    let tree: (Vec<(Index, u32)>, bool) = seq.next_element()?.ok_or_else(|| de::Error::invalid_length(1, &self))?;
+                    Ok(build(min_depth, tree))
+                }
+                fn visit_map<A: MapAccess<'de>>(self, mut map: A) -> Result<Self::Value, A::Error> {  // self-describing formats
+                    let (mut min_depth, mut tree): (Option<u32>, Option<(Vec<(Index, u32)>, bool)>) = (None, None);
+                    while let Some(key) = map.next_key::<String>()? {
+                        match key.as_str() {
+                            "min_depth" => min_depth = Some(map.next_value()?),
+                            "tree" => tree = Some(map.next_value()?),
+                            _ => { let _: de::IgnoredAny = map.next_value()?; }
+                        }
+                    }
+                    Ok(build(min_depth.ok_or_else(|| de::Error::missing_field("min_depth"))?,
+                             tree.ok_or_else(|| de::Error::missing_field("tree"))?))
+                }
+            }
+            deserializer.deserialize_struct("Layer", &["min_depth", "tree"], LayerVisitor::<Index>(std::marker::PhantomData))
+        }
+    }
+}
 
 /// `LayerBuilder` (`src/layer.rs:619-696`)
 #[derive(Default)]
