@@ -152,10 +152,10 @@ def cpu_baseline(n_objects, seed):
 def kernel_table(n, M, P_raw, P):
     return {
         "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)", 28.0 * n + 12.0 * M),
-        "tree_sort": ("radix_onesweep_kernel<u64,u32> (tree-sort pass)", 24.0 * M),
+        "tree_sort": ("radix_claim_kernel<u32> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 24.0 * M),
         "tree_finish": ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
-        "pair_sort": ("radix_onesweep_kernel<u64,NoVal> (pair-sort pass)", 16.0 * P_raw),
+        "pair_sort": ("radix_claim_kernel<NoVal> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 16.0 * P_raw),
         "dedup": ("group_finish_kernel (LDS finish of the pair sort + dedup)", 8.0 * P_raw + 8.0 * P),
     }
 
@@ -547,7 +547,8 @@ def single_gpu_line(args, r, np):
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": per_launch_ms, "launches_per_step": dom_prof[1] / steps if dom_prof[1] else 0.0,
-                     "chosen_by": "largest total time per step over all kernel classes (warm-up pass with every class timed)",
+                     "chosen_by": "largest total time per step over all kernel classes (warm-up pass with every class timed); a radix class is "
+                                  "one launch per pass (two different kernels): achieved = bytes per pass / the passes' mean duration",
                      "bytes_model": "SURVEY.md 8(d) per-unit figures x this run's N / M / P_raw / P"},
         "cold_frame_ms": r["cold_frame_ms"], "first_frame_ms": r["first_frame_ms"], "cold_plan": r["cold_plan"],
         "cold_note": "cold_frame_ms: buffers allocated, plan hints forgotten (the plan of a layer's first frame); first_frame_ms: a "
@@ -577,10 +578,14 @@ def single_gpu_line(args, r, np):
     # (profiles/traffic.json, written by profiles/summarize.py with the guide's gfx950 corrections); null when absent
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = dom_name.split(" ")[0].split("<")[0]
-        want_noval = "NoVal" in dom_name
-        hit = [v for kk, v in tj.get("bytes_per_launch", {}).items()
-               if kk.startswith(key) and (("NoVal" in kk) == want_noval or "radix" not in key)]
+        # the class may run several kernels per step ("a + b (...)"): the launches' traffic averages like their durations do
+        names = [t.strip() for t in dom_name.split(" (")[0].split(" + ")]
+        hit = []
+        for nm in names:
+            key = nm.split("<")[0]
+            want_noval = "NoVal" in nm
+            hit += [v for kk, v in tj.get("bytes_per_launch", {}).items()
+                    if kk.startswith(key) and (("NoVal" in kk) == want_noval or "radix" not in key)]
         if hit and tj.get("objects") == n:
             line["roofline"]["traffic"] = sum(hit) / len(hit)   # the two instantiations of a radix pass (first pass / later passes) average
             line["roofline"]["traffic_source"] = tj.get("source")

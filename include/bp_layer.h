@@ -17,7 +17,14 @@
  *     stream, call bp_layer_wait_stream(layer, that_stream) first (or synchronise that stream);
  *   - returned pointers are BORROWED: valid until the next mutating call on the same handle
  *     (the reference returns `&'a Vec<(ID, ID)>` tied to `&'a mut self`, src/layer.rs:449-451);
- *   - ID is u32.  Index values travel as u64 for every index kind (Index32_2D is zero-extended);
+ *   - ID is u32, by decision.  The reference's `ObjectID` (src/traits.rs:6-16) admits any `Copy + Hash + Ord` type; the only
+ *     ID the reference itself instantiates on this path is u32 (`data/src/lib.rs:16`, the example's entity ids), and every
+ *     byte of the pair side -- 57 % of a frame -- doubles with u64 ids (pairs are sorted as one packed 64-bit word here).  A host
+ *     with wider ids keeps a u32 -> ID table on its side (ids are dense per frame in the reference's use).  Two id ranges cost
+ *     time, never correctness: ids >= 2^27 (the 5 spare payload bits then cannot carry the box codes through the tree sort, so
+ *     duplicates are removed after the pair sort as in the reference: about 2 x the frame time) and ids that repeat across
+ *     objects (the reference's skip rule, src/layer.rs:563-565).  Index values travel as u64 for every index kind
+ *     (Index32_2D is zero-extended);
  *   - no CPU fallback exists: without a usable HIP device every call fails with BP_ERR_NO_DEVICE.
  */
 #ifndef BP_LAYER_H
