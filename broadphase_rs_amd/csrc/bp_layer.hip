@@ -40,6 +40,7 @@ struct bp_layer {
     uint32_t min_depth = 0;
     hipStream_t stream = nullptr;
     hipEvent_t fence_ev = nullptr;   // bp_layer_wait_stream: orders this layer's stream after a producer's
+    hipEvent_t early_ev = nullptr;   // extend on predicted sizes: the scalars' copy, waited for while encode_emit already runs
 
     // persistent state: tree (src/layer.rs:49-50)
     DevBuf keys[2], ids[2];
@@ -442,6 +443,17 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
                                           (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS,
                                           count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, cell_bytes / sizeof(unsigned long long)));
     }
+    // The entry total and the facts are final once the block sums are scanned: their copy is enqueued BEFORE encode_emit and
+    // the host waits for that copy alone (an event), while encode_emit is already running behind it -- the round trip costs
+    // the GPU no idle time, and the sort's kernels queue up behind the emit pass.  (The emit pass's own capacity guard is
+    // evaluated on the host from the same total.)
+    static const bool no_early = getenv("BP_NO_EARLY_FETCH") != nullptr;  // A/B switch
+    const bool early = !no_early && !count_cells;
+    if (early) {
+        if (!L->early_ev && hipEventCreateWithFlags(&L->early_ev, hipEventDisableTiming) != hipSuccess) return fail(L, BP_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+        HIP_TRY(L, hipEventRecord(L->early_ev, L->stream));
+    }
     {
         ProfScope ps(L, BP_K_ENCODE);
         HIP_TRY(L, launch_encode_emit(L->kind, sb, d_bounds, d_ids, n, L->min_depth, L->counts.p,
@@ -461,7 +473,16 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
         HIP_TRY(L, hipMemcpyAsync(L->h_cells.p, L->cell_sum.p, n_cellbins * sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream));
     }
     DevScalars sc;
-    BP_TRY(sc_fetch(L, &sc));
+    if (early) {
+        ++L->stats.host_syncs;  // a host round trip all the same (the GPU stays busy through it)
+        HIP_TRY(L, hipEventSynchronize(L->early_ev));
+        sc = *(const DevScalars*)L->h_sc.p;
+        if (sc.err & KERR_COUNT_OVERFLOW)
+            return fail(L, BP_ERR_TOO_LARGE, "an object expands to more than 2^20 cells (min_depth too high for its size)");
+        if ((size_t)sc.total > capacity) sc.err |= KERR_ENCODE_OVERFLOW;  // what the emit pass's guard concludes from the same total
+    } else {
+        BP_TRY(sc_fetch(L, &sc));
+    }
     const size_t add = (size_t)sc.total;
     const bool can_pack = !(sc.flags & EXT_IDS_REPEAT) && (sc.id_or >> BOX_ID_BITS) == 0;
     if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack)) {
@@ -1700,6 +1721,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);
+    if (L->early_ev) (void)hipEventDestroy(L->early_ev);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
