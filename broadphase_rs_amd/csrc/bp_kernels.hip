@@ -3045,7 +3045,9 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 // the claiming first pass (radix_claim_kernel): one persistent workgroup per CU
 template <typename V>
 static hipError_t launch_claim(const ClaimArgs& a, hipStream_t stream) {
+#ifndef RS_GEOMETRY_EXPERIMENT
     static_assert(RC_TILE == RS_THREADS_DEF * RS_ITEMS_DEF, "the pass kernels share the tile size (holes, workspace)");
+#endif
     static const unsigned resident = resident_blocks(radix_claim_kernel<V>, RC_THREADS);
     const unsigned grid = a.n_tiles < resident ? a.n_tiles : resident;
     radix_claim_kernel<V><<<grid, RC_THREADS, 0, stream>>>(a);
