@@ -988,7 +988,7 @@ constexpr int RC_THREADS = 1024, RC_ITEMS = 8, RC_TILE = RC_THREADS * RC_ITEMS, 
 constexpr int RC_LINE = 16;                                    // records per 128-byte line of keys
 constexpr int RC_CARRY_MAX = RS_BINS * (RC_LINE - 1);          // records a workgroup can carry between tiles
 constexpr int RC_STAGE = RC_TILE + RC_CARRY_MAX;               // a tile's records + the carried ones
-constexpr int RC_OUT_ITERS = (RC_STAGE + RC_THREADS - 1) / RC_THREADS;
+constexpr int RC_OUT_ITERS = (RC_STAGE / 2 + RC_THREADS - 1) / RC_THREADS;  // output iterations: two records per thread
 constexpr size_t SW_CURSOR_WORDS = 16 * (size_t)RS_CUR_STRIDE;  // one set of 256 cursors
 __host__ __device__ __forceinline__ u32 sw_cursor_slot(u32 d) { return (d >> 4) * (u32)RS_CUR_STRIDE + (d & 15u); }
 static_assert(RC_TILE == 8192, "the pass kernels share the tile size (holes, workspace)");
@@ -1210,21 +1210,25 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         }
         __syncthreads();
 
-        // ---- stream the lines out: 16 consecutive threads write one aligned 128-byte line ----------------------------
+        // ---- stream the lines out: 8 consecutive threads write one aligned 128-byte line, TWO records (16 bytes) per thread --
+        // the phase is store-ISSUE bound (s_memtime stamps: 17 % of a tile's time with 8-byte stores), and a line's records are
+        // consecutive in the stage, so a thread takes an even / odd pair of one line: half the store, LDS-read and base-lookup
+        // instructions.  (A line starts at an even stage slot and at a 128-byte aligned address: both halves of the pair
+        // belong to one bin and the 16-byte store is aligned.)
         const bool any_over = s_over != 0u;
-        u32 odg[HAS_VAL ? (RC_OUT_ITERS + 3) / 4 : 1];  // the written records' digits, one byte each (payload phase)
+        u32 odg[HAS_VAL ? (RC_OUT_ITERS + 3) / 4 : 1];  // the written pairs' digits, one byte each (payload phase)
         const u32 otid = opaque((u32)tid);
 #pragma unroll
         for (int k = 0; k < RC_OUT_ITERS; ++k) {
-            const u32 li = (u32)k * T + otid;
+            const u32 li = 2u * ((u32)k * T + otid);
             if constexpr (HAS_VAL) { if (k % 4 == 0) odg[k / 4] = 0u; }
             if (li < f_total) {
-                const K kk = s_stage[li];
-                const u32 dg = digit(kk);
+                const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_stage[li]);
+                const u32 dg = digit(kk.x);
                 if constexpr (HAS_VAL) odg[k / 4] |= dg << (8 * (k % 4));
                 const u32 g = s_glob[dg] + li;
                 if (!any_over || g < s_lim[dg]) {
-                    if (SW_EXP != 1) keys_out[g] = kk;
+                    if (SW_EXP != 1) *reinterpret_cast<ulonglong2*>(keys_out + g) = kk;
                 }
             }
             if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
@@ -1264,11 +1268,14 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < RC_OUT_ITERS; ++k) {
-                const u32 li = (u32)k * T + otid;
+                const u32 li = 2u * ((u32)k * T + otid);
                 if (li < f_total) {
                     const u32 dg = (odg[k / 4] >> (8 * (k % 4))) & 0xFFu;
                     const u32 g = s_glob[dg] + li;
-                    if (!any_over || g < s_lim[dg]) vals_out[g] = stage_v[li];
+                    if (!any_over || g < s_lim[dg]) {
+                        if constexpr (sizeof(V) == 4) *reinterpret_cast<uint2*>(vals_out + g) = *reinterpret_cast<const uint2*>(&stage_v[li]);
+                        else { vals_out[g] = stage_v[li]; vals_out[g + 1] = stage_v[li + 1]; }
+                    }
                 }
                 if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             }
