@@ -448,9 +448,17 @@ def main():
             cnt += k
         info = sharded.last if hasattr(sharded, "last") else layers[order].last
         route = info.get("pair_order", order) if isinstance(info, dict) else order
+        # load balance over the ranks (entries of the shard, pairs its scan emitted, pairs it returns): max / mean
+        mine = torch.tensor([float(info.get("entries_shard", 0)), float(info.get("raw_pairs", 0)), float(n_pairs_local)] if isinstance(info, dict)
+                            else [0.0, 0.0, float(n_pairs_local)], dtype=torch.float64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every)
+        imbalance = {k: (float(every[:, j].max() / every[:, j].mean()) if float(every[:, j].mean()) > 0 else None)
+                     for j, k in enumerate(("entries_shard", "raw_pairs", "pairs"))}
         return {"pair_order": route, "ms_per_step": dt / args.steps * 1e3, "pairs_total": cnt, "value": cnt / (dt / args.steps),
                 "pairs_this_rank": n_pairs_local, "list_hash": [cnt, s1, s2] if route == "global" else None, "set_hash": [cnt, s1, q2],
-                "stages": info}
+                "stages": info, "imbalance_max_over_mean": imbalance}
 
     main_rec = measure(args.pair_order)
     other = "global" if args.pair_order == "local" else "local"
@@ -479,7 +487,7 @@ def main():
             "roofline": None, "cpu_baseline": None,
             "objects_per_s": n_global / (main_rec["ms_per_step"] * 1e-3),
             "list_hash": main_rec["list_hash"], "set_hash": main_rec["set_hash"],
-            "sharded": main_rec["stages"],
+            "sharded": main_rec["stages"], "imbalance_max_over_mean": main_rec["imbalance_max_over_mean"],
         }
         if other_rec is not None:
             line["pair_order_" + other] = {"ms_per_step": other_rec["ms_per_step"], "value": other_rec["value"], "pairs_total": other_rec["pairs_total"],

@@ -190,7 +190,8 @@ struct ScanParams {
     size_t m;
     uint32_t depth_mask;    // present depths
     uint32_t coarse_depth;  // shard mode: entries with depth < coarse_depth are "coarse"
-    int emit_coarse;        // emit pairs whose deeper entry is coarse
+    int emit_coarse;        // pairs whose deeper entry is coarse: 0 never emitted here, 1 always, 2 when the deeper entry's id lies in
+    uint32_t coarse_id_lo, coarse_id_hi;  // ... [coarse_id_lo, coarse_id_hi] (the rank's first-id range)
     int general;            // ids may repeat: apply the reference's skip rule exactly
     uint8_t* skip;          // [m] general mode only
     const uint8_t* box;     // [m] per-entry cell-box code (BOX_*), or nullptr: emit every raw pair
@@ -235,7 +236,8 @@ constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 bool scan_can_count(const RadixPlan& plan);  // launch_scan_expand counts the digits of this plan (hist_plan / hist) iff true
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
-                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream);
+                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream, uint32_t active_lo = 1, uint32_t active_hi = 0);
+// active_lo .. active_hi: ids whose entries stay active below inactive_below (lo > hi: none)
 // scalars := init, blockfill[0..n_blocks) := 0, shards[0..n_shard_words) := 0, hist[0..n_hist_words) := 0 (hist may be null)
 hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t* blockfill, size_t n_blocks, uint64_t* shards,
                                uint32_t n_shard_words, unsigned long long* hist, uint32_t n_hist_words, hipStream_t stream);

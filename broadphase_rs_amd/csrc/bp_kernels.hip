@@ -21,6 +21,12 @@ typedef unsigned int u32;
 
 constexpr u32 MAX_CELLS_PER_OBJECT = 1u << 20;
 
+// shard scans: does a COARSE entry (depth < coarse_depth, replicated on every rank) act as the deeper side of a pair here?
+// emit_coarse 0: never, 1: always, 2: when its id lies in [coarse_id_lo, coarse_id_hi] (the rank's first-id range)
+__device__ __forceinline__ bool coarse_emits(const ScanParams& p, u32 id) {
+    return p.emit_coarse == 1 || (p.emit_coarse == 2 && id >= p.coarse_id_lo && id <= p.coarse_id_hi);
+}
+
 // =================================================================================================
 // encode: Layer::extend (src/layer.rs:94-121)
 // =================================================================================================
@@ -1528,7 +1534,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_count_kernel(ScanParams p, 
     u32 cnt = 0;
     if (gi < p.m) {
         const u64 key = p.keys[i];
-        bool active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        bool active = key_depth<KIND>(key) >= p.coarse_depth || coarse_emits(p, p.ids[i]);
         if (GENERAL) active = active && !p.skip[i];
         if (active) {
             if (GENERAL) {
@@ -1649,7 +1655,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
     bx.earlier = 0;
     if (gi < p.m) {
         key = p.keys[i];
-        active = key_depth<KIND>(key) >= p.coarse_depth || p.emit_coarse;
+        active = key_depth<KIND>(key) >= p.coarse_depth || coarse_emits(p, p.ids[i]);
         if (active) {
             hi_id = (u64)p.ids[i] << 32;
             if (p.box) bx.init(key, p.box[i]);
@@ -1839,16 +1845,20 @@ __device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 dj, u32 cbj) {
     return ((ctx_i >> (24u + idx)) & 1u) == 0u;
 }
 
+// active_lo / active_hi: entries of depth < inactive_below whose id lies in this range stay active all the same (shard
+// scans: coarse-coarse pairs are emitted by the rank that owns the deeper entry's id); lo > hi: no such range
 template <int KIND>
 __global__ __launch_bounds__(256) void entry_ctx_kernel(const u64* __restrict__ keys, const u32* __restrict__ ids,
                                                         const uint8_t* __restrict__ box, size_t m, u32 inactive_below,
-                                                        u64* __restrict__ idctx) {
+                                                        u64* __restrict__ idctx, u32 active_lo, u32 active_hi) {
     __shared__ u32 s_lut[CTX_LUT_WORDS];
     ctx_lut_load(s_lut);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const u32 code = box ? (u32)box[i] : (u32)BOX_UNKNOWN;
-    idctx[i] = ((u64)ids[i] << 32) | (u64)entry_ctx_lut<KIND>(keys[i], box_to_packed(code), inactive_below, s_lut);
+    const u32 id = ids[i];
+    const u32 thr = (id >= active_lo && id <= active_hi) ? 0u : inactive_below;
+    idctx[i] = ((u64)id << 32) | (u64)entry_ctx_lut<KIND>(keys[i], box_to_packed(code), thr, s_lut);
 }
 
 constexpr int SX_THREADS = 256;
@@ -3342,13 +3352,13 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 }
 
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,
-                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream) {
+                            uint32_t inactive_below, uint64_t* idctx, hipStream_t stream, uint32_t active_lo, uint32_t active_hi) {
     if (m == 0) return hipSuccess;
     const unsigned g = (unsigned)((m + 255) / 256);
     switch (kind) {
-        case 0: entry_ctx_kernel<0><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
-        case 1: entry_ctx_kernel<1><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
-        default: entry_ctx_kernel<2><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx); break;
+        case 0: entry_ctx_kernel<0><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx, active_lo, active_hi); break;
+        case 1: entry_ctx_kernel<1><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx, active_lo, active_hi); break;
+        default: entry_ctx_kernel<2><<<g, 256, 0, stream>>>((const u64*)keys, ids, box, m, inactive_below, (u64*)idctx, active_lo, active_hi); break;
     }
     return hipGetLastError();
 }

@@ -102,6 +102,9 @@ struct bp_layer {
     uint64_t epoch = 1;                 // bumped whenever the sorted tree's content may have changed
     uint64_t ctx_epoch = 0;             // epoch idctx was computed for (0: never), with ...
     uint32_t ctx_thr = 0;               // ... entries of depth < ctx_thr inactive and ...
+    uint32_t ctx_lo = 1, ctx_hi = 0;    // ... except those whose id lies in [ctx_lo, ctx_hi] (lo > hi: none) ...
+    // shard scans with emit_coarse == 2: coarse entries act as the deeper side iff their id lies in this range
+    uint32_t coarse_lo = 1, coarse_hi = 0;
     bool ctx_box = false;               // ... the box codes in use
 
     bp_stats stats{};
@@ -898,7 +901,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
             // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
             L->cur = dst;
             L->box_valid = ride;
-            if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; }
+            if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0; }
             L->ids_packed = false;
             L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride;
             static const bool no_defer = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
@@ -1005,6 +1008,7 @@ int scan_raw_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool so
     p.depth_mask = L->depth_mask;
     p.coarse_depth = coarse_depth;
     p.emit_coarse = emit_coarse;
+    p.coarse_id_lo = L->coarse_lo; p.coarse_id_hi = L->coarse_hi;
     p.general = L->ids_distinct ? 0 : 1;
     p.skip = nullptr;
     p.filt_bounds = nullptr;
@@ -1376,6 +1380,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.depth_mask = L->depth_mask;
     p.coarse_depth = coarse_depth;
     p.emit_coarse = emit_coarse;
+    p.coarse_id_lo = L->coarse_lo; p.coarse_id_hi = L->coarse_hi;
     p.general = 0;
     p.skip = nullptr;
     p.filt_bounds = filt_bounds;
@@ -1387,13 +1392,15 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     bool expand = !no_expand;
     if (expand) {
         // per-entry {id, suppression context} words; recomputed only when the tree or the mode changed
-        const uint32_t thr = emit_coarse ? 0u : coarse_depth;
+        const uint32_t thr = emit_coarse == 1 ? 0u : coarse_depth;
+        // emit_coarse == 2: coarse entries whose id lies in the layer's range stay active (an empty range otherwise)
+        const uint32_t alo = (emit_coarse == 2 && thr) ? L->coarse_lo : 1u, ahi = (emit_coarse == 2 && thr) ? L->coarse_hi : 0u;
         const bool with_box = p.box != nullptr;
-        if (L->ctx_epoch != L->epoch || L->ctx_thr != thr || L->ctx_box != with_box) {
+        if (L->ctx_epoch != L->epoch || L->ctx_thr != thr || L->ctx_box != with_box || L->ctx_lo != alo || L->ctx_hi != ahi) {
             BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             ProfScope ps(L, BP_K_SCAN_COUNT);
-            HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), p.box, L->m, thr, (uint64_t*)L->idctx.p, L->stream));
-            L->ctx_epoch = L->epoch; L->ctx_thr = thr; L->ctx_box = with_box;
+            HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), p.box, L->m, thr, (uint64_t*)L->idctx.p, L->stream, alo, ahi));
+            L->ctx_epoch = L->epoch; L->ctx_thr = thr; L->ctx_box = with_box; L->ctx_lo = alo; L->ctx_hi = ahi;
         }
         size_t big_cap = std::max<size_t>(65536, L->m / 16);
         if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));  // test hook: force the overflow fallback
@@ -1506,12 +1513,13 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
     L->owner_hist_valid = false;
     if (L->m == 0) { *done = 1; return BP_OK; }
     if (L->m >= 0xFFFFFFFFull) return fail(L, BP_ERR_TOO_LARGE, "scan: more than 2^32-1 index entries");
-    const uint32_t thr = emit_coarse ? 0u : coarse_depth;
+    const uint32_t thr = emit_coarse == 1 ? 0u : coarse_depth;
     BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
     L->ctx_epoch = 0;  // the words below carry skip marks, not suppression contexts
     {
         ProfScope ps(L, BP_K_SCAN_COUNT);
-        HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), nullptr, L->m, thr, (uint64_t*)L->idctx.p, L->stream));
+        HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), nullptr, L->m, thr, (uint64_t*)L->idctx.p, L->stream,
+                                    (emit_coarse == 2 && thr) ? L->coarse_lo : 1u, (emit_coarse == 2 && thr) ? L->coarse_hi : 0u));
     }
     size_t big_cap = std::max<size_t>(65536, L->m / 16);
     if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));
@@ -2441,6 +2449,12 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     DevScalars sc;
     BP_TRY(sc_fetch(L, &sc));
     for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = ((const unsigned long long*)L->h_raw.p)[i];
+    return BP_OK;
+}
+
+int bp_layer_set_coarse_emit_range(bp_layer_t* L, uint32_t id_lo, uint32_t id_hi) {
+    if (!L) return BP_ERR_INVALID_ARG;
+    L->coarse_lo = id_lo; L->coarse_hi = id_hi;
     return BP_OK;
 }
 

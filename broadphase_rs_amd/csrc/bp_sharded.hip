@@ -807,7 +807,15 @@ int bp_sharded_par_scan(bp_sharded_t* s, int pair_order, const uint32_t** d_pair
     std::vector<uint32_t> bounds(std::max(1, G - 1), 0xFFFFFFFFu);   // G - 1 bounds are used (never an empty vector: its data() is null)
     const uint32_t n_bounds = (uint32_t)(G - 1);
     for (int r = 0; r + 1 < G; ++r) bounds[r] = (uint32_t)std::min<uint64_t>(span * (uint64_t)(r + 1), 0xFFFFFFFFull);
-    const int emit_coarse = rank == 0 ? 1 : 0;
+    // pairs between two boundary entries (replicated on every rank) are emitted by the rank that owns the deeper entry's id
+    // -- the first id of the pair, so on the GLOBAL route they are already where they belong -- instead of by rank 0 alone:
+    // in a heavy-tailed scene (configs[4]) they are a large share of the pairs
+    const uint32_t own_lo = rank == 0 ? 0u : bounds[rank - 1];
+    const uint32_t own_hi = rank == G - 1 ? 0xFFFFFFFFu : (bounds[rank] == 0 ? 0u : bounds[rank] - 1u);
+    const bool own_empty = rank != G - 1 && (bounds[rank] == 0 || bounds[rank] <= own_lo);
+    static const bool coarse_rank0 = getenv("BP_SHARDED_COARSE_RANK0") != nullptr;  // A/B: the round-2 behaviour
+    const int emit_coarse = (G == 1 || coarse_rank0) ? (rank == 0 ? 1 : 0) : 2;
+    if (emit_coarse == 2) L_TRY(s, s->shard, bp_layer_set_coarse_emit_range(s->shard, own_empty ? 1u : own_lo, own_empty ? 0u : own_hi));
     // LOCAL order: possible while every shard suppresses its duplicates at the source -- box codes known for every entry and
     // ids provably distinct, facts every rank holds alike, so the route is decided without another exchange
     static const bool no_source_dedup = getenv("BP_NO_SOURCE_DEDUP") != nullptr;  // the layers' measurement switch

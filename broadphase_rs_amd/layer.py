@@ -78,6 +78,7 @@ EXPORTS = [
     "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
+    "bp_layer_set_coarse_emit_range",
     "bp_layer_set_cell_histogram_depth",
     "bp_layer_test_box_batch", "bp_layer_test_box_batch_device", "bp_layer_test_ray_batch", "bp_layer_test_ray_batch_device",
     "bp_layer_pick_ray_aabb_batch",
@@ -178,6 +179,7 @@ def load_library():
     L.bp_layer_partition_entries_device.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, u64p,
                                                     C.POINTER(vp), C.POINTER(vp)]
     L.bp_layer_scan_raw_shard_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), szp]
+    L.bp_layer_set_coarse_emit_range.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.bp_layer_can_pack_box.argtypes = [vp, ip]
     L.bp_layer_partition_entries_packed_device.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32,
                                                            C.c_int, u64p, C.POINTER(vp), C.POINTER(vp)]
@@ -536,7 +538,7 @@ class Layer:
 
     def scan_shard_device(self, coarse_depth, emit_coarse):
         p, n = C.c_void_p(), C.c_size_t()
-        self._check(self._L.bp_layer_scan_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+        self._check(self._L.bp_layer_scan_shard_device(self._h, coarse_depth, int(emit_coarse), C.byref(p),
                                                        C.byref(n)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self)
 
@@ -633,22 +635,26 @@ class Layer:
         m = len(self)
         return counts, DeviceArray(k.value, (m,), np.uint64, self), DeviceArray(i.value, (m,), np.uint32, self)
 
+    def set_coarse_emit_range(self, id_lo, id_hi):
+        """shard scans with emit_coarse = 2: coarse entries act as the deeper side of a pair iff id_lo <= id <= id_hi"""
+        self._check(self._L.bp_layer_set_coarse_emit_range(self._h, int(id_lo), int(id_hi)))
+
     def scan_raw_shard_device(self, coarse_depth, emit_coarse):
         p, n = C.c_void_p(), C.c_size_t()
-        self._check(self._L.bp_layer_scan_raw_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p), C.byref(n)))
+        self._check(self._L.bp_layer_scan_raw_shard_device(self._h, coarse_depth, int(emit_coarse), C.byref(p), C.byref(n)))
         return DeviceArray(p.value, (n.value,), np.uint64, self)
 
     def scan_shard_pairs_device(self, coarse_depth, emit_coarse):
         """(packed raw pairs in arbitrary order, duplicates-already-suppressed flag)"""
         p, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
-        self._check(self._L.bp_layer_scan_shard_pairs_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+        self._check(self._L.bp_layer_scan_shard_pairs_device(self._h, coarse_depth, int(emit_coarse), C.byref(p),
                                                              C.byref(n), C.byref(u)))
         return DeviceArray(p.value, (n.value,), np.uint64, self), bool(u.value)
 
     def par_scan_shard_device(self, coarse_depth, emit_coarse):
         """(this shard's sorted duplicate-free pairs, no-other-shard-holds-them flag)"""
         p, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
-        self._check(self._L.bp_layer_par_scan_shard_device(self._h, coarse_depth, 1 if emit_coarse else 0, C.byref(p),
+        self._check(self._L.bp_layer_par_scan_shard_device(self._h, coarse_depth, int(emit_coarse), C.byref(p),
                                                            C.byref(n), C.byref(u)))
         return DeviceArray(p.value, (n.value, 2), np.uint32, self), bool(u.value)
 
@@ -658,7 +664,7 @@ class Layer:
         counts = np.zeros(len(bounds) + 1, dtype=np.uint64)
         out, n, u = C.c_void_p(), C.c_size_t(), C.c_int()
         self._check(self._L.bp_layer_scan_shard_partition_device(
-            self._h, coarse_depth, 1 if emit_coarse else 0, bounds.ctypes.data_as(C.POINTER(C.c_uint32)), len(bounds),
+            self._h, coarse_depth, int(emit_coarse), bounds.ctypes.data_as(C.POINTER(C.c_uint32)), len(bounds),
             counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(out), C.byref(n), C.byref(u)))
         return counts, DeviceArray(out.value, (n.value,), np.uint64, self), bool(u.value)
 

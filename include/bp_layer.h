@@ -169,10 +169,14 @@ int bp_layer_device(const bp_layer_t *layer, int *device);
 
 /* ---- multi-GPU support (one process per GPU; the exchange itself is RCCL via the host side) --- */
 /* Scan variant for a Morton-range shard: entries whose depth is < coarse_depth are replicated on
- * every rank; pairs whose deeper entry is such a coarse entry are emitted only when emit_coarse
- * is non-zero (exactly one rank sets it), so the union over ranks is the single-GPU raw set. */
+ * every rank; pairs whose deeper entry is such a coarse entry must be emitted by exactly ONE rank, so that
+ * the union over ranks is the single-GPU raw set.  emit_coarse (this and every *_shard_* call below):
+ *   0  this rank emits none of them,   1  all of them (one designated rank),
+ *   2  those whose deeper entry's id lies in [id_lo, id_hi] as set by bp_layer_set_coarse_emit_range -- the ranks' ranges
+ *      partition the ids, so the coarse-coarse pairs of a heavy-tailed scene spread over the ranks instead of landing on one. */
 int bp_layer_scan_shard_device(bp_layer_t *layer, uint32_t coarse_depth, int emit_coarse,
                                const uint32_t **d_pairs, size_t *n_pairs);
+int bp_layer_set_coarse_emit_range(bp_layer_t *layer, uint32_t id_lo, uint32_t id_hi);
 /* Sort + dedup an arbitrary device-resident list of n (id, id_) pairs (interleaved u32) in place
  * semantics of collisions.sort_unstable(); collisions.dedup() (src/layer.rs:473-474, 516-517). */
 int bp_layer_sort_unique_pairs_device(bp_layer_t *layer, const uint32_t *d_pairs_in, size_t n,

@@ -236,6 +236,14 @@ def test_c_sharded_local_pair_order_is_a_disjoint_cover(world, giants):
     exp = (expect[:, 0].astype(np.uint64) << np.uint64(32)) | expect[:, 1].astype(np.uint64)
     assert np.array_equal(allp, exp)
     assert len({results[r][1]["pair_order"] for r in range(world)}) == 1
+    if giants:
+        # pairs between two boundary entries (both objects are giants, replicated on every rank) are emitted by the rank that
+        # owns the first id's range, not by rank 0 alone: with giants on every rank, every rank emits some
+        n = len(parts[0][2])
+        giant_ids = np.concatenate([np.arange(3, dtype=np.uint32) + np.uint32(r * n) for r in range(world)])
+        emitters = [r for r in range(world)
+                    if np.any(np.isin(results[r][0][:, 0], giant_ids) & np.isin(results[r][0][:, 1], giant_ids))]
+        assert len(emitters) == world, emitters
 
 
 @pytest.mark.gpu
