@@ -338,6 +338,11 @@ def main():
         return
 
     # ---- N > 1 (or --sharded rehearsal): Morton-range shards over torch.distributed ---------------------------
+    # librccl prints a version banner straight to file descriptor 1 when a communicator is created: keep stdout for the one
+    # JSON line (everything until then goes to stderr)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch.distributed as dist
     dist_backend = os.environ.get("BP_DIST_BACKEND", "nccl")
     if world == 1:
@@ -493,7 +498,10 @@ def main():
             line["pair_order_" + other] = {"ms_per_step": other_rec["ms_per_step"], "value": other_rec["value"], "pairs_total": other_rec["pairs_total"],
                                            "pair_order": other_rec["pair_order"], "note": order_note[other_rec["pair_order"]],
                                            "list_hash": other_rec["list_hash"], "set_hash": other_rec["set_hash"], "sharded": other_rec["stages"]}
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     dist.barrier()
     dist.destroy_process_group()
 
