@@ -86,6 +86,10 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float f) {
 // ---- wave64 primitives --------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// wave-wide vote straight from the compare's lane mask (HIP's __ballot takes an int: the bool is first materialised as
+// 0 / 1 in a VGPR and compared again -- two VALU instructions per vote in the hot loops)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // wave-uniform value -> SGPR.  (__builtin_amdgcn_readfirstlane returns int: without the cast back to
 // unsigned a 64-bit composition sign-extends its low half.)
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }

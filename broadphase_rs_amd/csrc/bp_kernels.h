@@ -232,7 +232,7 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 #endif
 constexpr uint32_t SX_BLOCK = SX_BLOCK_DEF;
 constexpr int SX_SHARDS = 64;
-constexpr uint32_t SX_RESERVE = 4;  // output blocks a wave reserves per atomic
+constexpr uint32_t SX_RESERVE = 1024 / SX_BLOCK;  // output blocks a wave reserves per atomic (1024 pairs)
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 bool scan_can_count(const RadixPlan& plan);  // launch_scan_expand counts the digits of this plan (hist_plan / hist) iff true
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,

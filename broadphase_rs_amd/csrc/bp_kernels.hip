@@ -781,12 +781,12 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
         for (int r = 0; r < RS_ITEMS; ++r) {
             const bool valid = (vmask >> r) & 1u;
             const u32 dg = digit(key[r]);
-            u64 todo = __ballot(valid);
+            u64 todo = ballot64(valid);
             u32 pos = 0;
             while (todo) {  // wave-uniform: one trip per distinct digit of the round
                 const int leader = __builtin_ctzll(todo);
                 const u32 d0 = (u32)__builtin_amdgcn_readlane((int)dg, leader);
-                const u64 m = __ballot(valid && dg == d0);
+                const u64 m = ballot64(valid && dg == d0);
                 const u32 cnt = s_cnt[w][d0];  // same address for the whole wave: a broadcast read
                 if (valid && dg == d0) pos = cnt + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
                 __builtin_amdgcn_wave_barrier();
@@ -1861,9 +1861,25 @@ __global__ __launch_bounds__(256) void entry_ctx_kernel(const u64* __restrict__ 
     idctx[i] = ((u64)id << 32) | (u64)entry_ctx_lut<KIND>(keys[i], box_to_packed(code), thr, s_lut);
 }
 
+// SX_STAMPS (diagnostic builds only, tools/ab.sh build stamps "-DSX_STAMPS"): where a scanning wave's time goes, summed over the
+// waves in s_memtime ticks -- read back with bp_debug_sx_stamps
+#ifdef SX_STAMPS
+__device__ unsigned long long g_sx_stamps[16];
+__device__ unsigned long long g_sx_wave[8192][4];  // per wave of the last launch: loop ticks, steps << 32 | chunks, HW_ID | XCC_ID << 32, start tick
+#if SX_STAMPS_LIGHT  // only the begin / end of a wave's chunk loop (the per-phase stamps slow the loop down)
+#define SX_T(var) const u64 var = 0
+#define SX_ACC(slot, v) sx_acc[slot] += (slot == 5 || slot == 6) ? (v) : 0
+#else
+#define SX_T(var) const u64 var = __builtin_readcyclecounter()
+#define SX_ACC(slot, v) sx_acc[slot] += (v)
+#endif
+#else
+#define SX_T(var)
+#define SX_ACC(slot, v)
+#endif
 constexpr int SX_THREADS = 256;
 constexpr int SX_WAVES = SX_THREADS / 64;
-constexpr u32 SX_STAGE = 2 * SX_BLOCK;  // per-wave LDS ring: two output blocks
+constexpr u32 SX_STAGE = SX_BLOCK + 128;  // per-wave LDS stage: one output block and the most one push can add to it
 constexpr u32 SX_BIG = 16384;           // ranges at least this long go to the work list, in slices of this size
 static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
 
@@ -1947,24 +1963,25 @@ template <int KIND> __device__ __forceinline__ u64 cell_upper(u64 key) {
 
 // Per-wave output stage.  One device-scope atomic on ONE address costs ~11 ns of serialised service
 // (88 / us for the whole chip), which at one reservation per ~500 pairs was 3/4 of this kernel's
-// time.  So the output is block-structured: a wave stages pairs in an LDS ring of two SX_BLOCK-pair
-// halves and writes every completed half as one whole block; blocks are handed out by SX_SHARDS
+// time.  So the output is block-structured: a wave stages pairs in LDS (a linear buffer: pushes append, a full
+// block leaves from the front and the few pairs behind it move down) and writes SX_BLOCK of them as one whole block; blocks are handed out by SX_SHARDS
 // independent cursors (shard s owns blocks s, s + SX_SHARDS, ...), so the atomics spread over 64
 // addresses.  Only a wave's last block is partial (blockfill says how much of it exists) and the
 // shards end a few blocks apart; the first pass of the pair sort reads around those holes.
 struct WaveStage {
-    u64* buf;      // LDS ring, SX_STAGE slots
-    u32 wp;        // pairs pushed so far (wave-uniform)
+    u64* buf;      // LDS, SX_STAGE slots
+    u32 wp;        // pairs staged and not yet written: < SX_BLOCK between pushes (wave-uniform)
     u32 shard;
     u64 next_k;    // blocks reserved from the shard's cursor and not yet used: [next_k, next_k + k_left)
     u32 k_left;
     u32* hist;     // LDS, workgroup-wide: SX_HIST_MAX x 256 digit counters
     u64 examined;  // candidates this wave tested (wave-uniform)
+    u64 total = 0; // pairs written so far
     // OWNER (multi-GPU): the pairs per owner of the first id are counted here, once per block -- a ballot per owner and
     // quarter block, one LDS add per owner (an LDS atomic per pushed pair on <= 16 counters serialised the wave's lanes
     // on a few addresses: the shard scan took 0.83 ms instead of 0.43)
     template <bool OWNER = false>
-    __device__ __forceinline__ void write_block(const ExpandParams& p, u32 half, u32 count) {
+    __device__ __forceinline__ void write_block(const ExpandParams& p, u32 fill) {
         __builtin_amdgcn_wave_barrier();
         if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
             u64 k = 0;
@@ -1976,80 +1993,95 @@ struct WaveStage {
         ++next_k;
         --k_left;
         const bool fits = g < p.out_blocks;  // capacity is checked by the host afterwards (from the cursors)
+        u64 pr[SX_BLOCK / 64];
 #pragma unroll
-        for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
-            const u32 k2 = q * 64u + (u32)lane_id();
-            const bool valid = k2 < count;
-            const u64 pair = buf[half * SX_BLOCK + k2];
-            if (valid && fits) p.out[g * SX_BLOCK + k2] = pair;
-            if (OWNER) {
-                const u32 first = (u32)(pair >> 32);
+        for (u32 q = 0; q < SX_BLOCK / 64; ++q) pr[q] = buf[q * 64u + (u32)lane_id()];
+#pragma unroll
+        for (u32 q = 0; q < SX_BLOCK / 64; ++q)
+            if (q * 64u + (u32)lane_id() < fill && fits) p.out[g * SX_BLOCK + q * 64u + (u32)lane_id()] = pr[q];
+        if (!OWNER) {
+            // the digit counters for the sort that follows are fed here, 64 pairs per instruction (counted where a pair is
+            // pushed, the same LDS adds ran on the ~45 % of the lanes whose candidate was kept, and cost twice the issue slots)
+#pragma unroll
+            for (int h = 0; h < SX_HIST_MAX; ++h) {
+                if (h < p.hist_passes) {  // a counted digit never straddles the two dwords (scan_can_count)
+                    const bool hi = p.hist_shift[h] >= 32;
+                    const u32 sh = (u32)p.hist_shift[h] & 31u;
+#pragma unroll
+                    for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                        const u32 dg = ((hi ? (u32)(pr[q] >> 32) : (u32)pr[q]) >> sh) & 255u;
+                        if (q * 64u + (u32)lane_id() < fill) __hip_atomic_fetch_add(&hist[h * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                const bool valid = q * 64u + (u32)lane_id() < fill;
+                const u32 first = (u32)(pr[q] >> 32);
                 u32 o = 0;
                 for (int i = 0; i < p.owner_n; ++i) o += first >= p.owner_bounds[i] ? 1u : 0u;  // wave-uniform trip counts
                 for (int r = 0; r <= p.owner_n; ++r) {
-                    const u32 c = (u32)__popcll(__ballot(valid && o == (u32)r));
+                    const u32 c = (u32)__popcll(ballot64(valid && o == (u32)r));
                     if (c && lane_id() == 0) __hip_atomic_fetch_add(&hist[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-        if (fits && lane_id() == 0) p.blockfill[g] = count;
+        if (fits && lane_id() == 0) p.blockfill[g] = fill;
         __builtin_amdgcn_wave_barrier();
     }
+    // a full block leaves; the (fewer than 128) pairs behind it move to the front
     template <bool OWNER>
-    __device__ __forceinline__ void count(u64 pair, const ExpandParams& p) {
-        const u32 first = (u32)(pair >> 32);
-#pragma unroll
-        for (int q = 0; q < SX_HIST_MAX; ++q) {
-            if (q < p.hist_passes) {
-                // a counted digit never straddles the two dwords (scan_can_count): one select + one bit-field extract
-                const u32 src = p.hist_shift[q] >= 32 ? first : (u32)pair;
-                const u32 dg = (src >> (p.hist_shift[q] & 31)) & 255u;
-                __hip_atomic_fetch_add(&hist[q * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+    __device__ __forceinline__ void flush_full(const ExpandParams& p) {
+        write_block<OWNER>(p, SX_BLOCK);
+        const u32 over = wp - SX_BLOCK;  // wave-uniform
+        total += SX_BLOCK;
+        wp = over;
+        if (over) {
+            const u32 l = (u32)lane_id();
+            const u64 a = buf[SX_BLOCK + l], b = buf[SX_BLOCK + 64u + l];  // (source and destination never overlap)
+            __builtin_amdgcn_wave_barrier();
+            if (l < over) buf[l] = a;
+            if (64u + l < over) buf[64u + l] = b;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     template <bool OWNER = false>
     __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
-        const u64 mask = __ballot(keep);
+        const u64 mask = ballot64(keep);
         const u32 n = (u32)__popcll(mask);
         if (n == 0) return;
-        if (keep) {
-            buf[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, wp)) & (SX_STAGE - 1u)] = pair;
-            count<OWNER>(pair, p);
-        }
-        const u32 before = wp / SX_BLOCK;
+        if (keep) buf[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, wp))] = pair;
         wp += n;
-        if (wp / SX_BLOCK != before) write_block<OWNER>(p, before & 1u, SX_BLOCK);  // n <= 64: at most one half completes
+        if (wp >= SX_BLOCK) flush_full<OWNER>(p);
     }
-    // two candidates per lane (<= 128 pairs per call: still at most one half of the ring completes)
+    // two candidates per lane (<= 128 pairs per call)
     template <bool OWNER = false>
     __device__ __forceinline__ void push2(bool keep0, u64 pair0, bool keep1, u64 pair1, const ExpandParams& p) {
-        static_assert(SX_BLOCK >= 128 && SX_STAGE >= SX_BLOCK + 128, "ring too small for two candidates per lane");
-        const u64 m0 = __ballot(keep0), m1 = __ballot(keep1);
+        push2<OWNER>(ballot64(keep0), keep0, pair0, ballot64(keep1), keep1, pair1, p);
+    }
+    // m0 / m1: the votes on keep0 / keep1, for a caller that has them as lane masks already
+    template <bool OWNER = false>
+    __device__ __forceinline__ void push2(u64 m0, bool keep0, u64 pair0, u64 m1, bool keep1, u64 pair1, const ExpandParams& p) {
+        static_assert(SX_BLOCK >= 128 && SX_STAGE >= SX_BLOCK + 128, "stage too small for two candidates per lane");
         const u32 n0 = (u32)__popcll(m0), n = n0 + (u32)__popcll(m1);
         if (n == 0) return;
-        if (keep0) {
-            buf[__builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, wp)) & (SX_STAGE - 1u)] = pair0;
-            count<OWNER>(pair0, p);
-        }
-        if (keep1) {
-            buf[__builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, wp + n0)) & (SX_STAGE - 1u)] = pair1;
-            count<OWNER>(pair1, p);
-        }
-        const u32 before = wp / SX_BLOCK;
+        if (keep0) buf[__builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, wp))] = pair0;
+        if (keep1) buf[__builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, wp + n0))] = pair1;
         wp += n;
-        if (wp / SX_BLOCK != before) write_block<OWNER>(p, before & 1u, SX_BLOCK);
+        if (wp >= SX_BLOCK) flush_full<OWNER>(p);
     }
     template <bool OWNER = false>
     __device__ __forceinline__ void finish(const ExpandParams& p) {
-        const u32 rem = wp & (SX_BLOCK - 1u);
-        if (rem) write_block<OWNER>(p, (wp / SX_BLOCK) & 1u, rem);
-        if (wp && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)wp);
+        if (wp) write_block<OWNER>(p, wp);
+        total += wp;
+        if (total && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)total);
         if (examined && lane_id() == 0) atomicAdd(&p.shards[2 * SX_SHARDS + shard], examined);
     }
 };
 
-__device__ __forceinline__ int sx_hist_rows(const ExpandParams& p) { return p.owner_n >= 0 ? 1 : p.hist_passes; }
+__host__ __device__ __forceinline__ int sx_hist_rows(const ExpandParams& p) { return p.owner_n >= 0 ? 1 : p.hist_passes; }
+static size_t sx_hist_bytes(const ExpandParams& p) { return (size_t)sx_hist_rows(p) * 256 * sizeof(u32); }
 __device__ __forceinline__ void sx_hist_clear(u32* s_hist, const ExpandParams& p) {
     for (int k = (int)threadIdx.x; k < sx_hist_rows(p) * 256; k += SX_THREADS) s_hist[k] = 0;
     __syncthreads();
@@ -2063,10 +2095,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 }
 
 #ifndef SX_WAVES_PER_EU
-#define SX_WAVES_PER_EU 5
+#define SX_WAVES_PER_EU 6  // measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.44 (with the stage cut to fit)
 #endif
 #if SX_WAVES_PER_EU
-#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SX_WAVES_PER_EU, SX_WAVES_PER_EU)))
+#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(5, SX_WAVES_PER_EU)))  // (the filtering variants need more registers than 7 waves leave)
 #else
 #define SX_OCC_ATTR
 #endif
@@ -2085,7 +2117,7 @@ template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
 #ifndef SX_SUPER_WORDS
-#define SX_SUPER_WORDS 64
+#define SX_SUPER_WORDS 16  // (a chunk has ~320 candidates on the uniform scene; every byte of LDS counts towards the 7th wave per SIMD)
 #endif
     constexpr u32 SUPER = 64 * SX_SUPER_WORDS;  // candidates covered by one fill of the boundary masks
     __shared__ u64 s_ends[SX_WAVES][SX_SUPER_WORDS];   // bit q of word b: some owner's range ends before candidate 64 b + q
@@ -2095,9 +2127,13 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     __shared__ RecWin s_recwin[SX_WAVES];
     __shared__ u64 s_cwin[SX_WAVES][SX_WIN];  // {id, context} words of the entries [base, base + SX_WIN)
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
-    __shared__ u32 s_hist[SX_HIST_MAX * 256];
+    // the digit counters: as many rows as this launch counts (dynamic LDS, sx_hist_bytes) -- with the two rows of the usual
+    // pair sort a workgroup needs 22.5 KB and six of them share a CU
+    extern __shared__ u32 s_hist[];
     sx_hist_clear(s_hist, p);
-    const int w = (int)(threadIdx.x >> 6), lane = lane_id();
+    // the wave's index and everything derived from it (chunk base, loop bounds, the stage's counters) are wave-uniform: said
+    // explicitly, they live in SGPRs and the loops branch on scalar conditions instead of exec masks
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     uint4* const s_rec_w = s_recwin[w].rec;
     u64* const win = s_recwin[w].win;
     u64* const cwin = s_cwin[w];
@@ -2123,9 +2159,14 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         return r;
     };
     size_t base = (size_t)gw * 64;
+#ifdef SX_STAMPS
+    u64 sx_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const u64 sx_begin = __builtin_readcyclecounter();
+#endif
     Pre cur_pre{};
     if (base < p.m) cur_pre = prefetch(base);
     for (; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
+        SX_T(t0);
         const Pre pre = cur_pre;
         const size_t nbase = base + (size_t)p.n_waves * 64;
         if (nbase < p.m) cur_pre = prefetch(nbase);  // the NEXT chunk's loads fly while this chunk is processed
@@ -2137,6 +2178,9 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         cwin[lane] = pre.w0;
         cwin[64 + lane] = pre.w1;
         __builtin_amdgcn_wave_barrier();
+        SX_T(t1);
+        SX_ACC(0, t1 - t0);
+        SX_ACC(5, 1);
         u32 c = 0, idj = 0, dj = 0, cbj = 0;
         if (in0) {
             const u64 wj = pre.w0;
@@ -2171,10 +2215,12 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             }
         }
         __builtin_amdgcn_wave_barrier();  // the key window is dead from here on (s_rec is written below)
-        const u64 nz = __ballot(c > 0);
+        const u64 nz = ballot64(c > 0);
+        SX_T(t2);
+        SX_ACC(1, t2 - t1);
         if (nz == 0) continue;  // wave-uniform
         const u32 incl = wave_incl_scan_u32(c);
-        const u32 total = __shfl(incl, 63, 64);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         // The candidates of the 64 ranges, concatenated, are dealt to the lanes 64 per step.  Which
         // owner a candidate belongs to = how many ranges end at or before it: every owner sets ONE
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
@@ -2185,6 +2231,8 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
                 make_uint4(incl - c - (u32)lane - 1u, idj, dj, cbj);
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
+        SX_T(t3);
+        SX_ACC(2, t3 - t2);
         for (u32 ss = 0; ss < total; ss += SUPER) {  // wave-uniform; one iteration unless the ranges are long
             if (lane < (int)SX_SUPER_WORDS) s_ends[w][lane] = 0ull;
             __builtin_amdgcn_wave_barrier();
@@ -2242,8 +2290,21 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
                     continue;
                 }
-                bool keep0 = act0 && ctx_keep(w0lo, r0.z, r0.w);
-                bool keep1 = act1 && ctx_keep(w1lo, r1.z, r1.w);
+                // no short circuit: the test runs on every lane (a lane beyond the last candidate tests garbage) and the
+                // ballots come straight out of the compares
+                const bool c0 = ctx_keep(w0lo, r0.z, r0.w), c1 = ctx_keep(w1lo, r1.z, r1.w);
+                bool keep0 = act0 & c0, keep1 = act1 & c1;
+                if (GEN == 0 && !FILT) {
+                    // the vote on (a & b) costs two VALU instructions, the AND of two votes on compares none
+                    // (the lanes with a candidate are the low `rem` ones: their mask is scalar arithmetic)
+                    const u32 rem = total - ss - b * 128u;  // >= 1
+                    const u64 am0 = rem >= 64u ? ~0ull : (1ull << rem) - 1ull;
+                    const u64 am1 = rem >= 128u ? ~0ull : rem > 64u ? (1ull << (rem - 64u)) - 1ull : 0ull;
+                    st.template push2<OWNER>(am0 & ballot64(c0), keep0, ((u64)w0hi << 32) | (u64)r0.y, am1 & ballot64(c1), keep1,
+                                             ((u64)w1hi << 32) | (u64)r1.y, p);
+                    SX_ACC(6, 1);
+                    continue;
+                }
                 if (GEN == 2) {
                     keep0 = keep0 && !(w0lo & CTX_SKIPPED);
                     keep1 = keep1 && !(w1lo & CTX_SKIPPED);
@@ -2253,11 +2314,32 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     if (keep0) keep0 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w0hi * fs, p.filt_bounds + (size_t)r0.y * fs, p.filt_shape);
                     if (keep1) keep1 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w1hi * fs, p.filt_bounds + (size_t)r1.y * fs, p.filt_shape);
                 }
+                SX_T(tp0);
                 st.template push2<OWNER>(keep0, ((u64)w0hi << 32) | (u64)r0.y, keep1, ((u64)w1hi << 32) | (u64)r1.y, p);
+                SX_T(tp1);
+                SX_ACC(4, tp1 - tp0);
+                SX_ACC(6, 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
+        SX_T(t4);
+        SX_ACC(3, t4 - t3);
     }
+#ifdef SX_STAMPS
+    sx_acc[7] = __builtin_readcyclecounter() - sx_begin;
+    if (lane == 0) {
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_sx_stamps[q], sx_acc[q]);
+        atomicMax(&g_sx_stamps[8], sx_acc[7]);                                  // the slowest wave's chunk loop
+        atomicMin(&g_sx_stamps[9], ~sx_acc[7]);                                 // (complement of) the fastest wave's
+        atomicMax(&g_sx_stamps[10], sx_acc[5]);                                 // most chunks of one wave
+        if (gw < 8192u) {
+            g_sx_wave[gw][0] = sx_acc[7];
+            g_sx_wave[gw][1] = (sx_acc[6] << 32) | sx_acc[5];
+            g_sx_wave[gw][2] = (u64)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((u64)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
+            g_sx_wave[gw][3] = sx_begin;
+        }
+    }
+#endif
     if (GEN == 1) return;
     st.template finish<OWNER>(p);
     sx_hist_flush(s_hist, p);
@@ -2270,7 +2352,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
     __shared__ u32 s_end;
-    const int w = (int)(threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 m = (u32)p.m;
     // an overflowed list has unwritten slots (a lane that did not fit reserved its slices anyway) and the host
     // discards this scan's output: do nothing
@@ -2383,7 +2465,7 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_finish_kernel(const u64* 
     for (int g = w; g < GROUPS; g += SEG_THREADS / 64) {
         const u32 x = (u32)g * 64u + (u32)lane;
         const bool head = x < wlen && (x == 0 || (u32)(s_win[x] >> 32) != (u32)(s_win[x - 1] >> 32));
-        const u64 m = __ballot(head);
+        const u64 m = ballot64(head);
         if (lane == 0) s_heads[g] = m;
     }
     __syncthreads();
@@ -2474,7 +2556,7 @@ __global__ __launch_bounds__(SEG_THREADS) void tree_segment_finish_kernel(const 
     for (int g = w; g < GROUPS; g += SEG_THREADS / 64) {
         const u32 x = (u32)g * 64u + (u32)lane;
         const bool head = x < wlen && (x == 0 || (s_key[x] >> seg_shift) != (s_key[x - 1] >> seg_shift));
-        const u64 m = __ballot(head);
+        const u64 m = ballot64(head);
         if (lane == 0) s_heads[g] = m;
     }
     __syncthreads();
@@ -2974,16 +3056,26 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
     return hipGetLastError();
 }
 
+// workgroups of a grid that places at most per_cu of them on a CU
+static unsigned resident_cap(int per_cu) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return (unsigned)(cus * per_cu);
+}
 // resident workgroups of a persistent kernel = CUs x occupancy (queried once per kernel)
 template <typename Kern>
-static unsigned resident_blocks(Kern kernel, int threads) {
+static unsigned resident_blocks(Kern kernel, int threads, size_t dyn_lds = 0) {
     int dev = 0, cus = 256, per_cu = 4;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) == hipSuccess && nb > 0) per_cu = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, dyn_lds) == hipSuccess && nb > 0) per_cu = nb;
     (void)hipGetLastError();
     return (unsigned)(cus * per_cu);
 }
@@ -3384,10 +3476,16 @@ hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t*
 
 template <int KIND, bool FILT, bool OWNER, int GEN = 0>
 static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
-    static const unsigned resident = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS);
-    const unsigned grid = (unsigned)std::min<size_t>(max_grid, resident);
+    // resident workgroups per dynamic-LDS size (0 .. SX_HIST_MAX rows of counters)
+    static unsigned resident[SX_HIST_MAX + 1] = {};
+    const int rows = sx_hist_rows(p);
+    if (rows < 0 || rows > SX_HIST_MAX) return hipErrorInvalidValue;
+    if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS, sx_hist_bytes(p));
+    unsigned res = std::min(resident[rows], resident_cap(SX_WAVES_PER_EU ? SX_WAVES_PER_EU * 4 / SX_WAVES : 64));
+    if (const char* e = getenv("BP_SX_GRID")) res = (unsigned)atoi(e);  // (measurement knob: workgroups of the persistent grid)
+    const unsigned grid = (unsigned)std::min<size_t>(max_grid, res);
     p.n_waves = grid * SX_WAVES;
-    scan_expand_kernel<KIND, FILT, OWNER, GEN><<<grid, SX_THREADS, 0, stream>>>(p);
+    scan_expand_kernel<KIND, FILT, OWNER, GEN><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
     scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
     return hipGetLastError();
 }
@@ -3496,7 +3594,7 @@ __global__ __launch_bounds__(SX_THREADS) void region_query_kernel(ExpandParams p
     constexpr u32 TOP = DIM * AB + DB;
     constexpr u32 ROW = RAY ? 2 * DIM + 2 : 2 * DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
-    const int w = (int)(threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;
     WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, nullptr, 0ull};
     const u32 q = blockIdx.x * SX_THREADS + threadIdx.x;
@@ -4231,7 +4329,7 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         const u32 x = (u32)k * GRD_THREADS + tid;
         const bool taken = x < ng && ((s_taken[x >> 5] >> (x & 31u)) & 1u) != 0u;
         idof[k] = taken ? (u32)s_idof[min(x, ng - 1u)] : 0xFFFFu;
-        const u64 bal = __ballot(taken);
+        const u64 bal = ballot64(taken);
         if (lane == 0) s_heads[k * GRD_WAVES + (int)w] = (u32)__popcll(bal);
     }
     __syncthreads();
@@ -4257,7 +4355,7 @@ __global__ __launch_bounds__(GRD_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     for (int k = 0; k < GRD_ITEMS; ++k) {
         const u32 x = (u32)k * GRD_THREADS + tid;
         const bool head = idof[k] != 0xFFFFu;
-        const u64 bal = __ballot(head);
+        const u64 bal = ballot64(head);
         if (head) {
             const u32 pos = s_heads[k * GRD_WAVES + (int)w] + (u32)__popcll(bal & ((1ull << lane) - 1ull));
             tmp[(size_t)lo + pos] = make_uint2(first_base | idof[k], s_second[x]);
@@ -4401,3 +4499,17 @@ hipError_t launch_unpack_pairs(const uint64_t* packed, size_t n, uint32_t* pairs
 }
 
 }  // namespace bp
+
+#ifdef SX_STAMPS
+extern "C" int bp_debug_sx_stamps(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bp::g_sx_stamps), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(bp::g_sx_stamps), z, sizeof z);
+    }
+    return (int)e;
+}
+extern "C" int bp_debug_sx_waves(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bp::g_sx_wave), 8192 * 4 * sizeof(unsigned long long));
+}
+#endif
