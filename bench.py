@@ -266,10 +266,14 @@ def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_la
            "frames": frames, "ms_per_step": sum(times) / len(times), "ms_min": min(times), "ms_max": max(times),
            "pairs_mean": sum(pairs) / len(pairs), "value": sum(pairs) / (sum(times) * 1e-3), "unit": "pairs/s",
            "host_syncs_per_step": (st1["host_syncs"] - st0["host_syncs"]) / frames,
-           "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs")},
+           "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs",
+                                                        "sorts_ahead_missed")},
+           "sorts_ahead": st1["sorts_ahead"] - st0["sorts_ahead"],
            "plan_events_note": "extend_reruns: extends launched on the previous frame's sizes that had to run again; *_plan_flips: sorts "
                                "whose grouped-finish plan differs from the previous frame's; sort_repairs: deferred tree-sort checks that "
-                               "failed (full-width re-sort + second scan)"}
+                               "failed (full-width re-sort + second scan); sorts_ahead: frames whose pair sort was enqueued behind the scan on the "
+                               "previous frame's sizes (no host round trip in between), sorts_ahead_missed: those that outgrew the sizes "
+                               "and ran again"}
     if check_last:                                       # the last frame against the CPU restatement on the same boxes
         import oracle  # checker only
         ref = oracle.OracleLayer(oracle.INDEX64_3D, 0)

@@ -144,7 +144,12 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
                       const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
-                      int ready_copies = 1, int unstable_first = 0, uint32_t* epoch_io = nullptr, const DevScalars* sc_init = nullptr);
+                      int ready_copies = 1, int unstable_first = 0, uint32_t* epoch_io = nullptr, const DevScalars* sc_init = nullptr,
+                      const uint32_t* dev_sizes = nullptr);
+// dev_sizes (with ready_hist only: nothing on the host side reads the records): the sort is enqueued behind a producer
+// nobody has waited for -- n and extent are UPPER BOUNDS (they size grids and the workspace), the kernels take the sizes
+// from dev_sizes[SIZES_N] / dev_sizes[SIZES_EXTENT] (launch_scan_finalize writes them; both 0 = do nothing)
+enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_WORDS = 8 };
 // unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
 // result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
 // varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.
@@ -251,7 +256,15 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
 // unskipped entries).  Run 1 then 2; the long-range counter in sc must be zero before each.
 // owner_bounds / owner_n (instead of hist_plan): count the pairs per owner rank of the first id into hist[0..255]
 // hist_plan / hist: also count the digits (pair >> shift[q]) & 255 of every emitted pair for the passes of
-// hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[n_passes][256] (zeroed by the caller)
+// hist_plan (n_passes <= SX_HIST_MAX, key digits only) into hist[HIST_COPIES][SX_HIST_MAX][256] (zeroed by the caller; the copies
+// are summed by radix_sort, ready_copies = HIST_COPIES)
+// The sizes of a finished expanding scan, on the device (for a sort enqueued without a host round trip): from the shard
+// cursors and counts, sizes[SIZES_EXTENT] = slots of the block-structured output, sizes[SIZES_N] = pairs in it.  Whatever
+// a later kernel could not cope with -- more blocks than out_blocks, more pairs than n_bound, a longer extent than
+// extent_bound, an overflowed work list -- sets sizes[SIZES_MISS] and leaves both sizes 0: everything enqueued behind
+// does nothing, and the host, which reads the sizes back at its one round trip, takes the blocking route.
+hipError_t launch_scan_finalize(const uint64_t* shards, size_t out_blocks, size_t n_bound, size_t extent_bound, const DevScalars* sc,
+                                uint32_t* sizes, hipStream_t stream);
 // Batched Layer::test_box / test_ray: (query << 32 | id) records for every entry whose cell the reference's
 // recursion reaches, block-structured like the scan's output (blockfill / shards zeroed by the caller).
 // queries (device memory): n_queries rows of 2*dim f32 [min, max] (ray = 0) or 2*dim + 2 f32
@@ -333,7 +346,8 @@ int tgroup_bin_bits();  // key bits below gshift the finish uses for its countin
 // a group of more than group_finish_capacity() pairs (or an id with very many) sets KERR_SEGMENT_TOO_LONG
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
                                uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats = nullptr,
-                               uint32_t second_max = 0xFFFFFFFFu);  // an upper bound of the second ids (only speed depends on it)
+                               uint32_t second_max = 0xFFFFFFFFu,  // an upper bound of the second ids (only speed depends on it)
+                               const uint32_t* dev_sizes = nullptr);  // n is an upper bound, the count is dev_sizes[SIZES_N]
 // stats (2 words of scratch): group-size statistics; with more than a quarter of the pairs in oversize groups the finish
 // does nothing and sets KERR_SEGMENT_TOO_LONG
 int group_finish_capacity();

@@ -710,7 +710,13 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
                                                                     size_t n, DigitFn digit, const u64* __restrict__ bin_base,
                                                                     u64* status, u32* tile_counter, DevScalars* sc,
                                                                     const uint8_t* __restrict__ box_in, uint8_t* __restrict__ box_out,
-                                                                    const u32* __restrict__ blockfill, size_t n_out, u32 epoch) {
+                                                                    const u32* __restrict__ blockfill, size_t n_out, u32 epoch,
+                                                                    const u32* __restrict__ dev_sizes) {
+    // dev_sizes: the sizes live on the device (n / n_out are upper bounds that sized the grid): tiles beyond the end leave
+    if (dev_sizes) {
+        n_out = dev_sizes[SIZES_N];
+        n = blockfill ? dev_sizes[SIZES_EXTENT] : dev_sizes[SIZES_N];
+    }
     // epoch: tag of this launch's status words (bits 32..61; counts and prefixes are < 2^32).  A word with another tag is
     // a leftover of an earlier launch on the same workspace and reads as "nothing published": no zero-fill between launches
     const u64 st_tag = (u64)(epoch & ST_EPOCH_MASK) << 32;
@@ -739,6 +745,7 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
     __syncthreads();
     const u32 tile = s_tile;
     const size_t base = (size_t)tile * RS_TILE;
+    if (base >= n) return;  // (workgroup-uniform; only with dev_sizes: no tile before this one waits for it)
     const u32 tile_n = (u32)((n - base) < (size_t)RS_TILE ? (n - base) : (size_t)RS_TILE);
 
     // ---- 1. load: wave w owns RS_ITEMS * 64 consecutive records, 64 per round (coalesced) -------
@@ -1011,6 +1018,9 @@ struct ClaimArgs {
     const uint8_t* box_in;
     const u32* blockfill;
     u32 n_tiles;
+    // sizes known only on the device (a sort enqueued behind its producer, see SIZES_*): n / n_out / n_tiles above are upper
+    // bounds that sized the grid and the workspace
+    const u32* dev_sizes;
 };
 
 // Bin b's output range [B, E): the aligned interior starts at A and holds I whole lines, handed out upwards from A.  What
@@ -1057,8 +1067,9 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     K* __restrict__ keys_out = a.keys_out;
     const V* __restrict__ vals_in = (const V*)a.vals_in;
     V* __restrict__ vals_out = (V*)a.vals_out;
-    const size_t n = a.n;
-    const u32 n_out = (u32)a.n_out, n_tiles = a.n_tiles;
+    const size_t n = a.dev_sizes ? (size_t)(a.blockfill ? a.dev_sizes[SIZES_EXTENT] : a.dev_sizes[SIZES_N]) : a.n;
+    const u32 n_out = a.dev_sizes ? a.dev_sizes[SIZES_N] : (u32)a.n_out;
+    const u32 n_tiles = a.dev_sizes ? (u32)((n + (size_t)TILE - 1) / (size_t)TILE) : a.n_tiles;
     const u32 wbase = (u32)w * (64 * ITEMS) + (u32)lane;
     // position p of the output is line-aligned <=> p = a0 (mod 16)
     const u32 a0 = (u32)(0u - (u32)((size_t)keys_out / sizeof(K))) & (u32)(RC_LINE - 1);
@@ -2090,7 +2101,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
     __syncthreads();
     for (int k = (int)threadIdx.x; k < sx_hist_rows(p) * 256; k += SX_THREADS) {
         const u32 c = s_hist[k];
-        if (c) atomicAdd(&p.hist[k], (u64)c);
+        // digit counts: spread over HIST_COPIES copies (one address serves ~90 atomics per us: 1536 workgroups on ONE copy queue
+        // for ~17 us at the end of the kernel); the per-owner counts of the shard scans stay in one row
+        u64* const dst = p.owner_n >= 0 ? p.hist : p.hist + (size_t)(blockIdx.x % HIST_COPIES) * (SX_HIST_MAX * 256);
+        if (c) atomicAdd(&dst[k], (u64)c);
     }
 }
 
@@ -2653,7 +2667,9 @@ constexpr u32 TGRP_SLOW_MAX = 32768;  // input positions travel as u16 + rounds 
 // `cap` (both zero beforehand: they live in the scalars the caller has just reset).  A workgroup covers 255 groups: its
 // 256 threads find 256 consecutive bounds, the last one again by the next workgroup.
 __global__ __launch_bounds__(256) void group_bounds_stats_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
-                                                                 u32* __restrict__ bounds, u32 cap, u32* __restrict__ stats) {
+                                                                 u32* __restrict__ bounds, u32 cap, u32* __restrict__ stats,
+                                                                 const u32* __restrict__ dev_sizes = nullptr) {
+    if (dev_sizes) n = dev_sizes[SIZES_N];  // (n was an upper bound)
     __shared__ u32 s_b[256];
     __shared__ u32 s_mx[4], s_ov[4];
     const u32 t = blockIdx.x * 255u + threadIdx.x;
@@ -2685,8 +2701,8 @@ __global__ __launch_bounds__(256) void group_bounds_stats_kernel(const u64* __re
     }
 }
 static hipError_t launch_group_bounds_stats(const u64* keys, u32 n, u32 n_groups, u64 g0, int gshift, u32* bounds, u32 cap, u32* stats,
-                                            hipStream_t stream) {
-    group_bounds_stats_kernel<<<(n_groups + 1 + 254) / 255, 256, 0, stream>>>(keys, n, n_groups, g0, gshift, bounds, cap, stats);
+                                            hipStream_t stream, const u32* dev_sizes = nullptr) {
+    group_bounds_stats_kernel<<<(n_groups + 1 + 254) / 255, 256, 0, stream>>>(keys, n, n_groups, g0, gshift, bounds, cap, stats, dev_sizes);
     return hipGetLastError();
 }
 // CTX_KIND >= 0 (with PACKED): also write the scan's per-entry {id, suppression context} word (entry_ctx_kernel's output
@@ -3166,23 +3182,24 @@ static hipError_t launch_claim(const ClaimArgs& a, hipStream_t stream) {
 template <typename K, typename V, typename DigitFn>
 static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t n, DigitFn fn, const u64* bb, u64* st,
                                   u32* tc, DevScalars* sc, hipStream_t stream, const uint8_t* bi = nullptr, uint8_t* bo = nullptr,
-                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true, u32 epoch = 0, bool few = false) {
+                                  const u32* blockfill = nullptr, size_t n_out = 0, bool stable = true, u32 epoch = 0, bool few = false,
+                                  const u32* dev_sizes = nullptr) {
     // n: extent of the input (tiles are cut from it); n_out: records that exist (== n without holes)
     const unsigned tiles = (unsigned)rs_num_tiles(n);
     if (!blockfill) n_out = n;
     if constexpr (!std::is_same<DigitFn, ShiftDigit>::value) {  // the bucketing passes (few buckets); radix digits never take this route
         if (few) {
             radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-                ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
+                ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch, dev_sizes);
             return hipGetLastError();
         }
     }
     if (stable)
         radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, true><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch, dev_sizes);
     else
         radix_onesweep_kernel<K, V, RS_THREADS_DEF, RS_ITEMS_DEF, DigitFn, false><<<tiles, RS_THREADS_DEF, 0, stream>>>(
-            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch);
+            ki, ko, vi, vo, n, fn, bb, st, tc, sc, bi, bo, blockfill, n_out, epoch, dev_sizes);
     return hipGetLastError();
 }
 
@@ -3191,7 +3208,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
                       const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies,
-                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init) {
+                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init, const uint32_t* dev_sizes) {
+    if (dev_sizes && (!ready_hist || vals0)) return hipErrorInvalidValue;  // (the counting kernel and the payload passes take host sizes)
     static const bool no_unstable = getenv("BP_NO_UNSTABLE_PASS") != nullptr;  // A/B switch
     if (no_unstable) unstable_first = 0;
     *result_buf = 0;
@@ -3277,12 +3295,14 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
             a.line_cur = cursors; a.frag_cur = cursors + SW_CURSOR_WORDS;
             a.box_in = box_in; a.blockfill = blockfill;
             a.n_tiles = (u32)rs_num_tiles(a.n);
+            a.dev_sizes = dev_sizes;
             e = vals0 ? launch_claim<u32>(a, stream) : launch_claim<NoVal>(a, stream);
         } else if (!vals0) {
             const bool holes = blockfill && p == 0;  // only the first pass sees the block-structured input
             e = launch_onesweep<u64, NoVal>(kb[cur], kb[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, holes ? extent : n,
                                             ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream, nullptr, nullptr,
-                                            holes ? blockfill : nullptr, n, !(unstable_first && p == 0), epoch0 ? epoch0 + (u32)p : 0u);
+                                            holes ? blockfill : nullptr, n, !(unstable_first && p == 0), epoch0 ? epoch0 + (u32)p : 0u, false,
+                                            dev_sizes);
         } else if (plan.from_val[p]) {
             e = launch_onesweep<u32, u64>(vb[cur], vb[cur ^ 1], kb[cur], kb[cur ^ 1], n, ShiftDigit{plan.shift[p]}, bb, st, tc, sc, stream,
                                           nullptr, nullptr, nullptr, 0, true, epoch0 ? epoch0 + (u32)p : 0u);
@@ -3471,6 +3491,31 @@ hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t*
     const unsigned grid = (unsigned)std::min<size_t>(2048, (std::max<size_t>(n_blocks, 1024) + 255) / 256);
     scan_prepare_kernel<<<grid, 256, 0, stream>>>(sc, init, blockfill, n_blocks, (u64*)shards, n_shard_words, (u64*)hist,
                                                   hist ? n_hist_words : 0u);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void scan_finalize_kernel(const u64* __restrict__ shards, u64 out_blocks, u64 n_bound, u64 extent_bound,
+                                                           const DevScalars* __restrict__ sc, u32* __restrict__ sizes) {
+    static_assert(SX_SHARDS == 64, "one lane per shard");
+    const int lane = lane_id();
+    u64 kmax = shards[lane], total = shards[SX_SHARDS + lane];
+    for (int o = 32; o; o >>= 1) {
+        const u64 k2 = ((u64)(u32)__shfl_xor((int)(u32)(kmax >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)kmax, o, 64);
+        const u64 t2 = ((u64)(u32)__shfl_xor((int)(u32)(total >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)total, o, 64);
+        kmax = kmax > k2 ? kmax : k2;
+        total += t2;
+    }
+    if (lane != 0) return;
+    const u64 extent_blocks = kmax * (u64)SX_SHARDS, extent = extent_blocks * (u64)SX_BLOCK;
+    const bool ok = extent_blocks <= out_blocks && total <= n_bound && extent <= extent_bound && extent < 0xFFFFFFFFull &&
+                    !(sc->err & (u32)KERR_BIGLIST_OVERFLOW);
+    sizes[SIZES_EXTENT] = ok ? (u32)extent : 0u;
+    sizes[SIZES_N] = ok ? (u32)total : 0u;
+    sizes[SIZES_MISS] = ok ? 0u : 1u;
+}
+hipError_t launch_scan_finalize(const uint64_t* shards, size_t out_blocks, size_t n_bound, size_t extent_bound, const DevScalars* sc,
+                                uint32_t* sizes, hipStream_t stream) {
+    scan_finalize_kernel<<<1, 64, 0, stream>>>((const u64*)shards, (u64)out_blocks, (u64)n_bound, (u64)extent_bound, sc, sizes);
     return hipGetLastError();
 }
 
@@ -4048,7 +4093,9 @@ constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;
 constexpr u32 GRP_SUB = 4;  // sub-bins per id by the top bits of the second id (fast path)  // larger groups than this are not attempted
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
                                                                    int gbits, int sshift, uint2* __restrict__ out, DevScalars* sc,
-                                                                   const u32* __restrict__ stats, u32 abort_over) {
+                                                                   const u32* __restrict__ stats, u32 abort_over,
+                                                                   const u32* __restrict__ dev_sizes) {
+    if (dev_sizes) abort_over = dev_sizes[SIZES_N] / 4u;
     // bins of the fast path: id within the group x GRP_SUB ranges of the second id (second >> sshift, clamped): shorter
     // bins, shorter rank loops (their cost is quadratic in the bin length)
     constexpr u32 NBINS = 256u * GRP_SUB;
@@ -4192,19 +4239,20 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
     for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_second[x]);
 }
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
-                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max) {
+                               uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max,
+                               const uint32_t* dev_sizes) {
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
     // stats (two words of the freshly reset scalars): [0] = largest group, [1] = pairs in groups above the capacity; a
     // quarter of all pairs there: the finish bails out
-    hipError_t e = launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream);
+    hipError_t e = launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream, dev_sizes);
     if (e != hipSuccess) return e;
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
     int bits = 0;
     while (bits < 32 && (second_max >> bits) != 0) ++bits;
     const int sshift = bits > 2 ? bits - 2 : 0;
     group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
-                                                              (u32)(n / 4));
+                                                              (u32)(n / 4), dev_sizes);
     return hipGetLastError();
 }
 int group_finish_capacity() { return GRP_CAP; }

@@ -112,6 +112,20 @@ struct bp_layer {
     uint32_t grp_off = 0;               // sorts left for which the grouped pair finish stays off (after a refusal)
     uint32_t grp_off_dups = 0;          // the same for the grouped finish of pairs that may repeat
     int grp_next_dups = 0;              // that finish ran last frame on groups of 2^this ids: the scan counts the digits of its plan
+    // Pair sort enqueued AHEAD of the scan's sizes (scan_fused_device): what the last frame's sort looked like.  While a frame
+    // matches it -- same plan, same id range, about as many entries -- the next scan is followed by the sort and the grouped
+    // finish without a host round trip in between: their grids and buffers are sized from these numbers plus a margin and the
+    // kernels take the true sizes from device memory (launch_scan_finalize); a frame that outgrows the margin leaves the
+    // enqueued kernels idle and runs again on the blocking route.
+    struct AheadHint {
+        bool valid = false;
+        size_t n_raw = 0, extent = 0, m = 0;
+        uint32_t n_groups = 0, first_lo = 0, first_hi = 0;
+        unsigned long long varying = 0;
+        RadixPlan plan{};
+    } ahead;
+    bool ahead_try = false;             // scan_device -> scan_fused_device: this frame qualifies
+    bool ahead_done = false;            // scan_fused_device -> scan_device: pairs are sorted and finished already
     bool grp_next = true;               // the last distinct-pair sort used the grouped finish (plan hint for the next scan; a new layer expects it: a wrong guess only makes that sort count its own digits)
     // grouped finish of the tree sort: chosen for a sort when the previous sort's group sizes (grp_max of the scalars) allow it
     bool tgrp_ok = false, tgrp_known = false;
@@ -308,12 +322,16 @@ int sc_reset(bp_layer* L) {
     return BP_OK;
 }
 // the scalars' device / host buffers carry the expanding scan's shard cursors behind them, so that ONE copy brings both back
-constexpr size_t SC_SHARDS_OFF = 256, SC_BLOCK_BYTES = SC_SHARDS_OFF + 3 * SX_SHARDS * sizeof(uint64_t);
+// (and, behind those, the device-side sizes of a scan whose sort was enqueued ahead: SIZES_WORDS words)
+constexpr size_t SC_SHARDS_OFF = 256, SC_SIZES_OFF = SC_SHARDS_OFF + 3 * SX_SHARDS * sizeof(uint64_t),
+                 SC_BLOCK_BYTES = SC_SIZES_OFF + SIZES_WORDS * sizeof(uint32_t);
 static_assert(sizeof(DevScalars) <= SC_SHARDS_OFF, "scalars block layout");
+uint32_t* sc_sizes_dev(bp_layer* L) { return (uint32_t*)((char*)L->d_sc.p + SC_SIZES_OFF); }
+const uint32_t* sc_sizes_host(bp_layer* L) { return (const uint32_t*)((const char*)L->h_sc.p + SC_SIZES_OFF); }
 uint64_t* sc_shards_dev(bp_layer* L) { return (uint64_t*)((char*)L->d_sc.p + SC_SHARDS_OFF); }
 const uint64_t* sc_shards_host(bp_layer* L) { return (const uint64_t*)((const char*)L->h_sc.p + SC_SHARDS_OFF); }
 int sc_fetch(bp_layer* L, DevScalars* out, bool with_shards = false) {  // D2H + sync
-    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, with_shards ? SC_BLOCK_BYTES : sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, with_shards ? SC_SIZES_OFF : sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
     BP_TRY(sync_stream(L));
     *out = *(DevScalars*)L->h_sc.p;
     if (out->err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
@@ -1083,6 +1101,7 @@ uint32_t group_finish_groups(size_t n, unsigned long long varying, uint32_t id_l
     return (id_hi >> 8) - (id_lo >> 8) + 1u;
 }
 // digit counts the scan left behind for exactly this plan (consumed by the first sort that asks)
+constexpr size_t PAIR_HIST_WORDS = (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS;
 const unsigned long long* take_ready_hist(bp_layer* L, const RadixPlan& plan, bool holes) {
     if (!L->pair_hist_valid) return nullptr;
     L->pair_hist_valid = false;
@@ -1112,19 +1131,24 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     L->stats.pair_sort_passes = (uint32_t)plan.n_passes;
     int res = 0;
     uint64_t* bufs[2] = {buf0, nullptr};
-    BP_TRY(ensure_dev(L, L->pairs[1], n * sizeof(uint64_t)));
+    // (buffers are sized with the margin the next frame's sort will ask for when it is enqueued ahead of its scan's sizes:
+    // that frame then allocates nothing)
+    const bool margin = holes && n_groups != 0;
+    const size_t n_alloc = margin ? n + n / 8 + 4096 : n;
+    BP_TRY(ensure_dev(L, L->pairs[1], n_alloc * sizeof(uint64_t)));
     bufs[1] = (uint64_t*)L->pairs[1].p;
     {
         const size_t extent = holes ? L->raw_extent : n;
+        const size_t extent_alloc = margin ? std::max(extent + extent / 8 + (size_t)SX_SHARDS * SX_BLOCK, n_alloc) : extent;
         uint32_t* ws_epoch = nullptr;
-        BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(extent, plan.n_passes), &ws_epoch));
+        BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(extent_alloc, plan.n_passes), &ws_epoch));
         const DevScalars sc_init = neutral_scalars();  // the scalars are reset by the sort's first kernel
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), 1,
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), HIST_COPIES,
                               /*unstable_first=*/1, ws_epoch, &sc_init));  // distinct pairs, finished by (first id, second id) in LDS
     }
-    BP_TRY(ensure_dev(L, L->out_pairs, n * 2 * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->out_pairs, n_alloc * 2 * sizeof(uint32_t)));
     if (n_groups) {
         BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
         ProfScope ps(L, BP_K_DEDUP);
@@ -1141,11 +1165,19 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     if (sc.err & KERR_SEGMENT_TOO_LONG) {  // a group / segment did not fit its window: sort all 64 bits instead
         L->grp_next = false;
+        L->ahead.valid = false;
         if (n_groups) { L->grp_off = 16; ++L->stats.pair_plan_flips; }
         return sort_unique_pairs_in(L, bufs[res], n, varying, true);
     }
     L->n_pairs = n;
     L->stats.pairs = n;
+    // what this sort looked like: the next frame's may be enqueued ahead of its scan's sizes (scan_fused_device)
+    L->ahead.valid = holes && n_groups != 0 && buf0 == (uint64_t*)L->pairs[0].p;
+    if (L->ahead.valid) {
+        L->ahead.n_raw = n; L->ahead.extent = L->raw_extent; L->ahead.m = L->m;
+        L->ahead.n_groups = n_groups; L->ahead.first_lo = first_range[0]; L->ahead.first_hi = first_range[1];
+        L->ahead.varying = varying; L->ahead.plan = plan;
+    }
     return BP_OK;
 }
 
@@ -1182,7 +1214,7 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
             const DevScalars sc_init = neutral_scalars();  // the scalars are reset by the sort's first kernel
             HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, gplan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                   &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                                  holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, gplan, holes), 1,
+                                  holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, gplan, holes), HIST_COPIES,
                                   /*unstable_first=*/1, ws_epoch, &sc_init));  // equal pairs are interchangeable; the finish orders by (first, second)
             BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
             BP_TRY(ensure_dev(L, L->block_sums, ((size_t)n_groups + 1) * sizeof(unsigned long long)));
@@ -1237,7 +1269,7 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
         BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(extent, plan.n_passes)));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), HIST_COPIES));
     }
     uint64_t* sorted = bufs[res ^ 1];  // the finish writes into the other ping-pong buffer (both hold >= n)
     {
@@ -1299,7 +1331,7 @@ int sort_unique_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long lo
         BP_TRY(sc_reset(L));
         HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n, plan, L->radix_ws.p, L->radix_ws.cap,
                               (DevScalars*)L->d_sc.p, &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
-                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes)));
+                              holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, plan, holes), HIST_COPIES));
     } else {
         BP_TRY(sc_reset(L));
     }
@@ -1420,7 +1452,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             const bool count_digits = allow_holes && hist_plan && scan_can_count(*hist_plan);
             const bool count_owners = allow_holes && !count_digits && owner_n >= 0 && owner_n <= 15;
             L->owner_hist_valid = false;
-            if (count_digits || count_owners) BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
+            if (count_digits || count_owners) BP_TRY(ensure_dev(L, L->pair_hist, PAIR_HIST_WORDS * sizeof(unsigned long long)));  // (the scan spreads its digit counts over HIST_COPIES copies)
             // scalars, fill counts, cursors and histograms are all reset by one small kernel
             static const bool no_prepare = getenv("BP_NO_SCAN_PREPARE") != nullptr;  // A/B switch for measurements
             if (no_prepare) {
@@ -1428,12 +1460,12 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 HIP_TRY(L, hipMemsetAsync(L->blockfill.p, 0, out_blocks * sizeof(uint32_t), L->stream));
                 HIP_TRY(L, hipMemsetAsync(d_shards, 0, shard_bytes, L->stream));
                 if (count_digits || count_owners)
-                    HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+                    HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, PAIR_HIST_WORDS * sizeof(unsigned long long), L->stream));
             } else
             HIP_TRY(L, launch_scan_prepare((DevScalars*)L->d_sc.p, neutral_scalars(), (uint32_t*)L->blockfill.p, out_blocks,
                                            d_shards, 3 * SX_SHARDS,
                                            (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
-                                           SX_HIST_MAX * RS_BINS, L->stream));
+                                           count_digits ? (uint32_t)PAIR_HIST_WORDS : (uint32_t)(SX_HIST_MAX * RS_BINS), L->stream));
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds, L->filt_shape,
@@ -1444,6 +1476,77 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                               (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
                                               count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1));
             }
+            if (L->ahead_try && attempt == 0 && count_digits) {
+                // ---- the pair sort and its finish go out behind the scan, sized by the last frame's numbers; ONE round trip ----
+                L->ahead_try = false;
+                const bp_layer::AheadHint h = L->ahead;
+                const size_t n_bound = std::min<size_t>(h.n_raw + h.n_raw / 8 + 4096, out_blocks * SX_BLOCK);
+                const size_t extent_bound = std::min<size_t>(std::max(h.extent + h.extent / 8 + (size_t)SX_SHARDS * SX_BLOCK, n_bound), out_blocks * SX_BLOCK);
+                uint32_t* const d_sizes = sc_sizes_dev(L);
+                {
+                    ProfScope ps(L, BP_K_MISC);
+                    HIP_TRY(L, launch_scan_finalize(d_shards, out_blocks, n_bound, extent_bound, (const DevScalars*)L->d_sc.p, d_sizes, L->stream));
+                }
+                uint64_t* bufs[2] = {(uint64_t*)L->pairs[0].p, nullptr};
+                BP_TRY(ensure_dev(L, L->pairs[1], n_bound * sizeof(uint64_t)));
+                bufs[1] = (uint64_t*)L->pairs[1].p;
+                int res = 0;
+                {
+                    uint32_t* ws_epoch = nullptr;
+                    BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(extent_bound, h.plan.n_passes), &ws_epoch));
+                    const DevScalars sc_init = neutral_scalars();
+                    HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n_bound, h.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
+                                          &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
+                                          (const uint32_t*)L->blockfill.p, extent_bound, (const unsigned long long*)L->pair_hist.p, HIST_COPIES,
+                                          /*unstable_first=*/1, ws_epoch, &sc_init, d_sizes));
+                }
+                BP_TRY(ensure_dev(L, L->out_pairs, n_bound * 2 * sizeof(uint32_t)));
+                BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)h.n_groups + 1) * sizeof(uint32_t)));
+                {
+                    ProfScope ps(L, BP_K_DEDUP);
+                    HIP_TRY(L, launch_group_finish(bufs[res], n_bound, h.n_groups, h.first_lo >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
+                                                   (DevScalars*)L->d_sc.p, L->stream, group_stats_words((DevScalars*)L->d_sc.p),
+                                                   (uint32_t)(h.varying & 0xFFFFFFFFull), d_sizes));
+                }
+                HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, SC_BLOCK_BYTES, hipMemcpyDeviceToHost, L->stream));
+                BP_TRY(sync_stream(L));
+                ++L->stats.sorts_ahead;
+                {
+                    bool redone = false;
+                    BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));
+                    if (redone) { L->ahead.valid = false; return rerun(); }
+                }
+                const DevScalars sc = *(const DevScalars*)L->h_sc.p;
+                const uint32_t* sz = sc_sizes_host(L);
+                if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
+                if (sz[SIZES_MISS]) {  // the frame outgrew the margins (or overflowed the work list): everything behind the scan idled
+                    ++L->stats.sorts_ahead_missed;
+                    L->ahead.valid = false;
+                    return rerun();
+                }
+                const uint64_t* sh = sc_shards_host(L);
+                uint64_t examined = 0;
+                for (int i = 0; i < SX_SHARDS; ++i) examined += sh[2 * SX_SHARDS + i];
+                const size_t n = sz[SIZES_N];
+                L->n_raw = n;
+                L->stats.raw_pairs = n;
+                L->stats.raw_candidates = examined;
+                L->raw_holes = false;  // (consumed)
+                L->raw_extent = sz[SIZES_EXTENT];
+                L->stats.pair_sort_passes = (uint32_t)h.plan.n_passes;
+                L->ahead_done = true;
+                if (sc.err & KERR_SEGMENT_TOO_LONG) {  // as on the blocking route: sort all 64 bits instead
+                    L->grp_next = false;
+                    L->ahead.valid = false;
+                    L->grp_off = 16; ++L->stats.pair_plan_flips;
+                    return sort_unique_pairs_in(L, bufs[res], n, h.varying, true);
+                }
+                L->n_pairs = n;
+                L->stats.pairs = n;
+                L->ahead.n_raw = n; L->ahead.extent = sz[SIZES_EXTENT]; L->ahead.m = L->m;
+                return BP_OK;
+            }
+            L->ahead_try = false;
             DevScalars sc;
             BP_TRY(sc_fetch(L, &sc, /*with_shards=*/true));
             {
@@ -1558,8 +1661,8 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
         const RadixPlan hplan = make_radix_plan(((unsigned long long)idv << 32) & ~((1ull << (32 + L->grp_next_dups)) - 1ull), 0, 0);
         const bool count_digits = segment_finish_enabled() && hplan.n_passes > 0 && scan_can_count(hplan);
         if (count_digits) {
-            BP_TRY(ensure_dev(L, L->pair_hist, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long)));
-            HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, SX_HIST_MAX * RS_BINS * sizeof(unsigned long long), L->stream));
+            BP_TRY(ensure_dev(L, L->pair_hist, PAIR_HIST_WORDS * sizeof(unsigned long long)));
+            HIP_TRY(L, hipMemsetAsync(L->pair_hist.p, 0, PAIR_HIST_WORDS * sizeof(unsigned long long), L->stream));
         }
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
@@ -1618,7 +1721,18 @@ int scan_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse) {
         const uint32_t idv = L->id_or ^ L->id_and;
         const RadixPlan plan = pair_sort_plan(((unsigned long long)idv << 32) | idv,
                                               !no_source_dedup && L->box_valid && L->box_all_known, L->grp_next, L->grp_next_dups);
+        // the sort may go out ahead of the scan's sizes when this frame looks like the last one (bp_layer::AheadHint)
+        static const bool no_ahead = getenv("BP_NO_SORT_AHEAD") != nullptr;  // A/B switch for measurements
+        const bp_layer::AheadHint& h = L->ahead;
+        const unsigned long long varying = ((unsigned long long)idv << 32) | idv;
+        L->ahead_done = false;
+        L->ahead_try = !no_ahead && h.valid && !no_source_dedup && L->box_valid && L->box_all_known && L->grp_next && L->grp_off <= 1 &&
+                       h.varying == varying && h.first_lo == L->id_and && h.first_hi == L->id_or && same_plan(h.plan, plan) &&
+                       L->m <= h.m + h.m / 16 && L->m + L->m / 16 >= h.m &&
+                       group_finish_groups(h.n_raw, varying, L->id_and, L->id_or) == h.n_groups && h.n_groups != 0;
         BP_TRY(scan_fused_device(L, coarse_depth, emit_coarse, !no_source_dedup, nullptr, 0, true, &plan));
+        L->ahead_try = false;
+        if (L->ahead_done) { L->ahead_done = false; return BP_OK; }
         BP_TRY(sort_unique_pairs(L, L->n_raw, L->id_or ^ L->id_and, L->raw_is_unique, L->raw_holes, true));
         if (L->n_raw == 0) BP_TRY(sync_stream(L));
         return BP_OK;
@@ -1753,6 +1867,7 @@ int bp_layer_reset_plan_hints(bp_layer_t* L) {
     L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
     L->grp_next = true; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
     L->enc_hint.valid = false;
+    L->ahead.valid = false;
     return BP_OK;
 }
 int bp_layer_stream(const bp_layer_t* L, void** stream) {

@@ -287,6 +287,9 @@ typedef struct bp_stats {
     uint32_t tree_plan_flips; /* tree sorts whose plan (grouped finish on / off) differs from the previous sort's     */
     uint32_t pair_plan_flips; /* the same for the pair sort's grouped finish                                          */
     uint32_t sort_repairs;    /* deferred tree-sort checks that failed: full-width re-sort + scan run again           */
+    uint32_t sorts_ahead;     /* scans whose pair sort + finish were enqueued behind them, sized by the previous frame
+                                 (no host round trip between scan and sort)                                            */
+    uint32_t sorts_ahead_missed; /* ... of which the frame outgrew those sizes: scan and sort ran again, blocking      */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 

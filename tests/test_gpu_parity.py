@@ -703,6 +703,38 @@ def test_moving_scene_frames_match_the_oracle_frame_by_frame():
         assert_pairs_equal(gpu.scan_device().to_numpy(), ref.par_scan(), "moving frame %d, par_scan" % frame)
     st = gpu.stats()
     assert st["host_syncs"] > ev0["host_syncs"] and all(k in st for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs"))
+    # from the second frame on the pair sort goes out behind the scan, sized by the previous frame (no round trip in between)
+    assert st["sorts_ahead"] >= 2 and st["sorts_ahead_missed"] == 0
+
+
+def test_a_frame_that_outgrows_the_sizes_its_sort_was_enqueued_with_runs_again():
+    """the pair sort of a frame is enqueued behind the scan with grids and buffers sized from the PREVIOUS frame's pair count
+    plus a margin (bp_stats.sorts_ahead); when the boxes grow between two frames -- same objects, same number of index
+    entries or nearly, several times the pairs -- the kernels behind the scan must idle, the miss must be noticed at the
+    frame's one round trip, and the blocking route must deliver the oracle's list; the frames after it go ahead again"""
+    n = 300000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=71)
+    ctr = (bounds[:, :3] + bounds[:, 3:]) * np.float32(0.5)
+    half = (bounds[:, 3:] - bounds[:, :3]) * np.float32(0.5)
+    side = np.float32(sysb[1][0])
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    grew = False
+    for frame, scale in enumerate((1.0, 1.0, 1.9, 1.9, 1.0, 1.0)):
+        h = half * np.float32(scale)
+        cur = np.ascontiguousarray(np.concatenate([np.maximum(ctr - h, np.float32(0)), np.minimum(ctr + h, side)], axis=1).astype(np.float32))
+        ref = oracle.OracleLayer(2, 0)
+        before = gpu.stats()
+        gpu.clear()
+        gpu.extend(sysb, cur, ids); ref.extend(sysb, cur, ids)
+        got, exp = gpu.scan_device().to_numpy(), ref.par_scan()
+        assert_pairs_equal(got, exp, "frame %d (boxes x %.1f)" % (frame, scale))
+        st = gpu.stats()
+        if st["sorts_ahead_missed"] > before["sorts_ahead_missed"]:
+            grew = True
+            assert scale > 1.0 and st["raw_pairs"] == len(exp)
+    st = gpu.stats()
+    assert st["sorts_ahead"] >= 3, st
+    assert grew, "the grown frame should have missed its predicted sizes: %r" % (st,)
 
 
 def test_large_ids_cannot_carry_box_codes_and_still_match():
