@@ -82,7 +82,9 @@ inline size_t enc_blocks(size_t n) { return (n + (size_t)ENC_THREADS * ENC_ROUND
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                                uint32_t min_depth, int have_prev_id, uint32_t prev_id, void* recs,
-                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream);
+                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream,
+                               unsigned long long* zero_a = nullptr, size_t n_a = 0, unsigned long long* zero_b = nullptr, size_t n_b = 0);
+// zero_a / zero_b (optional): words the count pass also zero-fills, spread over its workgroups (the histograms the emit pass adds into)
 // recs: ENC_REC_BYTES per object -- what the emit pass needs of it (first cell per axis, depth, cells per axis), so that
 // launch_encode_emit neither reads the bounds again nor repeats the quantisation
 constexpr size_t ENC_REC_BYTES = 16;
@@ -237,7 +239,10 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 #endif
 constexpr uint32_t SX_BLOCK = SX_BLOCK_DEF;
 constexpr int SX_SHARDS = 64;
-constexpr uint32_t SX_RESERVE = 1024 / SX_BLOCK;  // output blocks a wave reserves per atomic (1024 pairs)
+#ifndef SX_RESERVE_PAIRS
+#define SX_RESERVE_PAIRS 1024
+#endif
+constexpr uint32_t SX_RESERVE = SX_RESERVE_PAIRS / SX_BLOCK;  // output blocks a wave reserves per atomic
 constexpr int SXB_BLOCKS = 2048;    // grid of the work-list kernel
 bool scan_can_count(const RadixPlan& plan);  // launch_scan_expand counts the digits of this plan (hist_plan / hist) iff true
 hipError_t launch_entry_ctx(int kind, const uint64_t* keys, const uint32_t* ids, const uint8_t* box, size_t m,

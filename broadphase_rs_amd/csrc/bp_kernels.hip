@@ -146,8 +146,13 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_count_kernel(SysBounds sb,
                                                                   const u32* __restrict__ ids, size_t n,
                                                                   u32 min_depth, int have_prev, u32 prev_id,
                                                                   uint4* __restrict__ recs, u64* __restrict__ block_sums,
-                                                                  BlockAux* __restrict__ aux, DevScalars* sc) {
+                                                                  BlockAux* __restrict__ aux, DevScalars* sc,
+                                                                  u64* __restrict__ zero_a, u32 n_a, u64* __restrict__ zero_b, u32 n_b) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+    // the frame's zero fills ride along (the histograms encode_emit adds into): every workgroup clears its slice -- one
+    // workgroup of scan_block_sums spent a third of its time on the 256 KB
+    for (size_t k = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x; k < n_a; k += (size_t)gridDim.x * ENC_THREADS) zero_a[k] = 0ull;
+    for (size_t k = (size_t)blockIdx.x * ENC_THREADS + threadIdx.x; k < n_b; k += (size_t)gridDim.x * ENC_THREADS) zero_b[k] = 0ull;
     __shared__ u32 s_sum[ENC_THREADS / 64], s_dm[ENC_THREADS / 64], s_fl[ENC_THREADS / 64], s_er[ENC_THREADS / 64],
         s_inv[ENC_THREADS / 64], s_ior[ENC_THREADS / 64], s_iand[ENC_THREADS / 64], s_imax[ENC_THREADS / 64],
         s_imin[ENC_THREADS / 64];
@@ -2664,20 +2669,44 @@ static_assert(TGRP_THREADS >= TGRP_BINS && TGRP_CAP % TGRP_THREADS == 0, "tree g
 constexpr u32 TGRP_SLOW_MAX = 32768;  // input positions travel as u16 + rounds stay few; longer groups: classic sort
 // bounds[t] = first index whose (key >> gshift) is >= g0 + t, for t = 0 .. n_groups; and, in the same launch, the
 // statistics of the group sizes bounds[t + 1] - bounds[t]: stats[0] = largest group, stats[1] = records in groups above
-// `cap` (both zero beforehand: they live in the scalars the caller has just reset).  A workgroup covers 255 groups: its
-// 256 threads find 256 consecutive bounds, the last one again by the next workgroup.
-__global__ __launch_bounds__(256) void group_bounds_stats_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
-                                                                 u32* __restrict__ bounds, u32 cap, u32* __restrict__ stats,
-                                                                 const u32* __restrict__ dev_sizes = nullptr) {
+// `cap` (both zero beforehand: they live in the scalars the caller has just reset).
+#ifndef GBS_ARY
+#define GBS_ARY 4
+#endif
+// one WAVE per 63 groups (its 64 lanes find 64 consecutive bounds, the last one again by the next wave): at 10 M objects the
+// 39 K bounds are 620 workgroups instead of 153 of 256 threads -- the searches are chains of dependent, uncoalesced loads, and
+// what they need is every CU's load path, not threads per CU
+__global__ __launch_bounds__(64) void group_bounds_stats_kernel(const u64* __restrict__ keys, u32 n, u32 n_groups, u64 g0, int gshift,
+                                                                u32* __restrict__ bounds, u32 cap, u32* __restrict__ stats,
+                                                                const u32* __restrict__ dev_sizes = nullptr) {
     if (dev_sizes) n = dev_sizes[SIZES_N];  // (n was an upper bound)
-    __shared__ u32 s_b[256];
-    __shared__ u32 s_mx[4], s_ov[4];
-    const u32 t = blockIdx.x * 255u + threadIdx.x;
+    const u32 t = blockIdx.x * 63u + threadIdx.x;
     u32 a = n;
     if (t <= n_groups) {
+        // first index whose group is >= key.  GBS_ARY-ary: the probes of a step are independent loads (one memory latency
+        // per step); measured at 1 M / 10 M objects: binary 9.0 / 18.5 us (256-thread workgroups), 16-ary 12 / -- (the probes
+        // are uncoalesced: four times the requests)
         const u64 key = g0 + (u64)t;
         u32 b = n;
         a = 0;
+        constexpr int P = GBS_ARY - 1;
+        while (GBS_ARY > 2 && b - a > (u32)GBS_ARY) {
+            const u32 span = b - a;
+            u64 pv[P > 0 ? P : 1];
+            u32 pp[P > 0 ? P : 1];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                pp[q] = a + (u32)(((u64)span * (u32)(q + 1)) / (u32)GBS_ARY);  // a < pp[q] < b, non-decreasing in q
+                pv[q] = keys[pp[q]];
+            }
+            u32 na = a, nb = b;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                if ((pv[q] >> gshift) < key) na = pp[q] + 1u;          // everything up to pp[q] is below the key
+                else if (pp[q] < nb) nb = pp[q];                       // the first probe at or above the key bounds the answer
+            }
+            a = na; b = nb;
+        }
         while (a < b) {
             const u32 mid = a + ((b - a) >> 1);
             if ((keys[mid] >> gshift) < key) a = mid + 1; else b = mid;
@@ -2685,24 +2714,19 @@ __global__ __launch_bounds__(256) void group_bounds_stats_kernel(const u64* __re
         bounds[t] = a;
     }
     if (!stats) return;
-    s_b[threadIdx.x] = a;
-    __syncthreads();
+    const u32 nxt = (u32)__shfl_down((int)a, 1, 64);
     u32 c = 0;
-    if (threadIdx.x < 255u && t < n_groups) c = s_b[threadIdx.x + 1u] - a;
+    if (threadIdx.x < 63u && t < n_groups) c = nxt - a;
     u32 mx = c, over = c > cap ? c : 0u;
     for (int o = 32; o; o >>= 1) { mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); }
-    if (lane_id() == 0) { s_mx[threadIdx.x >> 6] = mx; s_ov[threadIdx.x >> 6] = over; }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
-        over = s_ov[0] + s_ov[1] + s_ov[2] + s_ov[3];
         if (mx) atomicMax(&stats[0], mx);
         if (over) atomicAdd(&stats[1], over);
     }
 }
 static hipError_t launch_group_bounds_stats(const u64* keys, u32 n, u32 n_groups, u64 g0, int gshift, u32* bounds, u32 cap, u32* stats,
                                             hipStream_t stream, const u32* dev_sizes = nullptr) {
-    group_bounds_stats_kernel<<<(n_groups + 1 + 254) / 255, 256, 0, stream>>>(keys, n, n_groups, g0, gshift, bounds, cap, stats, dev_sizes);
+    group_bounds_stats_kernel<<<(n_groups + 1 + 62) / 63, 64, 0, stream>>>(keys, n, n_groups, g0, gshift, bounds, cap, stats, dev_sizes);
     return hipGetLastError();
 }
 // CTX_KIND >= 0 (with PACKED): also write the scan's per-entry {id, suppression context} word (entry_ctx_kernel's output
@@ -3028,11 +3052,14 @@ inline unsigned grid_for(size_t n, int threads, unsigned cap) {
 
 hipError_t launch_encode_count(int kind, SysBounds sb, const float* bounds, const uint32_t* ids, size_t n,
                                uint32_t min_depth, int have_prev_id, uint32_t prev_id, void* recs,
-                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream) {
+                               unsigned long long* block_sums, BlockAux* aux, DevScalars* sc, hipStream_t stream,
+                               unsigned long long* zero_a, size_t n_a, unsigned long long* zero_b, size_t n_b) {
     if (n == 0) return hipSuccess;
     const unsigned g = (unsigned)enc_blocks(n);
     BP_DISPATCH_KIND(kind, (encode_count_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, have_prev_id,
-                                                                                  prev_id, (uint4*)recs, block_sums, aux, sc)));
+                                                                                  prev_id, (uint4*)recs, block_sums, aux, sc,
+                                                                                  (u64*)zero_a, zero_a ? (u32)n_a : 0u, (u64*)zero_b,
+                                                                                  zero_b ? (u32)n_b : 0u)));
     return hipGetLastError();
 }
 

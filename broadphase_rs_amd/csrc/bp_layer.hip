@@ -453,16 +453,18 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     {
         ProfScope ps(L, BP_K_ENCODE);
+        // (the histograms the emit pass adds into are zero-filled by the count pass, the scalars reset by scan_block_sums: no fills, no H2D copy)
         HIP_TRY(L, launch_encode_count(L->kind, sb, d_bounds, d_ids, n, L->min_depth, 0, 0u, L->counts.p,
-                                       (unsigned long long*)L->block_sums.p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream));
+                                       (unsigned long long*)L->block_sums.p, (BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
+                                       count_digits ? (unsigned long long*)L->tree_hist.p : nullptr,
+                                       (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS,
+                                       count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, cell_bytes / sizeof(unsigned long long)));
     }
     {
         ProfScope ps(L, BP_K_MISC);
         const DevScalars init = neutral_scalars();
         HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
-                                          &init, count_digits ? (unsigned long long*)L->tree_hist.p : nullptr,
-                                          (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS,
-                                          count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, cell_bytes / sizeof(unsigned long long)));
+                                          &init, nullptr, 0, nullptr, 0));
     }
     // The entry total and the facts are final once the block sums are scanned: their copy is enqueued BEFORE encode_emit and
     // the host waits for that copy alone (an event), while encode_emit is already running behind it -- the round trip costs
