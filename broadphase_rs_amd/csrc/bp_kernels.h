@@ -147,11 +147,16 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
                       const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
                       int ready_copies = 1, int unstable_first = 0, uint32_t* epoch_io = nullptr, const DevScalars* sc_init = nullptr,
-                      const uint32_t* dev_sizes = nullptr);
+                      const uint32_t* dev_sizes = nullptr, const struct ScanFinalize* finalize = nullptr);
 // dev_sizes (with ready_hist only: nothing on the host side reads the records): the sort is enqueued behind a producer
 // nobody has waited for -- n and extent are UPPER BOUNDS (they size grids and the workspace), the kernels take the sizes
 // from dev_sizes[SIZES_N] / dev_sizes[SIZES_EXTENT] (launch_scan_finalize writes them; both 0 = do nothing)
 enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_WORDS = 8 };
+// finalize (with dev_sizes): the sort's first kernel also does launch_scan_finalize's job (one launch less): it derives the
+// sizes from the scan's shard words and writes them to `sizes` (== dev_sizes) before any pass reads them
+struct ScanFinalize {
+    const uint64_t* shards; size_t out_blocks, n_bound, extent_bound; const DevScalars* sc; uint32_t* sizes;
+};
 // unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
 // result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
 // varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.

@@ -622,6 +622,27 @@ __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __res
     bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
 }
 
+// one wave: the sizes of a finished expanding scan from its shard cursors and counts (launch_scan_finalize, or the first
+// kernel of the sort enqueued behind the scan)
+__device__ __forceinline__ void scan_finalize_wave(const u64* __restrict__ shards, u64 out_blocks, u64 n_bound, u64 extent_bound,
+                                                   const DevScalars* __restrict__ sc, u32* __restrict__ sizes) {
+    static_assert(SX_SHARDS == 64, "one lane per shard");
+    const int lane = lane_id();
+    u64 kmax = shards[lane], total = shards[SX_SHARDS + lane];
+    for (int o = 32; o; o >>= 1) {
+        const u64 k2 = ((u64)(u32)__shfl_xor((int)(u32)(kmax >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)kmax, o, 64);
+        const u64 t2 = ((u64)(u32)__shfl_xor((int)(u32)(total >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)total, o, 64);
+        kmax = kmax > k2 ? kmax : k2;
+        total += t2;
+    }
+    if (lane != 0) return;
+    const u64 extent_blocks = kmax * (u64)SX_SHARDS, extent = extent_blocks * (u64)SX_BLOCK;
+    const bool ok = extent_blocks <= out_blocks && total <= n_bound && extent <= extent_bound && extent < 0xFFFFFFFFull &&
+                    !(sc->err & (u32)KERR_BIGLIST_OVERFLOW);
+    sizes[SIZES_EXTENT] = ok ? (u32)extent : 0u;
+    sizes[SIZES_N] = ok ? (u32)total : 0u;
+    sizes[SIZES_MISS] = ok ? 0u : 1u;
+}
 #ifndef RS_CUR_STRIDE
 #define RS_CUR_STRIDE 1040  // u32 words between two groups of 16 bin cursors (4160 bytes): the groups spread over memory channels
 #endif
@@ -632,9 +653,13 @@ constexpr int RS_TICKETS = 1;  // ticket counters per pass
 // scalars the sort's kernels report into reset to `sc_init`.
 __global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
                                                                 u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
-                                                                DevScalars sc_init, int set_sc, u32* __restrict__ cursors = nullptr) {
+                                                                DevScalars sc_init, int set_sc, u32* __restrict__ cursors = nullptr,
+                                                                ScanFinalize fin = ScanFinalize{}) {
     __shared__ u64 s_wave[RS_BINS / 64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    // the sizes of the scan this sort was enqueued behind (fin.sc may be the very scalars thread 0 resets below: read first)
+    if (fin.shards && blockIdx.x == 0 && w == 0)
+        scan_finalize_wave((const u64*)fin.shards, (u64)fin.out_blocks, (u64)fin.n_bound, (u64)fin.extent_bound, fin.sc, fin.sizes);
     const size_t k = (size_t)blockIdx.x * RS_BINS + threadIdx.x;
     u64 v;
     if (copies) {
@@ -3235,8 +3260,9 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
                       const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies,
-                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init, const uint32_t* dev_sizes) {
+                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init, const uint32_t* dev_sizes, const ScanFinalize* finalize) {
     if (dev_sizes && (!ready_hist || vals0)) return hipErrorInvalidValue;  // (the counting kernel and the payload passes take host sizes)
+    if (finalize && (!dev_sizes || finalize->sizes != dev_sizes)) return hipErrorInvalidValue;
     static const bool no_unstable = getenv("BP_NO_UNSTABLE_PASS") != nullptr;  // A/B switch
     if (no_unstable) unstable_first = 0;
     *result_buf = 0;
@@ -3284,7 +3310,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     if (sc_init) init = *sc_init;
     if (ready_hist) {  // the producer of the records already counted the digits of this plan
         radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
-                                                         claim ? cursors : nullptr);
+                                                         claim ? cursors : nullptr, finalize ? *finalize : ScanFinalize{});
     } else {
         if (epoch_io) {  // the counting kernel adds into the histogram
             e = hipMemsetAsync(hist, 0, (size_t)np * RS_BINS * sizeof(u64), stream);
@@ -3523,22 +3549,7 @@ hipError_t launch_scan_prepare(DevScalars* sc, const DevScalars& init, uint32_t*
 
 __global__ __launch_bounds__(64) void scan_finalize_kernel(const u64* __restrict__ shards, u64 out_blocks, u64 n_bound, u64 extent_bound,
                                                            const DevScalars* __restrict__ sc, u32* __restrict__ sizes) {
-    static_assert(SX_SHARDS == 64, "one lane per shard");
-    const int lane = lane_id();
-    u64 kmax = shards[lane], total = shards[SX_SHARDS + lane];
-    for (int o = 32; o; o >>= 1) {
-        const u64 k2 = ((u64)(u32)__shfl_xor((int)(u32)(kmax >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)kmax, o, 64);
-        const u64 t2 = ((u64)(u32)__shfl_xor((int)(u32)(total >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)total, o, 64);
-        kmax = kmax > k2 ? kmax : k2;
-        total += t2;
-    }
-    if (lane != 0) return;
-    const u64 extent_blocks = kmax * (u64)SX_SHARDS, extent = extent_blocks * (u64)SX_BLOCK;
-    const bool ok = extent_blocks <= out_blocks && total <= n_bound && extent <= extent_bound && extent < 0xFFFFFFFFull &&
-                    !(sc->err & (u32)KERR_BIGLIST_OVERFLOW);
-    sizes[SIZES_EXTENT] = ok ? (u32)extent : 0u;
-    sizes[SIZES_N] = ok ? (u32)total : 0u;
-    sizes[SIZES_MISS] = ok ? 0u : 1u;
+    scan_finalize_wave(shards, out_blocks, n_bound, extent_bound, sc, sizes);
 }
 hipError_t launch_scan_finalize(const uint64_t* shards, size_t out_blocks, size_t n_bound, size_t extent_bound, const DevScalars* sc,
                                 uint32_t* sizes, hipStream_t stream) {

@@ -1485,10 +1485,8 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 const size_t n_bound = std::min<size_t>(h.n_raw + h.n_raw / 8 + 4096, out_blocks * SX_BLOCK);
                 const size_t extent_bound = std::min<size_t>(std::max(h.extent + h.extent / 8 + (size_t)SX_SHARDS * SX_BLOCK, n_bound), out_blocks * SX_BLOCK);
                 uint32_t* const d_sizes = sc_sizes_dev(L);
-                {
-                    ProfScope ps(L, BP_K_MISC);
-                    HIP_TRY(L, launch_scan_finalize(d_shards, out_blocks, n_bound, extent_bound, (const DevScalars*)L->d_sc.p, d_sizes, L->stream));
-                }
+                // (the sort's first kernel derives the sizes from the shard words: launch_scan_finalize's job without the launch)
+                const ScanFinalize fin{d_shards, out_blocks, n_bound, extent_bound, (const DevScalars*)L->d_sc.p, d_sizes};
                 uint64_t* bufs[2] = {(uint64_t*)L->pairs[0].p, nullptr};
                 BP_TRY(ensure_dev(L, L->pairs[1], n_bound * sizeof(uint64_t)));
                 bufs[1] = (uint64_t*)L->pairs[1].p;
@@ -1500,7 +1498,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                     HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n_bound, h.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                           &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
                                           (const uint32_t*)L->blockfill.p, extent_bound, (const unsigned long long*)L->pair_hist.p, HIST_COPIES,
-                                          /*unstable_first=*/1, ws_epoch, &sc_init, d_sizes));
+                                          /*unstable_first=*/1, ws_epoch, &sc_init, d_sizes, &fin));
                 }
                 BP_TRY(ensure_dev(L, L->out_pairs, n_bound * 2 * sizeof(uint32_t)));
                 BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)h.n_groups + 1) * sizeof(uint32_t)));
