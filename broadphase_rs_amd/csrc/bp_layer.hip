@@ -1855,6 +1855,13 @@ int bp_layer_destroy(bp_layer_t* L) {
 int bp_layer_wait_stream(bp_layer_t* L, void* producer_stream) {
     if (!L) return BP_ERR_INVALID_ARG;
     DeviceGuard g(L->device);
+    // a producer stream with nothing in flight needs no fence (the per-frame case: the boxes were written long ago) -- an event
+    // wait in the layer's stream costs the frame's first kernel a few microseconds
+    {
+        const hipError_t q = hipStreamQuery((hipStream_t)producer_stream);
+        if (q == hipSuccess) return BP_OK;
+        if (q != hipErrorNotReady) (void)hipGetLastError();
+    }
     if (!L->fence_ev) HIP_TRY(L, hipEventCreateWithFlags(&L->fence_ev, hipEventDisableTiming));
     HIP_TRY(L, hipEventRecord(L->fence_ev, (hipStream_t)producer_stream));
     HIP_TRY(L, hipStreamWaitEvent(L->stream, L->fence_ev, 0));

@@ -352,9 +352,13 @@ class Layer:
     def extend(self, system_bounds, bounds, ids):
         """src/layer.rs:94-121.  bounds: (n, 2*dim) f32 rows [min.., max..]; ids: (n,) u32."""
         dim = self.index.dim
-        smin = np.ascontiguousarray(np.asarray(system_bounds[0], dtype=np.float32).reshape(dim))
-        smax = np.ascontiguousarray(np.asarray(system_bounds[1], dtype=np.float32).reshape(dim))
-        f32p = C.POINTER(C.c_float)
+        # (the per-frame call: the two corner points go straight into C float arrays; numpy's conversion chain took 5 us)
+        fvec = C.c_float * dim
+        try:
+            c_min, c_max = fvec(*system_bounds[0]), fvec(*system_bounds[1])
+        except TypeError:  # nested / oddly shaped input: let numpy flatten it
+            c_min = fvec(*np.asarray(system_bounds[0], dtype=np.float32).reshape(dim))
+            c_max = fvec(*np.asarray(system_bounds[1], dtype=np.float32).reshape(dim))
         if _is_device_tensor(bounds) or _is_device_tensor(ids):
             if not (_is_device_tensor(bounds) and _is_device_tensor(ids)):
                 raise ValueError("bounds and ids must both be device tensors or both be host arrays")
@@ -364,15 +368,13 @@ class Layer:
             if not (bounds.is_contiguous() and ids.is_contiguous()):
                 raise ValueError("device tensors must be contiguous")
             self._fence(bounds, ids)
-            self._check(self._L.bp_layer_extend_device(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p),
-                                                       C.c_void_p(bounds.data_ptr()), C.c_void_p(ids.data_ptr()), n))
+            self._check(self._L.bp_layer_extend_device(self._h, c_min, c_max, C.c_void_p(bounds.data_ptr()), C.c_void_p(ids.data_ptr()), n))
             return
         b = np.ascontiguousarray(np.asarray(bounds, dtype=np.float32).reshape(-1, 2 * dim))
         i = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32).reshape(-1))
         if len(b) != len(i):
             raise ValueError("bounds and ids differ in length")
-        self._check(self._L.bp_layer_extend_host(self._h, smin.ctypes.data_as(f32p), smax.ctypes.data_as(f32p),
-                                                 C.c_void_p(b.ctypes.data), C.c_void_p(i.ctypes.data), len(i)))
+        self._check(self._L.bp_layer_extend_host(self._h, c_min, c_max, C.c_void_p(b.ctypes.data), C.c_void_p(i.ctypes.data), len(i)))
 
     def merge(self, other):  # src/layer.rs:127-138
         self._check(self._L.bp_layer_merge(self._h, other._h))
