@@ -147,16 +147,49 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
                       int class_hist, int class_sort, const uint8_t* box_in = nullptr, uint8_t* box_out = nullptr,
                       const uint32_t* blockfill = nullptr, size_t extent = 0, const unsigned long long* ready_hist = nullptr,
                       int ready_copies = 1, int unstable_first = 0, uint32_t* epoch_io = nullptr, const DevScalars* sc_init = nullptr,
-                      const uint32_t* dev_sizes = nullptr, const struct ScanFinalize* finalize = nullptr);
+                      const uint32_t* dev_sizes = nullptr, const struct ScanFinalize* finalize = nullptr,
+                      const struct CellRoute* cells = nullptr);
 // dev_sizes (with ready_hist only: nothing on the host side reads the records): the sort is enqueued behind a producer
 // nobody has waited for -- n and extent are UPPER BOUNDS (they size grids and the workspace), the kernels take the sizes
 // from dev_sizes[SIZES_N] / dev_sizes[SIZES_EXTENT] (launch_scan_finalize writes them; both 0 = do nothing)
-enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_WORDS = 8 };
+enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_CELL_MISS = 3, SIZES_WORDS = 8 };
 // finalize (with dev_sizes): the sort's first kernel also does launch_scan_finalize's job (one launch less): it derives the
 // sizes from the scan's shard words and writes them to `sizes` (== dev_sizes) before any pass reads them
 struct ScanFinalize {
     const uint64_t* shards; size_t out_blocks, n_bound, extent_bound; const DevScalars* sc; uint32_t* sizes;
 };
+// cells (two key passes, key-only records, unstable_first, counts ready): NO pass keeps a stable order.  The claiming pass
+// goes by the HIGH digit (plan.shift[1]) and a second claiming pass spreads every high bin over its 256 CELLS (high digit,
+// low digit), whose ranges were laid out beforehand with room to spare (launch_cell_layout: from the cells' sizes in the
+// PREVIOUS sort of the same kind).  The result is in keys0, gapped: cell c holds 16 * line_cur[c] records from
+// cell_base[c] upwards and frag_cur[c] records from cell_base[c + 1] downwards (launch_cell_count turns the cursors into
+// the exact group bounds a finishing kernel writes its dense output by).  A cell that overflowed sets *miss: the result
+// is incomplete and the caller sorts again the plain way.
+// would a sort of `extent` slots take radix_claim_kernel for its first pass (size threshold and switches, read per call)?
+bool radix_claim_applies(size_t extent);
+constexpr uint32_t CELL_COUNT = 65536;
+struct CellRoute {
+    const uint32_t* cell_base;  // [CELL_COUNT + 1], multiples of 16
+    uint32_t* line_cur;         // [CELL_COUNT] zero at launch
+    uint32_t* frag_cur;         // [CELL_COUNT] zero at launch
+    uint32_t* miss;             // one word, zero at launch
+    uint4* src;                 // [CELL_COUNT] scratch: launch_cell_count leaves every group's two input pieces here for the finish kernel
+    unsigned long long* status; // [64] scratch of the two cell walks (zero once, when allocated)
+    uint32_t tag;               // an even number the caller never repeats for this `status` (launch_cell_layout tags its walk with it, launch_cell_count with tag + 1)
+};
+// cell_base from the group bounds of the previous sort (prev_bounds[g] = start of group prev_g0 + g, g = 0 .. prev_groups; cell
+// index = group index = first id >> 8): capacity = count + 25 % + 64, rounded to whole lines (an empty cell: one line);
+// also zeroes the cursors and the miss word.  total_cap (host, optional): upper bound of cell_base[CELL_COUNT] for n records.
+// limit: slots of the buffer the cells live in -- a layout that would not fit (prev_bounds not what the caller thought) gives
+// every cell the range [0, 0) and sets *miss
+hipError_t launch_cell_layout(const uint32_t* prev_bounds, uint32_t prev_g0, uint32_t prev_groups, uint32_t* cell_base, uint32_t* line_cur,
+                              uint32_t* frag_cur, uint32_t* miss, size_t limit, unsigned long long* status, uint32_t tag, hipStream_t stream);
+inline size_t cell_layout_capacity(size_t n) { return n + n / 4 + (size_t)CELL_COUNT * 80; }
+// after the sort: bounds[g] (g = 0 .. n_groups) = exact prefix of the sizes of cells g0 .. g0 + n_groups - 1, the group statistics
+// launch_group_finish wants in stats[0..1], and *miss |= 1 when a cell holds more than its range or the total differs from
+// dev_sizes[SIZES_N]
+hipError_t launch_cell_count(const CellRoute& cells, uint32_t g0, uint32_t n_groups, uint32_t* bounds, uint32_t cap, uint32_t* stats,
+                             const uint32_t* dev_sizes, hipStream_t stream);
 // unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
 // result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
 // varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.
@@ -357,7 +390,8 @@ int tgroup_bin_bits();  // key bits below gshift the finish uses for its countin
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
                                uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats = nullptr,
                                uint32_t second_max = 0xFFFFFFFFu,  // an upper bound of the second ids (only speed depends on it)
-                               const uint32_t* dev_sizes = nullptr);  // n is an upper bound, the count is dev_sizes[SIZES_N]
+                               const uint32_t* dev_sizes = nullptr,  // n is an upper bound, the count is dev_sizes[SIZES_N]
+                               const struct CellRoute* cells = nullptr);  // `in` is the gapped result of a cell sort: bounds come from launch_cell_count (not computed here)
 // stats (2 words of scratch): group-size statistics; with more than a quarter of the pairs in oversize groups the finish
 // does nothing and sets KERR_SEGMENT_TOO_LONG
 int group_finish_capacity();

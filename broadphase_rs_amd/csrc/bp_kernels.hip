@@ -1051,6 +1051,13 @@ struct ClaimArgs {
     // sizes known only on the device (a sort enqueued behind its producer, see SIZES_*): n / n_out / n_tiles above are upper
     // bounds that sized the grid and the workspace
     const u32* dev_sizes;
+    // CELLS mode (the second pass of a sort whose first, claiming pass went by the HIGH digit `hi_shift`): the records of high
+    // bin h and digit d go to cell h * 256 + d, a range laid out beforehand with room to spare -- cell_base[c] (a multiple of
+    // RC_LINE; keys_out is line-aligned) .. cell_base[c + 1]: whole lines are claimed upwards from its start
+    // (cell_line_cur[c]), what is left over (a workgroup's carry when it leaves the high bin) record by record downwards from
+    // its end (cell_frag_cur[c]).  A cell that would overflow drops the records and sets *miss.
+    const u32* cell_base; u32* cell_line_cur; u32* cell_frag_cur; u32* miss;
+    int hi_shift;
 };
 
 // Bin b's output range [B, E): the aligned interior starts at A and holds I whole lines, handed out upwards from A.  What
@@ -1074,9 +1081,10 @@ __device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.
 #ifndef SW_EXP
 #define SW_EXP 0  // timing experiments (results are WRONG): 1 no key stores
 #endif
-template <typename V>
+template <typename V, bool CELLS = false>
 __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     typedef u64 K;
+    static_assert(!CELLS || StageBytes<V>::value == 0, "cell mode: key-only records");
     constexpr int T = RC_THREADS, ITEMS = RC_ITEMS, TILE = RC_TILE;
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
     static_assert((64 * ITEMS) % HOLE_BLOCK == 0 && TILE % HOLE_BLOCK == 0, "waves must not straddle blocks");
@@ -1090,9 +1098,11 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     __shared__ u32 s_c0[RS_BINS], s_keep[RS_BINS], s_ko[RS_BINS], s_glob[RS_BINS], s_lim[RS_BINS];
     __shared__ u32 s_ws[RC_WAVES];
     __shared__ u32 s_over;
+    __shared__ u32 s_hb[2];  // CELLS: high digit of the tile's first / last record
 
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     const ShiftDigit digit{a.shift};
+    const ShiftDigit digit_hi{a.hi_shift};
     const K* __restrict__ keys_in = a.keys_in;
     K* __restrict__ keys_out = a.keys_out;
     const V* __restrict__ vals_in = (const V*)a.vals_in;
@@ -1107,15 +1117,18 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     // the per-lane pointers and offsets of every phase cost more registers than the tile's records)
     auto opaque = [](u32 v) { asm volatile("" : "+v"(v)); return v; };
 
-    // owner threads (one per bin): the bin's aligned interior
+    // owner threads (one per bin): the bin's aligned interior (CELLS: set when the workgroup enters a high bin)
     u32 own_A = 0, own_I = 0;
     if (tid < RS_BINS) {
-        const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
-        own_A = g.A; own_I = g.I;
-        s_lim[tid] = g.A + g.I * RC_LINE;
+        if (!CELLS) {
+            const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
+            own_A = g.A; own_I = g.I;
+            s_lim[tid] = g.A + g.I * RC_LINE;
+        }
         s_c0[tid] = 0u; s_keep[tid] = 0u; s_cnt[0][tid] = 0u; s_cnt[1][tid] = 0u;
     }
     if (tid == 0) s_over = 0u;
+    u32 cur_hi = 0xFFFFFFFFu;  // CELLS: the high bin the carried records belong to
 
     K key[ITEMS];
     u32 vmask = 0;  // bit r: record r of this lane exists
@@ -1156,13 +1169,86 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             vmask &= keep;
         }
     };
-    u32 tile = (u32)blockIdx.x;
-    fetch(tile);
+    // CELLS: a workgroup takes a CONTIGUOUS range of tiles (it stays inside a high bin for as long as possible: its carry
+    // is flushed whenever it leaves one); otherwise the tiles are dealt round robin
+    const u32 tiles_per = CELLS ? (n_tiles + (u32)gridDim.x - 1u) / (u32)gridDim.x : 1u;
+    const u32 tile_step = CELLS ? 1u : (u32)gridDim.x;
+    const u32 tile_end = CELLS ? min(n_tiles, ((u32)blockIdx.x + 1u) * tiles_per) : n_tiles;
+    u32 tile = CELLS ? (u32)blockIdx.x * tiles_per : (u32)blockIdx.x;
+    auto fetch_next = [&](u32 t) { if (t < tile_end) fetch(t); else vmask = 0; };
+    fetch_next(tile);
     u32 own_keep = 0;  // owner: records of its bin the workgroup carries into the next tile
     __syncthreads();
 
-    for (u32 it = 0; tile < n_tiles; tile += (u32)gridDim.x, ++it) {
-        const u32 cur_vmask = vmask;
+    // what the workgroup still carries goes to the fragment slots of its bins (the end of the kernel; CELLS: also whenever
+    // it moves on to another high bin)
+    auto flush_carry = [&]() {
+        __syncthreads();
+        if (tid < RS_BINS) {
+            s_keep[tid] = own_keep;
+            if (own_keep) {
+                if (CELLS) s_glob[tid] = atomicAdd(a.cell_frag_cur + (size_t)cur_hi * RS_BINS + (u32)tid, own_keep);
+                else s_glob[tid] = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), own_keep);
+            }
+        }
+        __syncthreads();
+        for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
+            const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE;
+            if (i < s_keep[b]) {
+                if (CELLS) {
+                    const size_t c = (size_t)cur_hi * RS_BINS + b;
+                    const u32 lim = a.cell_base[CELL_COUNT], ce = min(a.cell_base[c + 1], lim), cb = min(a.cell_base[c], ce);
+                    const u32 q = s_glob[b] + i;
+                    if (q < ce - cb) keys_out[ce - 1u - q] = s_carry[b][i];
+                    else *a.miss = 1u;
+                } else {
+                    const BinGeom g = bin_geom(a.bin_base, b, n_out, a0);
+                    const u32 pos = frag_pos(g, s_glob[b] + i);
+                    keys_out[pos] = s_carry[b][i];
+                    if constexpr (HAS_VAL) vals_out[pos] = (V)s_carry_v[b][i];
+                }
+            }
+        }
+        __syncthreads();
+        own_keep = 0;
+    };
+
+    u32 it = 0;
+    for (; tile < tile_end; tile += tile_step) {
+      // CELLS: the tile's records are sorted by the high digit: one sub-pass per high bin it touches (all but ~1 % of the
+      // tiles lie inside one)
+      u32 hb_lo = 0, hb_hi = 0;
+      if (CELLS) {
+          const size_t tbase = (size_t)tile * TILE;
+          const u32 tile_n = (u32)((n - tbase) < (size_t)TILE ? (n - tbase) : (size_t)TILE);
+          if (tid == 0) s_hb[0] = digit_hi(key[0]);
+#pragma unroll
+          for (int r = 0; r < ITEMS; ++r)
+              if (wbase + (u32)r * 64u == tile_n - 1u) s_hb[1] = digit_hi(key[r]);
+          __syncthreads();
+          hb_lo = s_hb[0]; hb_hi = s_hb[1];
+      }
+      for (u32 hb = hb_lo; hb <= hb_hi; ++hb, ++it) {
+        const bool last_sub = hb == hb_hi;
+        u32 cur_vmask = vmask;
+        if (CELLS) {
+            if (hb != cur_hi) {  // (workgroup-uniform) leave the high bin: flush, then the new bin's cells
+                if (cur_hi != 0xFFFFFFFFu) flush_carry();
+                cur_hi = hb;
+                if (tid < RS_BINS) {
+                    // (clipped to the layout's total -- 0 after a failed layout --: whatever the ranges say, nothing leaves the buffer)
+                    const size_t c = (size_t)cur_hi * RS_BINS + (u32)tid;
+                    const u32 lim = a.cell_base[CELL_COUNT], ce = min(a.cell_base[c + 1], lim);
+                    own_A = min(a.cell_base[c], ce);
+                    own_I = (ce - own_A) / RC_LINE;
+                    s_lim[tid] = own_A + own_I * RC_LINE;
+                }
+            }
+            u32 m = 0;
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) m |= digit_hi(key[r]) == hb ? (1u << r) : 0u;
+            cur_vmask &= m;
+        }
         const size_t base = (size_t)tile * TILE;
         u32* const cnt_cur = s_cnt[it & 1u];
 
@@ -1207,7 +1293,10 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             s_cnt[(it & 1u) ^ 1u][tid] = 0u;  // the next tile's counters (last touched a whole tile ago)
             nl = c / RC_LINE; keep = c % RC_LINE;
             packed = (nl << 16) | keep;
-            if (nl) l0 = atomicAdd(a.line_cur + sw_cursor_slot((u32)tid), nl);  // consumed after the tile sits in LDS
+            if (nl) {  // consumed after the tile sits in LDS
+                if (CELLS) l0 = atomicAdd(a.cell_line_cur + (size_t)cur_hi * RS_BINS + (u32)tid, nl);
+                else l0 = atomicAdd(a.line_cur + sw_cursor_slot((u32)tid), nl);
+            }
         }
         u32 tot;
         const u32 ex = block_excl_scan_u32<T>(packed, s_ws, tot);
@@ -1245,8 +1334,8 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
                 s_stage[dest] = s_carry[b][i];
             }
         }
-        // the next tile's keys: in flight under this tile's stores
-        fetch(tile + (u32)gridDim.x);
+        // the next tile's keys: in flight under this tile's stores (CELLS: the keys are still needed by the tile's next sub-pass)
+        if (last_sub) fetch_next(tile + tile_step);
 
         // ---- the claimed lines' positions --------------------------------------------------------------------------
         bool over = false;  // owner: its claim reaches beyond the bin's interior (at most one line per bin and launch)
@@ -1254,6 +1343,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             s_glob[tid] = own_A + l0 * RC_LINE - foff;
             over = nl != 0 && l0 + nl > own_I;
             if (over) s_over = 1u;
+            if (CELLS && over) *a.miss = 1u;  // the cell was laid out too small: the lines beyond it are dropped
         }
         __syncthreads();
 
@@ -1282,7 +1372,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         }
         // a line beyond the interior: its records fill fragment slots instead (rare: the owner moves them alone)
         u32 over_q = 0, over_at = 0;
-        if (over) {
+        if (!CELLS && over) {
             const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
             const u32 first = l0 > own_I ? l0 : own_I;  // first line index beyond the interior
             over_at = foff + (first - l0) * RC_LINE;
@@ -1326,7 +1416,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
                 }
                 if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            if (over) {
+            if (!CELLS && over) {
                 const BinGeom g = bin_geom(a.bin_base, (u32)tid, n_out, a0);
                 const u32 first = l0 > own_I ? l0 : own_I;
                 const u32 cnt = (l0 + nl - first) * RC_LINE;
@@ -1342,24 +1432,12 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             __syncthreads();
             if (tid == 0) s_over = 0u;
         }
+        if (CELLS && !last_sub) __syncthreads();  // the next sub-pass reuses the tile's LDS bookkeeping
+      }
     }
 
-    // ---- what the workgroup still carries: into the fragment slots of its bin -------------------------------------------
-    __syncthreads();
-    if (tid < RS_BINS) {
-        s_keep[tid] = own_keep;
-        if (own_keep) s_glob[tid] = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), own_keep);
-    }
-    __syncthreads();
-    for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
-        const u32 b = (u32)slot / RC_LINE, i = (u32)slot % RC_LINE;
-        if (i < s_keep[b]) {
-            const BinGeom g = bin_geom(a.bin_base, b, n_out, a0);
-            const u32 pos = frag_pos(g, s_glob[b] + i);
-            keys_out[pos] = s_carry[b][i];
-            if constexpr (HAS_VAL) vals_out[pos] = (V)s_carry_v[b][i];
-        }
-    }
+    // ---- what the workgroup still carries: into the fragment slots of its bins ------------------------------------------
+    if (!CELLS || cur_hi != 0xFFFFFFFFu) flush_carry();
 }
 
 // =================================================================================================
@@ -3220,14 +3298,155 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 }
 
 // the claiming first pass (radix_claim_kernel): one persistent workgroup per CU
-template <typename V>
+template <typename V, bool CELLS = false>
 static hipError_t launch_claim(const ClaimArgs& a, hipStream_t stream) {
 #ifndef RS_GEOMETRY_EXPERIMENT
     static_assert(RC_TILE == RS_THREADS_DEF * RS_ITEMS_DEF, "the pass kernels share the tile size (holes, workspace)");
 #endif
-    static const unsigned resident = resident_blocks(radix_claim_kernel<V>, RC_THREADS);
+    static const unsigned resident = resident_blocks(radix_claim_kernel<V, CELLS>, RC_THREADS);
     const unsigned grid = a.n_tiles < resident ? a.n_tiles : resident;
-    radix_claim_kernel<V><<<grid, RC_THREADS, 0, stream>>>(a);
+    radix_claim_kernel<V, CELLS><<<grid, RC_THREADS, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+// ---- cell route (CellRoute, bp_kernels.h) --------------------------------------------------------------------------------
+// ---- cell route (CellRoute, bp_kernels.h) --------------------------------------------------------------------------------
+// (+ 25 % + 64: between two frames of the moving-scene bench -- every object re-placed by up to half its size -- the worst of 39 K
+// cells grows by 18 - 22 %; the gaps cost address space in a buffer sized for the scan's raw output anyway, not bandwidth)
+__device__ __forceinline__ u32 cell_capacity(u32 cnt) { return cnt ? (cnt + cnt / 4u + 64u + (u32)(RC_LINE - 1)) & ~(u32)(RC_LINE - 1) : (u32)RC_LINE; }
+// A walk over the 65536 cells with an exclusive prefix, in ONE launch of CELL_WGS workgroups: every workgroup loads its 1024
+// cells (consecutive threads on consecutive cells, all loads of a thread issued before anything is computed), publishes their
+// sum in a status word tagged with the launch (no zero fill between launches) and adds up the sums of the workgroups before
+// it -- all CELL_WGS workgroups are resident, so the wait is a few hundred nanoseconds.  (One workgroup walking all cells took
+// 25 - 115 us: a single CU's memory pipe.)
+constexpr int CELL_WGS = 64, CELL_THREADS = 256, CELL_PER_THREAD = (int)CELL_COUNT / (CELL_WGS * CELL_THREADS);
+static_assert(CELL_PER_THREAD == 4, "cell walk geometry");
+constexpr u64 CELL_SUM_MASK = (1ull << 40) - 1ull;
+template <class Load, class Value, class Emit>
+__device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Value&& value, Emit&& emit) {
+    __shared__ u32 s_ws[CELL_THREADS / 64];
+    __shared__ u64 s_before;
+    const u32 t = threadIdx.x, b = blockIdx.x;
+    uint4 raw[CELL_PER_THREAD];
+    u32 v[CELL_PER_THREAD], ex[CELL_PER_THREAD], row[CELL_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < CELL_PER_THREAD; ++k) raw[k] = load(b * 1024u + (u32)k * CELL_THREADS + t);
+    __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler pairs every cell's loads with their use: a wait per cell)
+#pragma unroll
+    for (int k = 0; k < CELL_PER_THREAD; ++k) v[k] = value(b * 1024u + (u32)k * CELL_THREADS + t, raw[k]);
+    u32 wg_total = 0;
+#pragma unroll
+    for (int k = 0; k < CELL_PER_THREAD; ++k) {  // cell order inside the workgroup: row k, then thread
+        u32 tot;
+        ex[k] = block_excl_scan_u32<CELL_THREADS>(v[k], s_ws, tot);
+        row[k] = wg_total;
+        wg_total += tot;
+        __syncthreads();
+    }
+    if (t == 0u) __hip_atomic_store(&status[b], ((u64)tag << 40) | (u64)wg_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 64u) {  // wave 0: the sums of the workgroups before this one
+        u64 mine = 0;
+        if (t < b) {
+            for (;;) {
+                const u64 w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((u32)(w >> 40) == tag) { mine = w & CELL_SUM_MASK; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        for (int o = 32; o; o >>= 1)
+            mine += ((u64)(u32)__shfl_xor((int)(u32)(mine >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)mine, o, 64);
+        if (t == 0u) s_before = mine;
+    }
+    __syncthreads();
+    const u64 before = s_before;
+#pragma unroll
+    for (int k = 0; k < CELL_PER_THREAD; ++k) emit(b * 1024u + (u32)k * CELL_THREADS + t, (u32)before + row[k] + ex[k], v[k], raw[k]);
+    return before + wg_total;  // (the last workgroup: the grand total)
+}
+__global__ __launch_bounds__(CELL_THREADS) void cell_layout_kernel(const u32* __restrict__ prev_bounds, u32 prev_g0, u32 prev_groups,
+                                                                   u32* __restrict__ cell_base, u32* __restrict__ line_cur,
+                                                                   u32* __restrict__ frag_cur, u32* __restrict__ miss, u64 limit,
+                                                                   u64* status, u32 tag) {
+    // (capacities are clamped: prev_bounds may be anything when the caller's bookkeeping was wrong -- the total then fails the
+    // limit and *miss is set: the sort's kernels drop what does not fit its cell, nothing is written out of bounds as long as
+    // limit <= the buffer, because cell_base[CELL_COUNT] is what every range is clipped to)
+    const u64 total = cells_walk(
+        status, tag,
+        [&](u32 c) {
+            const u32 g = c - prev_g0;  // (wraps for c < prev_g0: then g >= prev_groups)
+            const u32 gi = g < prev_groups ? g : 0u;  // (the load is unconditional: prev_bounds has at least two words)
+            return make_uint4(prev_bounds[gi], prev_bounds[gi + 1u], g < prev_groups ? 1u : 0u, 0u);
+        },
+        [&](u32, uint4 r) { return cell_capacity(min(r.z ? r.y - r.x : 0u, 1u << 16)); },
+        [&](u32 c, u32 at, u32, uint4) {
+            cell_base[c] = at;
+            line_cur[c] = 0u;
+            frag_cur[c] = 0u;
+        });
+    if (blockIdx.x == CELL_WGS - 1 && threadIdx.x == 0u) {
+        const bool fits = total <= limit && total < 0xFFFFFFFFull;
+        cell_base[CELL_COUNT] = (u32)(fits ? total : 0ull);
+        *miss = fits ? 0u : 1u;
+    }
+}
+hipError_t launch_cell_layout(const uint32_t* prev_bounds, uint32_t prev_g0, uint32_t prev_groups, uint32_t* cell_base, uint32_t* line_cur,
+                              uint32_t* frag_cur, uint32_t* miss, size_t limit, unsigned long long* status, uint32_t tag, hipStream_t stream) {
+    if (prev_groups == 0) return hipErrorInvalidValue;
+    cell_layout_kernel<<<CELL_WGS, CELL_THREADS, 0, stream>>>(prev_bounds, prev_g0, prev_groups, cell_base, line_cur, frag_cur, miss, (u64)limit,
+                                                              (u64*)status, tag);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(CELL_THREADS) void cell_count_kernel(CellRoute cr, u32 g0, u32 n_groups, u32* __restrict__ bounds, u32 cap,
+                                                                  u32* __restrict__ stats, const u32* __restrict__ dev_sizes, u64* status, u32 tag) {
+    __shared__ u32 s_mx[CELL_THREADS / 64], s_ov[CELL_THREADS / 64], s_bad[CELL_THREADS / 64];
+    const u32* __restrict__ const lc = cr.line_cur;
+    const u32* __restrict__ const fc = cr.frag_cur;
+    const u32* __restrict__ const cb = cr.cell_base;
+    uint4* __restrict__ const srcs = cr.src;
+    const u32 t = threadIdx.x;
+    const u32 limit = cb[CELL_COUNT];  // (every cell's range is clipped to the layout's total: a failed layout leaves 0)
+    u32 mx = 0, over = 0, bad = 0;
+    const u64 total = cells_walk(
+        status, tag,
+        [&](u32 c) { return make_uint4(lc[c], fc[c], cb[c], cb[c + 1u]); },  // {lines, fragment records, start, end}
+        [&](u32 c, uint4 r) {
+            const u32 cnt = r.x * (u32)RC_LINE + r.y;
+            const bool in_range = c >= g0 && c - g0 < n_groups;
+            // the two fronts of the cell ran into each other / no finish kernel could take it / a first id outside the range the
+            // caller vouched for / the layout failed
+            bad |= (cnt > r.w - r.z || r.w > limit || cnt >= 65536u || (cnt != 0u && !in_range)) ? 1u : 0u;
+            mx = max(mx, cnt);
+            over += cnt > cap ? cnt : 0u;
+            return cnt;
+        },
+        [&](u32 c, u32 at, u32 cnt, uint4 r) {
+            if (c >= g0 && c - g0 <= n_groups) bounds[c - g0] = at;  // (bounds[n_groups]: the total -- the cells behind the groups are empty)
+            // everything the finish kernel needs of group c - g0 in one 16-byte word: where its whole lines start, where the
+            // records claimed downwards start, its offset in the dense output, its size and how much of it is whole lines
+            if (c >= g0 && c - g0 < n_groups) srcs[c - g0] = make_uint4(r.z, r.w - r.y, at, ((cnt & 0xFFFFu) << 16) | ((cnt - r.y) & 0xFFFFu));
+        });
+    for (int o = 32; o; o >>= 1) {
+        mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); bad |= (u32)__shfl_xor((int)bad, o, 64);
+    }
+    if (lane_id() == 0) { s_mx[t >> 6] = mx; s_ov[t >> 6] = over; s_bad[t >> 6] = bad; }
+    __syncthreads();
+    if (t == 0u) {
+        for (int k = 1; k < CELL_THREADS / 64; ++k) { mx = max(mx, s_mx[k]); over += s_ov[k]; bad |= s_bad[k]; }
+        if (stats) {
+            if (mx) atomicMax(&stats[0], mx);
+            if (over) atomicAdd(&stats[1], over);
+        }
+        if (blockIdx.x == CELL_WGS - 1) {
+            if (g0 + n_groups == CELL_COUNT) bounds[n_groups] = (u32)total;
+            if (total >= 0xFFFFFFFFull || (dev_sizes && (u32)total != dev_sizes[SIZES_N])) bad = 1u;
+        }
+        if (bad) *cr.miss = 1u;
+    }
+}
+hipError_t launch_cell_count(const CellRoute& cells, uint32_t g0, uint32_t n_groups, uint32_t* bounds, uint32_t cap, uint32_t* stats,
+                             const uint32_t* dev_sizes, hipStream_t stream) {
+    if ((size_t)g0 + n_groups > CELL_COUNT) return hipErrorInvalidValue;
+    cell_count_kernel<<<CELL_WGS, CELL_THREADS, 0, stream>>>(cells, g0, n_groups, bounds, cap, stats, dev_sizes, (u64*)cells.status, cells.tag + 1u);
     return hipGetLastError();
 }
 
@@ -3255,12 +3474,21 @@ static hipError_t launch_onesweep(const K* ki, K* ko, const V* vi, V* vo, size_t
     return hipGetLastError();
 }
 
+bool radix_claim_applies(size_t extent) {
+    const char* const claim_env = getenv("BP_RADIX_CLAIM");
+    const char* const claim_min_env = getenv("BP_RADIX_CLAIM_MIN_TILES");
+    const bool claim_off = claim_env != nullptr && atoi(claim_env) == 0;
+    const size_t claim_min_tiles = claim_min_env ? (size_t)atoll(claim_min_env) : 256;
+    return !claim_off && rs_num_tiles(extent) >= claim_min_tiles;
+}
+
 hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, size_t n,
                       const RadixPlan& plan, void* workspace, size_t workspace_bytes, DevScalars* sc,
                       int* result_buf, hipStream_t stream, void (*mark)(void*, int), void* mark_ctx,
                       int class_hist, int class_sort, const uint8_t* box_in, uint8_t* box_out,
                       const uint32_t* blockfill, size_t extent, const unsigned long long* ready_hist, int ready_copies,
-                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init, const uint32_t* dev_sizes, const ScanFinalize* finalize) {
+                      int unstable_first, uint32_t* epoch_io, const DevScalars* sc_init, const uint32_t* dev_sizes, const ScanFinalize* finalize,
+                      const CellRoute* cells) {
     if (dev_sizes && (!ready_hist || vals0)) return hipErrorInvalidValue;  // (the counting kernel and the payload passes take host sizes)
     if (finalize && (!dev_sizes || finalize->sizes != dev_sizes)) return hipErrorInvalidValue;
     static const bool no_unstable = getenv("BP_NO_UNSTABLE_PASS") != nullptr;  // A/B switch
@@ -3284,11 +3512,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     // the first pass of a sort that a finishing kernel completes: radix_claim_kernel (line-aligned stores, no chain) when the
     // input is large enough for its persistent workgroups to amortise their final partial lines; BP_RADIX_CLAIM=0: off
     // (the two switches are read per sort, so that the tests can force the kernel onto small inputs)
-    const char* const claim_env = getenv("BP_RADIX_CLAIM");
-    const char* const claim_min_env = getenv("BP_RADIX_CLAIM_MIN_TILES");
-    const bool claim_off = claim_env != nullptr && atoi(claim_env) == 0;
-    const size_t claim_min_tiles = claim_min_env ? (size_t)atoll(claim_min_env) : 256;
-    const bool claim = !claim_off && unstable_first && !plan.from_val[0] && tiles >= claim_min_tiles && !(np == 1 && box_out);
+    const bool claim = radix_claim_applies(extent) && unstable_first && !plan.from_val[0] && !(np == 1 && box_out);
+    if (cells && (np != 2 || !claim || vals0 || !ready_hist || plan.from_val[1] || plan.shift[1] <= plan.shift[0])) return hipErrorInvalidValue;
 
     if (mark) mark(mark_ctx, class_hist);
     // status words: tagged per launch when the caller keeps an epoch counter for this workspace (epoch_io; the words of
@@ -3333,6 +3558,36 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         if (!plan.from_val[p]) first_key_pass = p;
     if (box_in && first_key_pass != 0) return hipErrorInvalidValue;                   // must be gathered before any permutation
     if (box_out && (first_key_pass < 0 || plan.from_val[np - 1])) return hipErrorInvalidValue;  // no key pass to split them off
+    if (cells) {
+        // the claiming pass by the HIGH digit, then the claiming pass that spreads every high bin over its cells
+        const bool holes = blockfill != nullptr;
+        ClaimArgs a{};
+        a.keys_in = kb[0]; a.keys_out = kb[1];
+        a.n = holes ? extent : n; a.n_out = n;
+        a.shift = plan.shift[1]; a.bin_base = bin_base + RS_BINS;
+        a.line_cur = cursors; a.frag_cur = cursors + SW_CURSOR_WORDS;
+        a.blockfill = blockfill;
+        a.n_tiles = (u32)rs_num_tiles(a.n);
+        a.dev_sizes = dev_sizes;
+        if (mark) mark(mark_ctx, class_sort);
+        e = launch_claim<NoVal>(a, stream);
+        if (mark) mark(mark_ctx, -1);
+        if (e != hipSuccess) return e;
+        ClaimArgs b{};
+        b.keys_in = kb[1]; b.keys_out = kb[0];
+        b.n = n; b.n_out = n;
+        b.shift = plan.shift[0]; b.hi_shift = plan.shift[1];
+        b.n_tiles = (u32)rs_num_tiles(n);
+        b.dev_sizes = dev_sizes;
+        b.cell_base = cells->cell_base; b.cell_line_cur = cells->line_cur; b.cell_frag_cur = cells->frag_cur; b.miss = cells->miss;
+        if (((size_t)kb[0] & 127u) != 0) return hipErrorInvalidValue;  // cell bases are whole lines of a line-aligned buffer
+        if (mark) mark(mark_ctx, class_sort);
+        e = launch_claim<NoVal, true>(b, stream);
+        if (mark) mark(mark_ctx, -1);
+        if (e != hipSuccess) return e;
+        *result_buf = 0;
+        return hipSuccess;
+    }
     for (int p = 0; p < np; ++p) {
         if (mark) mark(mark_ctx, class_sort);  // one timed region per pass = per kernel launch
         const u64* bb = bin_base + (size_t)p * RS_BINS;
@@ -3340,7 +3595,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         u32* tc = counters + (size_t)p * RS_TICKETS;
         if (claim && p == 0) {
             const bool holes = blockfill != nullptr;
-            ClaimArgs a;
+            ClaimArgs a{};
             a.keys_in = kb[cur]; a.keys_out = kb[cur ^ 1];
             a.vals_in = vals0 ? vb[cur] : nullptr; a.vals_out = vals0 ? vb[cur ^ 1] : nullptr;
             a.n = holes ? extent : n; a.n_out = n;
@@ -4132,10 +4387,11 @@ constexpr int GRP_THREADS = GRP_THREADS_MACRO, GRP_CAP = 4096, GRP_ITEMS = GRP_C
 constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
 constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;
 constexpr u32 GRP_SUB = 4;  // sub-bins per id by the top bits of the second id (fast path)  // larger groups than this are not attempted
+template <bool GAPPED>
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
                                                                    int gbits, int sshift, uint2* __restrict__ out, DevScalars* sc,
                                                                    const u32* __restrict__ stats, u32 abort_over,
-                                                                   const u32* __restrict__ dev_sizes) {
+                                                                   const u32* __restrict__ dev_sizes, CellRoute cells) {
     if (dev_sizes) abort_over = dev_sizes[SIZES_N] / 4u;
     // bins of the fast path: id within the group x GRP_SUB ranges of the second id (second >> sshift, clamped): shorter
     // bins, shorter rank loops (their cost is quadratic in the bin length)
@@ -4152,9 +4408,20 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
-    const u32 lo = bounds[g], hi = bounds[g + 1];
-    const u32 ng = hi - lo;
+    // where record x of the group is read: `in` dense (the group is in[lo .. hi)), or the gapped result of a cell sort (the
+    // cell's whole lines from its start, then what was claimed downwards from its end: ONE 16-byte word per group, written by
+    // launch_cell_count, instead of the two bounds -- a second, dependent load would add a memory latency to every workgroup)
+    u32 lo, ng, src_a, src_nf, src_b = 0;
+    if (GAPPED) {
+        const uint4 si = cells.src[g];
+        src_a = si.x; src_b = si.y; lo = si.z; ng = si.w >> 16; src_nf = si.w & 0xFFFFu;
+    } else {
+        lo = bounds[g];
+        ng = bounds[g + 1] - lo;
+        src_a = lo; src_nf = ng;
+    }
     if (ng == 0) return;  // workgroup-uniform
+    auto src = [&](u32 x) -> size_t { return !GAPPED || x < src_nf ? (size_t)src_a + x : (size_t)src_b + (x - src_nf); };
     const u32 bmask = (1u << gbits) - 1u;
     if (ng > (u32)GRP_CAP) {
         // A group that does not fit the LDS buffers (rare: the host only picks this kernel when the average group is
@@ -4167,7 +4434,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         if (tid < 256u) s_cnt[tid] = 0;
         __syncthreads();
         for (u32 x = tid; x < ng; x += GRP_THREADS)
-            __hip_atomic_fetch_add(&s_cnt[(u32)(in[(size_t)lo + x] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_cnt[(u32)(in[src(x)] >> 32) & bmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         const u32 mine_s = tid < 256u ? s_cnt[tid] : 0u;
         u32 total_s;
@@ -4186,7 +4453,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
             if (tid >= b0 && tid < b1) s_cur[tid] = s_off[tid] - base;
             __syncthreads();
             for (u32 x = tid; x < ng; x += GRP_THREADS) {
-                const u64 vv = in[(size_t)lo + x];
+                const u64 vv = in[src(x)];
                 const u32 b = (u32)(vv >> 32) & bmask;
                 if (b >= b0 && b < b1) {
                     const u32 pos = __hip_atomic_fetch_add(&s_cur[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -4195,7 +4462,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
             }
             __syncthreads();
             for (u32 x = tid; x < ng; x += GRP_THREADS) {
-                const u64 vv = in[(size_t)lo + x];
+                const u64 vv = in[src(x)];
                 const u32 b = (u32)(vv >> 32) & bmask, vb = (u32)vv;
                 if (b >= b0 && b < b1) {
                     const u32 start = s_off[b] - base, end = min(s_off[b + 1u] - base, (u32)GRP_CAP);
@@ -4220,7 +4487,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
         const u32 x = (u32)k * GRP_THREADS + tid;
-        v[k] = x < ng ? in[(size_t)lo + x] : 0ull;
+        v[k] = x < ng ? in[src(x)] : 0ull;
     }
     __syncthreads();
     // one returning LDS atomic per pair: the arrival ticket inside its bin is also its slot there (no second, cursor pass)
@@ -4291,19 +4558,25 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
 }
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
                                uint32_t* pairs_out, DevScalars* sc, hipStream_t stream, uint32_t* stats, uint32_t second_max,
-                               const uint32_t* dev_sizes) {
+                               const uint32_t* dev_sizes, const CellRoute* cells) {
     if (n == 0 || n_groups == 0) return hipSuccess;
     if (n >= 0xFFFFFFFFull || gbits < 1 || gbits > GRP_MAX_BITS) return hipErrorInvalidValue;
     // stats (two words of the freshly reset scalars): [0] = largest group, [1] = pairs in groups above the capacity; a
     // quarter of all pairs there: the finish bails out
-    hipError_t e = launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream, dev_sizes);
+    // (cells: the bounds and the statistics come from launch_cell_count -- the input is gapped, nothing to search)
+    hipError_t e = cells ? launch_cell_count(*cells, g0, n_groups, bounds, (u32)GRP_CAP, stats, dev_sizes, stream)
+                         : launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream, dev_sizes);
     if (e != hipSuccess) return e;
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
     int bits = 0;
     while (bits < 32 && (second_max >> bits) != 0) ++bits;
     const int sshift = bits > 2 ? bits - 2 : 0;
-    group_finish_kernel<<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
-                                                              (u32)(n / 4), dev_sizes);
+    if (cells)
+        group_finish_kernel<true><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
+                                                                        (u32)(n / 4), dev_sizes, *cells);
+    else
+        group_finish_kernel<false><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
+                                                                         (u32)(n / 4), dev_sizes, CellRoute{});
     return hipGetLastError();
 }
 int group_finish_capacity() { return GRP_CAP; }

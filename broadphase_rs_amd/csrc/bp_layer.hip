@@ -124,6 +124,9 @@ struct bp_layer {
         unsigned long long varying = 0;
         RadixPlan plan{};
     } ahead;
+    DevBuf cell_ws;                     // the cell route of the pair sort (CellRoute): cell_base[65537], line / fragment cursors[65536] each
+    uint32_t cell_off = 0;              // sorts ahead for which the cell route stays off (after a cell outgrew its range)
+    uint32_t cell_tag = 0;              // launch tag of the cell walks' status words (CellRoute::tag)
     bool ahead_try = false;             // scan_device -> scan_fused_device: this frame qualifies
     bool ahead_done = false;            // scan_fused_device -> scan_device: pairs are sorted and finished already
     bool grp_next = true;               // the last distinct-pair sort used the grouped finish (plan hint for the next scan; a new layer expects it: a wrong guess only makes that sort count its own digits)
@@ -1219,6 +1222,7 @@ int sort_dups_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long long
                                   holes ? (const uint32_t*)L->blockfill.p : nullptr, extent, take_ready_hist(L, gplan, holes), HIST_COPIES,
                                   /*unstable_first=*/1, ws_epoch, &sc_init));  // equal pairs are interchangeable; the finish orders by (first, second)
             BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)n_groups + 1) * sizeof(uint32_t)));
+            L->ahead.valid = false;  // (grp_bounds no longer holds the last distinct-pair sort's groups)
             BP_TRY(ensure_dev(L, L->block_sums, ((size_t)n_groups + 1) * sizeof(unsigned long long)));
             {
                 ProfScope ps(L, BP_K_DEDUP);
@@ -1490,6 +1494,35 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 uint64_t* bufs[2] = {(uint64_t*)L->pairs[0].p, nullptr};
                 BP_TRY(ensure_dev(L, L->pairs[1], n_bound * sizeof(uint64_t)));
                 bufs[1] = (uint64_t*)L->pairs[1].p;
+                BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)h.n_groups + 1) * sizeof(uint32_t)));
+                // The cell route (CellRoute, bp_kernels.h): two claiming passes -- high digit, then every high bin over its cells
+                // (= the finish's groups), laid out from the group sizes the LAST frame's finish left in grp_bounds -- instead of
+                // a claiming and a stable pass + the search for the group bounds.  A cell that outgrows its range is a miss.
+                static const bool no_cells = getenv("BP_NO_CELL_SORT") != nullptr;  // A/B switch for measurements
+                if (L->cell_off) --L->cell_off;
+                const bool cell_route = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
+                                        h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 &&
+                                        radix_claim_applies(extent_bound) && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
+                CellRoute cr{};
+                if (cell_route) {
+                    const bool fresh = L->cell_ws.p == nullptr;
+                    BP_TRY(ensure_dev(L, L->cell_ws, (7 * (size_t)CELL_COUNT + 16 + 128) * sizeof(uint32_t)));
+                    uint32_t* const cw = (uint32_t*)L->cell_ws.p;
+                    cr.status = (unsigned long long*)(cw + 7 * (size_t)CELL_COUNT + 16);
+                    if (fresh) { HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream)); L->cell_tag = 0; }
+                    L->cell_tag += 2;
+                    if (L->cell_tag >= (1u << 23)) {  // (24-bit tags: start over on clean words)
+                        HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream));
+                        L->cell_tag = 2;
+                    }
+                    cr.tag = L->cell_tag;
+                    cr.src = (uint4*)cw;  // (16-byte aligned: first)
+                    cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
+                    cr.miss = d_sizes + SIZES_CELL_MISS;
+                    ProfScope ps(L, BP_K_PAIR_HIST);
+                    HIP_TRY(L, launch_cell_layout((const uint32_t*)L->grp_bounds.p, h.first_lo >> 8, h.n_groups, (uint32_t*)cr.cell_base, cr.line_cur, cr.frag_cur, cr.miss,
+                                                  out_blocks * SX_BLOCK, cr.status, cr.tag, L->stream));
+                }
                 int res = 0;
                 {
                     uint32_t* ws_epoch = nullptr;
@@ -1498,15 +1531,14 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                     HIP_TRY(L, radix_sort(bufs[0], bufs[1], nullptr, nullptr, n_bound, h.plan, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p,
                                           &res, L->stream, prof_mark, L, BP_K_PAIR_HIST, BP_K_PAIR_SORT, nullptr, nullptr,
                                           (const uint32_t*)L->blockfill.p, extent_bound, (const unsigned long long*)L->pair_hist.p, HIST_COPIES,
-                                          /*unstable_first=*/1, ws_epoch, &sc_init, d_sizes, &fin));
+                                          /*unstable_first=*/1, ws_epoch, &sc_init, d_sizes, &fin, cell_route ? &cr : nullptr));
                 }
                 BP_TRY(ensure_dev(L, L->out_pairs, n_bound * 2 * sizeof(uint32_t)));
-                BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)h.n_groups + 1) * sizeof(uint32_t)));
                 {
                     ProfScope ps(L, BP_K_DEDUP);
                     HIP_TRY(L, launch_group_finish(bufs[res], n_bound, h.n_groups, h.first_lo >> 8, 8, (uint32_t*)L->grp_bounds.p, (uint32_t*)L->out_pairs.p,
                                                    (DevScalars*)L->d_sc.p, L->stream, group_stats_words((DevScalars*)L->d_sc.p),
-                                                   (uint32_t)(h.varying & 0xFFFFFFFFull), d_sizes));
+                                                   (uint32_t)(h.varying & 0xFFFFFFFFull), d_sizes, cell_route ? &cr : nullptr));
                 }
                 HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, SC_BLOCK_BYTES, hipMemcpyDeviceToHost, L->stream));
                 BP_TRY(sync_stream(L));
@@ -1519,9 +1551,15 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 const DevScalars sc = *(const DevScalars*)L->h_sc.p;
                 const uint32_t* sz = sc_sizes_host(L);
                 if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
-                if (sz[SIZES_MISS]) {  // the frame outgrew the margins (or overflowed the work list): everything behind the scan idled
+                if (sz[SIZES_MISS] || (cell_route && (sz[SIZES_CELL_MISS] || (sc.err & KERR_SEGMENT_TOO_LONG)))) {
+                    // the frame outgrew the margins (or overflowed the work list): everything behind the scan idled; or a cell
+                    // outgrew its range / a group the finish's window (the gapped cells cannot be handed to the full-width sort)
                     ++L->stats.sorts_ahead_missed;
                     L->ahead.valid = false;
+                    if (getenv("BP_DEBUG_AHEAD"))
+                        fprintf(stderr, "sort ahead missed: sizes extent %u n %u miss %u cell_miss %u err %x (bounds n %zu extent %zu, hint n %zu) cells %d grp_max %u\n",
+                                sz[SIZES_EXTENT], sz[SIZES_N], sz[SIZES_MISS], sz[SIZES_CELL_MISS], sc.err, n_bound, extent_bound, h.n_raw, (int)cell_route, sc.grp_max);
+                    if (!sz[SIZES_MISS]) L->cell_off = 16;  // the cells were the problem: the next sorts ahead go the two-kernel-kinds way
                     return rerun();
                 }
                 const uint64_t* sh = sc_shards_host(L);
@@ -1840,7 +1878,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
+    free_dev(L->pair_hist); free_dev(L->cell_ws); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);
     if (L->early_ev) (void)hipEventDestroy(L->early_ev);
@@ -1874,7 +1912,7 @@ int bp_layer_reset_plan_hints(bp_layer_t* L) {
     L->tgrp_ok = false; L->tgrp_known = false; L->tgrp_probe = 0;
     L->grp_next = true; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
     L->enc_hint.valid = false;
-    L->ahead.valid = false;
+    L->ahead.valid = false; L->cell_off = 0;
     return BP_OK;
 }
 int bp_layer_stream(const bp_layer_t* L, void** stream) {
