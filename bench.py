@@ -268,7 +268,7 @@ def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_la
            "host_syncs_per_step": (st1["host_syncs"] - st0["host_syncs"]) / frames,
            "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs",
                                                         "sorts_ahead_missed")},
-           "sorts_ahead": st1["sorts_ahead"] - st0["sorts_ahead"],
+           "sorts_ahead": st1["sorts_ahead"] - st0["sorts_ahead"], "sorts_in_cells": st1["sorts_in_cells"] - st0["sorts_in_cells"],
            "plan_events_note": "extend_reruns: extends launched on the previous frame's sizes that had to run again; *_plan_flips: sorts "
                                "whose grouped-finish plan differs from the previous frame's; sort_repairs: deferred tree-sort checks that "
                                "failed (full-width re-sort + second scan); sorts_ahead: frames whose pair sort was enqueued behind the scan on the "

@@ -1543,6 +1543,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, SC_BLOCK_BYTES, hipMemcpyDeviceToHost, L->stream));
                 BP_TRY(sync_stream(L));
                 ++L->stats.sorts_ahead;
+                if (cell_route) ++L->stats.sorts_in_cells;
                 {
                     bool redone = false;
                     BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));

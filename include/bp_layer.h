@@ -290,6 +290,8 @@ typedef struct bp_stats {
     uint32_t sorts_ahead;     /* scans whose pair sort + finish were enqueued behind them, sized by the previous frame
                                  (no host round trip between scan and sort)                                            */
     uint32_t sorts_ahead_missed; /* ... of which the frame outgrew those sizes: scan and sort ran again, blocking      */
+    uint32_t sorts_in_cells;  /* ... of which took the cell route: two line-claiming passes into ranges laid out from the
+                                 previous frame's group sizes (no stable pass, no search for the group bounds)            */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 

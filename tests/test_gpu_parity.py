@@ -737,6 +737,37 @@ def test_a_frame_that_outgrows_the_sizes_its_sort_was_enqueued_with_runs_again()
     assert grew, "the grown frame should have missed its predicted sizes: %r" % (st,)
 
 
+@pytest.mark.parametrize("id0,stride", [(0, 1), (777, 1), (1 << 20, 1), (16_000_000, 1)])
+def test_cell_route_of_the_pair_sort_on_small_moving_scenes(monkeypatch, id0, stride):
+    """the pair sort's cell route (two claiming passes into cells laid out from the previous frame's group sizes, gapped input
+    to the finish kernel) only starts at ~2 M pairs by default; BP_RADIX_CLAIM_MIN_TILES=1 sends small scenes through it, with id
+    ranges that start inside a group, far from zero, or end just below 2^24; every frame's list must be the oracle's,
+    whether the frame fits the cells (most) or outgrows them (the boxes are re-placed and resized a little every frame)"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    n = 200000  # (more than 2^16 ids: the pair sort needs its two digits)
+    if id0 + n * stride >= (1 << 24):
+        id0 = (1 << 24) - n * stride - 1
+    sysb, bounds, _ = scenes.gen_boxes(n, seed=81)
+    ids = (np.arange(n, dtype=np.uint64) * stride + id0).astype(np.uint32)
+    ctr = (bounds[:, :3] + bounds[:, 3:]) * np.float32(0.5)
+    half = (bounds[:, 3:] - bounds[:, :3]) * np.float32(0.5)
+    side = np.float32(sysb[1][0])
+    rng = np.random.default_rng(82)
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    for frame in range(8):
+        scale = np.float32(1.0 if frame in (4, 5) else 0.9 + 0.004 * frame)   # (frame 4 outgrows the cells laid out from frame 3: + 35 % pairs)
+        jit = ((rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * half).astype(np.float32)
+        c = ctr + jit
+        h = half * scale
+        cur = np.ascontiguousarray(np.concatenate([np.maximum(c - h, np.float32(0)), np.minimum(c + h, side)], axis=1).astype(np.float32))
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, cur, ids); ref.extend(sysb, cur, ids)
+        assert_pairs_equal(gpu.scan_device().to_numpy(), ref.par_scan(), "cell route, ids %d + %d k, frame %d" % (id0, stride, frame))
+    st = gpu.stats()
+    assert st["sorts_in_cells"] >= 4 and st["sorts_ahead_missed"] >= 1, {k: st[k] for k in ("sorts_ahead", "sorts_ahead_missed", "sorts_in_cells")}
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list

@@ -3,11 +3,16 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import broadphase_rs_amd as bp
 from broadphase_rs_amd import scenes
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-sysb, bounds, ids = scenes.gen_boxes(n, seed=61)
-db, di = torch.from_numpy(bounds).cuda(), torch.from_numpy(ids.view(np.int32)).cuda()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+scale0 = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+sysb, bounds, ids = scenes.gen_boxes(n, seed=81)
+ctr = (bounds[:, :3] + bounds[:, 3:]) * np.float32(0.5)
+half = (bounds[:, 3:] - bounds[:, :3]) * np.float32(0.5)
+side = np.float32(sysb[1][0])
 L = bp.Layer(bp.Index64_3D, 0)
-for f in range(5):
-    L.clear(); L.extend(sysb, db, di); out = L.scan_device()
+for f in range(6):
+    h = half * np.float32(scale0 + 0.05 * f)
+    cur = np.ascontiguousarray(np.concatenate([np.maximum(ctr - h, np.float32(0)), np.minimum(ctr + h, side)], axis=1).astype(np.float32))
+    L.clear(); L.extend(sysb, cur, ids); out = L.scan_device()
     st = L.stats()
-    print(f, len(out), st["sorts_ahead"], st["sorts_ahead_missed"], flush=True)
+    print(f, len(out), {k: st[k] for k in ("sorts_ahead", "sorts_ahead_missed", "sorts_in_cells", "pair_sort_passes", "pair_plan_flips", "entries")}, flush=True)
