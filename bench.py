@@ -149,13 +149,18 @@ def cpu_baseline(n_objects, seed):
 
 
 # one kernel per class on the default path (bp_kernel_class of include/bp_layer.h) -> (kernel name, SURVEY 8(d) bytes per launch)
-def kernel_table(n, M, P_raw, P):
+def kernel_table(n, M, P_raw, P, cells=False):
+    """cells: the timed frames' pair sorts took the cell route (bp_stats.sorts_in_cells: two claiming passes, no stable pass)"""
+    pair_sort = ("radix_claim_kernel<NoVal, false> + radix_claim_kernel<NoVal, true> (pair-sort passes: both claim whole aligned lines -- by the "
+                 "high digit, then every high bin into cells laid out from the previous frame's group sizes; no stable pass)") if cells else \
+                ("radix_claim_kernel<NoVal, false> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, "
+                 "the second is the stable one-sweep pass)")
     return {
         "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)", 28.0 * n + 12.0 * M),
-        "tree_sort": ("radix_claim_kernel<u32> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 24.0 * M),
+        "tree_sort": ("radix_claim_kernel<u32, false> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 24.0 * M),
         "tree_finish": ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
-        "pair_sort": ("radix_claim_kernel<NoVal> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 16.0 * P_raw),
+        "pair_sort": (pair_sort, 16.0 * P_raw),
         "dedup": ("group_finish_kernel (LDS finish of the pair sort + dedup)", 8.0 * P_raw + 8.0 * P),
     }
 
@@ -200,11 +205,13 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     st = layer.stats()
     table = kernel_table(n, st["entries"], st["raw_pairs"], st["pairs"])
     dom_cls = max(table, key=lambda c: wprof[c][0])
+    cells0 = layer.stats()["sorts_in_cells"]
     # timed region: events only around the dominant class (every event pair costs a few us of stream bubble)
     layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(True)
     syncs0 = layer.stats()["host_syncs"]
     res["ms_per_step"], out = timed(steps)
     res["host_syncs_per_step"] = (layer.stats()["host_syncs"] - syncs0) / steps
+    res["cell_route"] = (layer.stats()["sorts_in_cells"] - cells0) == steps   # every timed frame's pair sort took the cell route
     layer.profile_enable(False)
     res["dom_cls"], res["dom_prof"] = dom_cls, layer.profile()[dom_cls]
     if detail:
@@ -516,7 +523,7 @@ def single_gpu_line(args, r, np):
     n_pairs = r["n_pairs"]
     M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
     pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
-    table = kernel_table(n, M, P_raw, P)
+    table = kernel_table(n, M, P_raw, P, cells=bool(r.get("cell_route")))
     k = r["detail_steps"]
     launches = {c: v[1] / k for c, v in prof.items()}
     per_step_ms = {c: v[0] / k for c, v in prof.items()}
@@ -558,6 +565,7 @@ def single_gpu_line(args, r, np):
         "value": n_pairs / (ms_per_step * 1e-3), "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,  # the N = 1 point of either curve
         "dtype": "u64", "data": "synthetic",
+        "pair_sort_route": "cells (two claiming passes; every timed frame)" if r.get("cell_route") else "claiming pass + stable one-sweep pass",
         "config": {"workload": ("%s%dM Index64_3D uniform-random AABBs, single MI355X (gen_boxes recipe, density 0.001, "
                                 "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
                                 % ("configs[2]: " if n == 10_000_000 else "", n // 1_000_000)) if n % 1_000_000 == 0
@@ -604,8 +612,9 @@ def single_gpu_line(args, r, np):
         for nm in names:
             key = nm.split("<")[0]
             want_noval = "NoVal" in nm
+            exact = ", " in nm   # a full instantiation name (as rocprof prints it): radix_claim_kernel<NoVal, true>
             hit += [v for kk, v in tj.get("bytes_per_launch", {}).items()
-                    if kk.startswith(key) and (("NoVal" in kk) == want_noval or "radix" not in key)]
+                    if (kk.startswith(nm) if exact else (kk.startswith(key) and (("NoVal" in kk) == want_noval or "radix" not in key)))]
         if hit and tj.get("objects") == n:
             line["roofline"]["traffic"] = sum(hit) / len(hit)   # the two instantiations of a radix pass (first pass / later passes) average
             line["roofline"]["traffic_source"] = tj.get("source")
