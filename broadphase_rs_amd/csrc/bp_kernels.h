@@ -174,6 +174,8 @@ struct CellRoute {
     uint32_t* frag_cur;         // [CELL_COUNT] zero at launch
     uint32_t* miss;             // one word, zero at launch
     uint4* src;                 // [CELL_COUNT] scratch: launch_cell_count leaves every group's two input pieces here for the finish kernel
+    uint64_t* out_keys;         // sorts with a payload: where the gapped result goes (cell_layout_capacity(n) slots each, line-aligned);
+    uint32_t* out_vals;         //   key-only sorts leave it in keys0 (both null)
     unsigned long long* status; // [64] scratch of the two cell walks (zero once, when allocated)
     uint32_t tag;               // an even number the caller never repeats for this `status` (launch_cell_layout tags its walk with it, launch_cell_count with tag + 1)
 };
@@ -188,8 +190,11 @@ inline size_t cell_layout_capacity(size_t n) { return n + n / 4 + (size_t)CELL_C
 // after the sort: bounds[g] (g = 0 .. n_groups) = exact prefix of the sizes of cells g0 .. g0 + n_groups - 1, the group statistics
 // launch_group_finish wants in stats[0..1], and *miss |= 1 when a cell holds more than its range or the total differs from
 // dev_sizes[SIZES_N]
+// err_word / err_bit (optional): *err_word |= err_bit whenever *miss is or gets set (a caller that reads scalars, not the miss word);
+// want_total (optional, host-known record count): a different total is a miss too
 hipError_t launch_cell_count(const CellRoute& cells, uint32_t g0, uint32_t n_groups, uint32_t* bounds, uint32_t cap, uint32_t* stats,
-                             const uint32_t* dev_sizes, hipStream_t stream);
+                             const uint32_t* dev_sizes, hipStream_t stream, uint32_t* err_word = nullptr, uint32_t err_bit = 0,
+                             uint32_t want_total = 0);
 // unstable_first: the first pass may order records of equal digit arbitrarily (cheaper ranking).  Only for sorts whose
 // result does not depend on the input order of equal keys: a finishing kernel orders what the passes leave tied, or all
 // varying bits of distinct records are sorted.  NOT for the key-only stable tree sort that keeps equal keys in id order.
@@ -375,7 +380,11 @@ hipError_t launch_tgroup_bounds(const uint64_t* keys, size_t m, uint32_t n_group
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
                                 hipStream_t stream, int ctx_kind = -1, uint64_t* idctx_out = nullptr,
-                                const uint32_t* stats = nullptr, uint32_t abort_over = 0xFFFFFFFFu, int distinct_id_bits = 0);
+                                const uint32_t* stats = nullptr, uint32_t abort_over = 0xFFFFFFFFu, int distinct_id_bits = 0,
+                                const struct CellRoute* cells = nullptr);
+// cells: keys_in / ids_in are the gapped result of a cell sort (CellRoute::out_keys / out_vals) and the bounds came from
+// launch_cell_count; only where tgroup_composite_applies(gshift, distinct_id_bits) (the composite-key kernel reads gapped input)
+bool tgroup_composite_applies(int gshift, int distinct_id_bits);
 // distinct_id_bits > 0 (with payload_packed): the caller vouches that the ids are DISTINCT and below 2^distinct_id_bits; where
 // the rest of the key and the id fit one 64-bit word the composite-key kernel runs (a group above the capacity then sets
 // KERR_SEGMENT_TOO_LONG instead of taking the multi-round path)

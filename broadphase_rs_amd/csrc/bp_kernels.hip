@@ -1084,7 +1084,6 @@ __device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.
 template <typename V, bool CELLS = false>
 __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     typedef u64 K;
-    static_assert(!CELLS || StageBytes<V>::value == 0, "cell mode: key-only records");
     constexpr int T = RC_THREADS, ITEMS = RC_ITEMS, TILE = RC_TILE;
     constexpr bool HAS_VAL = StageBytes<V>::value != 0;
     static_assert((64 * ITEMS) % HOLE_BLOCK == 0 && TILE % HOLE_BLOCK == 0, "waves must not straddle blocks");
@@ -1199,8 +1198,12 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
                     const size_t c = (size_t)cur_hi * RS_BINS + b;
                     const u32 lim = a.cell_base[CELL_COUNT], ce = min(a.cell_base[c + 1], lim), cb = min(a.cell_base[c], ce);
                     const u32 q = s_glob[b] + i;
-                    if (q < ce - cb) keys_out[ce - 1u - q] = s_carry[b][i];
-                    else *a.miss = 1u;
+                    if (q < ce - cb) {
+                        keys_out[ce - 1u - q] = s_carry[b][i];
+                        if constexpr (HAS_VAL) vals_out[ce - 1u - q] = (V)s_carry_v[b][i];
+                    } else {
+                        *a.miss = 1u;
+                    }
                 } else {
                     const BinGeom g = bin_geom(a.bin_base, b, n_out, a0);
                     const u32 pos = frag_pos(g, s_glob[b] + i);
@@ -1252,24 +1255,28 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         const size_t base = (size_t)tile * TILE;
         u32* const cnt_cur = s_cnt[it & 1u];
 
-        // payload of THIS tile: in flight under the ranking
+        // payload of THIS tile: in flight under the ranking (CELLS: loaded when the keys have left -- the registers it would occupy
+        // through the ranking do not exist: 41 spilled at 128 per thread; before the next tile's prefetch: 73)
         V val[HAS_VAL ? ITEMS : 1];
-        if constexpr (HAS_VAL) {
-            const V* __restrict__ vsrc = vals_in + base + opaque(wbase);
+        auto load_vals = [&]() {
+            if constexpr (HAS_VAL) {
+                const V* __restrict__ vsrc = vals_in + base + opaque(wbase);
 #pragma unroll
-            for (int r = 0; r < ITEMS; ++r) {
-                if ((cur_vmask >> r) & 1u) val[r] = vsrc[r * 64];
-            }
-            if constexpr (sizeof(V) == 4) {
-                if (a.box_in) {  // pack the box codes into the payload
-                    const uint8_t* __restrict__ bsrc = a.box_in + base + opaque(wbase);
+                for (int r = 0; r < ITEMS; ++r) {
+                    if ((cur_vmask >> r) & 1u) val[r] = vsrc[r * 64];
+                }
+                if constexpr (sizeof(V) == 4) {
+                    if (a.box_in) {  // pack the box codes into the payload
+                        const uint8_t* __restrict__ bsrc = a.box_in + base + opaque(wbase);
 #pragma unroll
-                    for (int r = 0; r < ITEMS; ++r) {
-                        if ((cur_vmask >> r) & 1u) val[r] |= (V)box_to_packed(bsrc[r * 64]) << BOX_ID_BITS;
+                        for (int r = 0; r < ITEMS; ++r) {
+                            if ((cur_vmask >> r) & 1u) val[r] |= (V)box_to_packed(bsrc[r * 64]) << BOX_ID_BITS;
+                        }
                     }
                 }
             }
-        }
+        };
+        if constexpr (!CELLS) load_vals();
 
         // ---- rank: one counter per digit for the whole tile, one returning LDS atomic per record ----------------
         u32 rk[ITEMS / 2];  // two 16-bit fields each: the record's rank among the tile's records of its digit, later its stage slot
@@ -1380,6 +1387,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             over_q = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), cnt);
             for (u32 i = 0; i < cnt; ++i) keys_out[frag_pos(g, over_q + i)] = s_stage[over_at + i];
         }
+        if constexpr (CELLS) load_vals();
         // what stays: back into the carry slots
 #pragma unroll
         for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
@@ -2996,12 +3004,13 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish_kernel(const u64* 
 // A group beyond the capacity sets KERR_SEGMENT_TOO_LONG (the host sorts full-width and leaves this plan).
 constexpr int TG2_BIN_BITS = 10, TG2_BINS = 1 << TG2_BIN_BITS, TG2_BINS_PER_THREAD = TG2_BINS / TGRP_THREADS;
 static_assert(TGRP_THREADS == 256 && TG2_BINS_PER_THREAD == 4, "tgroup_finish2: four bins per thread in the prefix scan");
-template <int CTX_KIND>
+template <int CTX_KIND, bool GAPPED = false>
 __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ ids_in,
                                                                       const u32* __restrict__ bounds, int gshift, int id_bits,
                                                                       u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                       uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
-                                                                      DevScalars* sc, const u32* __restrict__ stats, u32 abort_over) {
+                                                                      DevScalars* sc, const u32* __restrict__ stats, u32 abort_over,
+                                                                      const uint4* __restrict__ cell_src = nullptr) {
     __shared__ u64 s_comp[TGRP_CAP];  // composites grouped by bin while ranking, then the keys in final order
     // counts / offsets of the bins while ranking; afterwards the same storage takes the payloads in final order
     union Aux { struct { u32 cnt[TG2_BINS]; u32 off[TG2_BINS + 4]; } b; u32 id[TGRP_CAP]; };
@@ -3016,9 +3025,19 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
-    const u32 lo = bounds[g], hi = bounds[g + 1];
-    const u32 ng = hi - lo;
+    // GAPPED: the entries are the result of a cell sort -- one 16-byte word per group says where its two pieces lie, where it
+    // goes in the dense output and how long it is (launch_cell_count; group_finish_kernel reads the same word)
+    u32 lo, ng, src_a, src_nf, src_b = 0;
+    if (GAPPED) {
+        const uint4 si = cell_src[g];
+        src_a = si.x; src_b = si.y; lo = si.z; ng = si.w >> 16; src_nf = si.w & 0xFFFFu;
+    } else {
+        lo = bounds[g];
+        ng = bounds[g + 1] - lo;
+        src_a = lo; src_nf = ng;
+    }
     if (ng == 0) return;  // workgroup-uniform
+    auto src = [&](u32 x) -> size_t { return !GAPPED || x < src_nf ? (size_t)src_a + x : (size_t)src_b + (x - src_nf); };
     if (ng > (u32)TGRP_CAP) {
         if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
@@ -3032,8 +3051,8 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
 #pragma unroll
     for (int i = 0; i < TGRP_ITEMS; ++i) {
         const u32 x = (u32)i * TGRP_THREADS + tid;
-        k[i] = x < ng ? keys_in[(size_t)lo + x] : 0ull;
-        p[i] = x < ng ? ids_in[(size_t)lo + x] : 0u;
+        k[i] = x < ng ? keys_in[src(x)] : 0ull;
+        p[i] = x < ng ? ids_in[src(x)] : 0u;
     }
     __syncthreads();
     u32 slot[TGRP_ITEMS];  // arrival ticket inside the bin, then the scatter slot, then the final position
@@ -3397,7 +3416,8 @@ hipError_t launch_cell_layout(const uint32_t* prev_bounds, uint32_t prev_g0, uin
     return hipGetLastError();
 }
 __global__ __launch_bounds__(CELL_THREADS) void cell_count_kernel(CellRoute cr, u32 g0, u32 n_groups, u32* __restrict__ bounds, u32 cap,
-                                                                  u32* __restrict__ stats, const u32* __restrict__ dev_sizes, u64* status, u32 tag) {
+                                                                  u32* __restrict__ stats, const u32* __restrict__ dev_sizes, u64* status, u32 tag,
+                                                                  u32* err_word, u32 err_bit, u32 want_total) {
     __shared__ u32 s_mx[CELL_THREADS / 64], s_ov[CELL_THREADS / 64], s_bad[CELL_THREADS / 64];
     const u32* __restrict__ const lc = cr.line_cur;
     const u32* __restrict__ const fc = cr.frag_cur;
@@ -3438,15 +3458,18 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_count_kernel(CellRoute cr, 
         }
         if (blockIdx.x == CELL_WGS - 1) {
             if (g0 + n_groups == CELL_COUNT) bounds[n_groups] = (u32)total;
-            if (total >= 0xFFFFFFFFull || (dev_sizes && (u32)total != dev_sizes[SIZES_N])) bad = 1u;
+            if (total >= 0xFFFFFFFFull || (dev_sizes && (u32)total != dev_sizes[SIZES_N]) || (want_total && (u32)total != want_total)) bad = 1u;
         }
         if (bad) *cr.miss = 1u;
+        // (a caller that reads an error word instead of the miss word: set there too, also for what the layout and the sort flagged)
+        if (err_word && (bad || (blockIdx.x == 0 && *cr.miss))) atomicOr(err_word, err_bit);
     }
 }
 hipError_t launch_cell_count(const CellRoute& cells, uint32_t g0, uint32_t n_groups, uint32_t* bounds, uint32_t cap, uint32_t* stats,
-                             const uint32_t* dev_sizes, hipStream_t stream) {
+                             const uint32_t* dev_sizes, hipStream_t stream, uint32_t* err_word, uint32_t err_bit, uint32_t want_total) {
     if ((size_t)g0 + n_groups > CELL_COUNT) return hipErrorInvalidValue;
-    cell_count_kernel<<<CELL_WGS, CELL_THREADS, 0, stream>>>(cells, g0, n_groups, bounds, cap, stats, dev_sizes, (u64*)cells.status, cells.tag + 1u);
+    cell_count_kernel<<<CELL_WGS, CELL_THREADS, 0, stream>>>(cells, g0, n_groups, bounds, cap, stats, dev_sizes, (u64*)cells.status, cells.tag + 1u,
+                                                             err_word, err_bit, want_total);
     return hipGetLastError();
 }
 
@@ -3513,7 +3536,9 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     // input is large enough for its persistent workgroups to amortise their final partial lines; BP_RADIX_CLAIM=0: off
     // (the two switches are read per sort, so that the tests can force the kernel onto small inputs)
     const bool claim = radix_claim_applies(extent) && unstable_first && !plan.from_val[0] && !(np == 1 && box_out);
-    if (cells && (np != 2 || !claim || vals0 || !ready_hist || plan.from_val[1] || plan.shift[1] <= plan.shift[0])) return hipErrorInvalidValue;
+    if (cells && (np != 2 || !claim || !ready_hist || plan.from_val[1] || plan.shift[1] != plan.shift[0] + 8 || (vals0 && !cells->out_vals) ||
+                  box_out || (dev_sizes && vals0)))
+        return hipErrorInvalidValue;
 
     if (mark) mark(mark_ctx, class_hist);
     // status words: tagged per launch when the caller keeps an epoch counter for this workspace (epoch_io; the words of
@@ -3563,29 +3588,33 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         const bool holes = blockfill != nullptr;
         ClaimArgs a{};
         a.keys_in = kb[0]; a.keys_out = kb[1];
+        a.vals_in = vals0 ? vb[0] : nullptr; a.vals_out = vals0 ? vb[1] : nullptr;
         a.n = holes ? extent : n; a.n_out = n;
         a.shift = plan.shift[1]; a.bin_base = bin_base + RS_BINS;
         a.line_cur = cursors; a.frag_cur = cursors + SW_CURSOR_WORDS;
-        a.blockfill = blockfill;
+        a.blockfill = blockfill; a.box_in = box_in;
         a.n_tiles = (u32)rs_num_tiles(a.n);
         a.dev_sizes = dev_sizes;
         if (mark) mark(mark_ctx, class_sort);
-        e = launch_claim<NoVal>(a, stream);
+        e = vals0 ? launch_claim<u32>(a, stream) : launch_claim<NoVal>(a, stream);
         if (mark) mark(mark_ctx, -1);
         if (e != hipSuccess) return e;
+        // the gapped result: in keys0 (key-only sorts) or in the buffers the caller set aside for it
+        u64* const gk = cells->out_keys ? (u64*)cells->out_keys : kb[0];
         ClaimArgs b{};
-        b.keys_in = kb[1]; b.keys_out = kb[0];
+        b.keys_in = kb[1]; b.keys_out = gk;
+        b.vals_in = vals0 ? vb[1] : nullptr; b.vals_out = vals0 ? cells->out_vals : nullptr;
         b.n = n; b.n_out = n;
         b.shift = plan.shift[0]; b.hi_shift = plan.shift[1];
         b.n_tiles = (u32)rs_num_tiles(n);
         b.dev_sizes = dev_sizes;
         b.cell_base = cells->cell_base; b.cell_line_cur = cells->line_cur; b.cell_frag_cur = cells->frag_cur; b.miss = cells->miss;
-        if (((size_t)kb[0] & 127u) != 0) return hipErrorInvalidValue;  // cell bases are whole lines of a line-aligned buffer
+        if (((size_t)gk & 127u) != 0) return hipErrorInvalidValue;  // cell bases are whole lines of a line-aligned buffer
         if (mark) mark(mark_ctx, class_sort);
-        e = launch_claim<NoVal, true>(b, stream);
+        e = vals0 ? launch_claim<u32, true>(b, stream) : launch_claim<NoVal, true>(b, stream);
         if (mark) mark(mark_ctx, -1);
         if (e != hipSuccess) return e;
-        *result_buf = 0;
+        *result_buf = 0;  // (key-only: keys0; with a payload: cells->out_keys / out_vals)
         return hipSuccess;
     }
     for (int p = 0; p < np; ++p) {
@@ -4807,9 +4836,21 @@ bool tgroup_composite_fits(int gshift, int id_bits) {
 hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in, uint32_t n_groups, const uint32_t* bounds, int gshift,
                                 int payload_packed, uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, DevScalars* sc,
                                 hipStream_t stream, int ctx_kind, uint64_t* idctx_out, const uint32_t* stats, uint32_t abort_over,
-                                int distinct_id_bits) {
+                                int distinct_id_bits, const CellRoute* cells) {
     if (n_groups == 0) return hipSuccess;
     if (gshift < TGRP_BIN_BITS) return hipErrorInvalidValue;
+    if (cells) {  // gapped input (the result of a cell sort): the composite-key kernel only -- the caller checked tgroup_composite_applies
+        if (!(payload_packed && box_out && distinct_id_bits > 0 && tgroup_composite_fits(gshift, distinct_id_bits))) return hipErrorInvalidValue;
+#define BP_TG2G_LAUNCH(K)                                                                                                                \
+    tgroup_finish2_kernel<K, true><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, distinct_id_bits,  \
+                                                                          (u64*)keys_out, ids_out, box_out, (u64*)idctx_out, sc, stats, abort_over, cells->src)
+        if (!idctx_out || ctx_kind < 0) BP_TG2G_LAUNCH(-1);
+        else if (ctx_kind == 0) BP_TG2G_LAUNCH(0);
+        else if (ctx_kind == 1) BP_TG2G_LAUNCH(1);
+        else BP_TG2G_LAUNCH(2);
+#undef BP_TG2G_LAUNCH
+        return hipGetLastError();
+    }
     if (payload_packed && box_out && distinct_id_bits > 0 && tgroup_composite_fits(gshift, distinct_id_bits)) {
 #define BP_TG2_LAUNCH(K)                                                                                                          \
     tgroup_finish2_kernel<K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)keys_in, ids_in, bounds, gshift, distinct_id_bits,  \
@@ -4832,6 +4873,7 @@ hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in,
 #undef BP_TGRP_LAUNCH
     return hipGetLastError();
 }
+bool tgroup_composite_applies(int gshift, int distinct_id_bits) { return distinct_id_bits > 0 && tgroup_composite_fits(gshift, distinct_id_bits); }
 int tgroup_capacity() { return TGRP_CAP; }
 int tgroup_bin_bits() { return TGRP_BIN_BITS; }
 

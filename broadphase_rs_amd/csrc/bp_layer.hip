@@ -143,7 +143,12 @@ struct bp_layer {
     struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; } enc_hint;
     // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
     // NEXT host round trip (the scan's) instead of one of their own
-    struct { bool on = false; int src = 0; bool ride = false; } sort_pend;
+    struct { bool on = false; int src = 0; bool ride = false; bool cells = false; } sort_pend;
+    // cell route of the grouped tree sort (CellRoute with a payload): laid out from the group bounds the previous sort of the same
+    // plan left in tgrp_bounds; its gapped result goes to tcell_keys / tcell_ids, the finish kernel writes the dense tree
+    struct { bool valid = false; unsigned long long g0 = 0; uint32_t n_groups = 0; int gshift = 0; size_t m = 0; } tcell;
+    DevBuf tcell_keys, tcell_ids, tcell_ws;
+    uint32_t tcell_off = 0, tcell_tag = 0;
     // a partition pass that was only enqueued (BP_PARTITION_ENQUEUE_ONLY): its error word, copied behind the pass into
     // h_part_err, is looked at by the layer's next host round trip (sync_stream)
     bool part_pend = false;
@@ -837,7 +842,10 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     if ((sc.err & KERR_SEGMENT_TOO_LONG) || L->tgrp_ok != tgrp_before) ++L->stats.tree_plan_flips;
     if (sc.err & KERR_SEGMENT_TOO_LONG) {
         ++L->stats.sort_repairs;
-        L->tgrp_ok = false;
+        // (a cell-route attempt that failed with groups that fit: only the cells were laid out too small -- the grouped plan stays)
+        if (!(L->sort_pend.cells && sc.grp_max <= (uint32_t)tgroup_capacity())) L->tgrp_ok = false;
+        if (L->sort_pend.cells) L->tcell_off = 16;
+        L->tcell.valid = false;
         L->cur = L->sort_pend.src;
         L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
         ++L->epoch;
@@ -896,12 +904,50 @@ int sort_tree(bp_layer* L, bool defer_check) {
             uint32_t* vb[2] = {(uint32_t*)L->ids[L->cur].p, (uint32_t*)L->ids[other].p};
             const bool hist_ready = L->tree_hist_valid && L->tree_hist_m == L->m && same_plan(gp.plan, L->tree_hist_plan);
             L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
+            // The cell route (CellRoute, bp_kernels.h): claiming pass by the high digit, claiming pass into cells
+            // (= the finish's groups) laid out from the bounds the previous sort left in tgrp_bounds, finish from the gapped
+            // buffers -- no stable pass, no search for the bounds.  A cell that outgrows its range sets KERR_SEGMENT_TOO_LONG in
+            // the sort's scalars: the deferred check repairs the tree from the first pass's (dense) output like any other failure.
+            static const bool no_tcells = getenv("BP_NO_TREE_CELL_SORT") != nullptr;  // A/B switch
+            const int distinct_bits = (ride && L->ids_distinct) ? std::max(1, 32 - __builtin_clz(L->id_or | 1u)) : 0;
+            const uint32_t cell0 = (uint32_t)(gp.g0 & 0xFFFFu);
+            if (L->tcell_off) --L->tcell_off;
+            const bool tcell = !no_tcells && !L->tcell_off && L->tcell.valid && L->tcell.g0 == gp.g0 && L->tcell.n_groups == gp.n_groups &&
+                               L->tcell.gshift == gp.gshift && gp.plan.n_passes == 2 && hist_ready && ride &&
+                               tgroup_composite_applies(gp.gshift, distinct_bits) && (size_t)cell0 + gp.n_groups <= CELL_COUNT &&
+                               radix_claim_applies(L->m) && L->m <= L->tcell.m + L->tcell.m / 16 && L->m + L->m / 16 >= L->tcell.m;
+            CellRoute cr{};
+            if (tcell) {
+                const size_t slots = cell_layout_capacity(L->m);
+                BP_TRY(ensure_dev(L, L->tcell_keys, slots * sizeof(uint64_t)));
+                BP_TRY(ensure_dev(L, L->tcell_ids, slots * sizeof(uint32_t)));
+                const bool fresh = L->tcell_ws.p == nullptr;
+                BP_TRY(ensure_dev(L, L->tcell_ws, (7 * (size_t)CELL_COUNT + 16 + 128 + 16) * sizeof(uint32_t)));
+                uint32_t* const cw = (uint32_t*)L->tcell_ws.p;
+                cr.src = (uint4*)cw;
+                cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
+                cr.status = (unsigned long long*)(cw + 7 * (size_t)CELL_COUNT + 16);
+                cr.miss = cw + 7 * (size_t)CELL_COUNT + 16 + 128;
+                cr.out_keys = (uint64_t*)L->tcell_keys.p; cr.out_vals = (uint32_t*)L->tcell_ids.p;
+                if (fresh) { HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream)); L->tcell_tag = 0; }
+                L->tcell_tag += 2;
+                if (L->tcell_tag >= (1u << 23)) {
+                    HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream));
+                    L->tcell_tag = 2;
+                }
+                cr.tag = L->tcell_tag;
+                HIP_TRY(L, launch_cell_layout((const uint32_t*)L->tgrp_bounds.p, cell0, gp.n_groups, (uint32_t*)cr.cell_base, cr.line_cur, cr.frag_cur,
+                                              cr.miss, slots, cr.status, cr.tag, L->stream));
+            }
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, d_ssc,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
                                   hist_ready ? (const unsigned long long*)L->tree_hist.p : nullptr, HIST_COPIES,
-                                  /*unstable_first=*/1, ws_epoch, &ssc_init));  // the finish kernel orders every group by (key, id, position)
-            const int src = res ? other : L->cur, dst = src ^ 1;
+                                  /*unstable_first=*/1, ws_epoch, &ssc_init, nullptr, nullptr,
+                                  tcell ? &cr : nullptr));  // the finish kernel orders every group by (key, id, position)
+            // cell route: the gapped result sits in tcell_keys / tcell_ids, the first pass's dense output in `other` (what a repair
+            // starts from), and the finish writes the tree back into the current buffers
+            const int src = tcell ? other : (res ? other : L->cur), dst = src ^ 1;
             if (ride) BP_TRY(ensure_dev(L, L->box[dst], L->m, dst == L->cur ? L->m : 0));
             // the finish has key and box code at hand: it also writes the scan's per-entry context words
             static const bool no_ctx_fuse = getenv("BP_NO_CTX_FUSE") != nullptr;  // A/B switch
@@ -909,24 +955,32 @@ int sort_tree(bp_layer* L, bool defer_check) {
             if (with_ctx) BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             {
                 ProfScope ps(L, BP_K_TREE_FINISH);
-                HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
-                                                (uint32_t*)L->tgrp_bounds.p, group_stats_words(d_ssc), L->stream));
-                HIP_TRY(L, launch_tgroup_finish((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p, gp.n_groups,
+                if (tcell)
+                    HIP_TRY(L, launch_cell_count(cr, cell0, gp.n_groups, (uint32_t*)L->tgrp_bounds.p, (uint32_t)tgroup_capacity(), group_stats_words(d_ssc),
+                                                 nullptr, L->stream, &d_ssc->err, (uint32_t)KERR_SEGMENT_TOO_LONG, (uint32_t)L->m));
+                else
+                    HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[src].p, L->m, gp.n_groups, gp.g0, gp.gshift,
+                                                    (uint32_t*)L->tgrp_bounds.p, group_stats_words(d_ssc), L->stream));
+                HIP_TRY(L, launch_tgroup_finish(tcell ? (const uint64_t*)L->tcell_keys.p : (const uint64_t*)L->keys[src].p,
+                                                tcell ? (const uint32_t*)L->tcell_ids.p : (const uint32_t*)L->ids[src].p, gp.n_groups,
                                                 (const uint32_t*)L->tgrp_bounds.p, gp.gshift, ride ? 1 : 0, (uint64_t*)L->keys[dst].p,
                                                 (uint32_t*)L->ids[dst].p, ride ? (uint8_t*)L->box[dst].p : nullptr,
                                                 d_ssc, L->stream, with_ctx ? L->kind : -1,
                                                 with_ctx ? (uint64_t*)L->idctx.p : nullptr, group_stats_words(d_ssc),
                                                 (uint32_t)(L->m / 4),
                                                 // ids distinct (the codes ride in them): the composite-key kernel may run
-                                                (ride && L->ids_distinct) ? std::max(1, 32 - __builtin_clz(L->id_or | 1u)) : 0));
+                                                distinct_bits, tcell ? &cr : nullptr));
+                if (tcell) ++L->stats.tree_sorts_in_cells;
             }
+            // (optimistic, like the rest of the state below: tgrp_bounds will hold this sort's group bounds)
+            L->tcell.valid = true; L->tcell.g0 = gp.g0; L->tcell.n_groups = gp.n_groups; L->tcell.gshift = gp.gshift; L->tcell.m = L->m;
             HIP_TRY(L, hipMemcpyAsync(L->h_sort_sc.p, L->d_sort_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
             L->cur = dst;
             L->box_valid = ride;
             if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0; }
             L->ids_packed = false;
-            L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride;
+            L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride; L->sort_pend.cells = tcell;
             static const bool no_defer = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
             if (defer_check && !no_defer) {  // no host round trip here: the check rides on the caller's next one
                 L->sorted = true;
@@ -975,6 +1029,10 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 ProfScope ps(L, BP_K_TREE_FINISH);
                 HIP_TRY(L, launch_tgroup_bounds((const uint64_t*)L->keys[dst].p, L->m, gp.n_groups, gp.g0, gp.gshift,
                                                 (uint32_t*)L->tgrp_bounds.p, group_stats_words((DevScalars*)L->d_sc.p), L->stream));
+                // (exact group bounds of this tree under the grouped plan: what the cell route of the next sort lays its cells out by)
+                L->tcell.valid = true; L->tcell.g0 = gp.g0; L->tcell.n_groups = gp.n_groups; L->tcell.gshift = gp.gshift; L->tcell.m = L->m;
+            } else {
+                L->tcell.valid = false;
             }
             HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             BP_TRY(sync_stream(L));
@@ -1880,7 +1938,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
     free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
-    free_dev(L->pair_hist); free_dev(L->cell_ws); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
+    free_dev(L->pair_hist); free_dev(L->cell_ws); free_dev(L->tcell_keys); free_dev(L->tcell_ids); free_dev(L->tcell_ws); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);
     if (L->early_ev) (void)hipEventDestroy(L->early_ev);
@@ -1915,6 +1973,7 @@ int bp_layer_reset_plan_hints(bp_layer_t* L) {
     L->grp_next = true; L->grp_off = 0; L->grp_off_dups = 0; L->grp_next_dups = 0;
     L->enc_hint.valid = false;
     L->ahead.valid = false; L->cell_off = 0;
+    L->tcell.valid = false; L->tcell_off = 0;
     return BP_OK;
 }
 int bp_layer_stream(const bp_layer_t* L, void** stream) {

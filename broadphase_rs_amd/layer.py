@@ -60,7 +60,8 @@ class _Stats(C.Structure):
                 ("pair_sort_passes", C.c_uint32), ("depth_mask", C.c_uint32), ("flags", C.c_uint32),
                 ("host_syncs", C.c_uint64), ("extend_reruns", C.c_uint32), ("tree_plan_flips", C.c_uint32),
                 ("pair_plan_flips", C.c_uint32), ("sort_repairs", C.c_uint32), ("sorts_ahead", C.c_uint32),
-                ("sorts_ahead_missed", C.c_uint32), ("sorts_in_cells", C.c_uint32)]
+                ("sorts_ahead_missed", C.c_uint32), ("sorts_in_cells", C.c_uint32),
+                ("tree_sorts_in_cells", C.c_uint32)]
 
 
 FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)

@@ -292,6 +292,8 @@ typedef struct bp_stats {
     uint32_t sorts_ahead_missed; /* ... of which the frame outgrew those sizes: scan and sort ran again, blocking      */
     uint32_t sorts_in_cells;  /* ... of which took the cell route: two line-claiming passes into ranges laid out from the
                                  previous frame's group sizes (no stable pass, no search for the group bounds)            */
+    uint32_t tree_sorts_in_cells; /* grouped tree sorts that took the cell route (the same idea for the (index, id) sort: a
+                                     cell that outgrows its range is a sort_repair)                                        */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 

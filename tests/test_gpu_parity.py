@@ -768,6 +768,35 @@ def test_cell_route_of_the_pair_sort_on_small_moving_scenes(monkeypatch, id0, st
     assert st["sorts_in_cells"] >= 4 and st["sorts_ahead_missed"] >= 1, {k: st[k] for k in ("sorts_ahead", "sorts_ahead_missed", "sorts_in_cells")}
 
 
+def test_cell_route_of_the_tree_sort_is_repaired_when_the_scene_bunches_up(monkeypatch):
+    """the grouped tree sort's cell route lays its cells out from the PREVIOUS sort's group sizes; when a third of the objects
+    moves into one corner between two frames, cells there overflow: the deferred sort check must notice (KERR_SEGMENT_TOO_LONG
+    in the sort's scalars), repair the tree from the first pass's dense output and run the scan again -- tree and pairs equal
+    the oracle's in every frame, bunched or not"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    n = 300000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=91)
+    size = bounds[:, 3:] - bounds[:, :3]
+    side = np.float32(sysb[1][0])
+    rng = np.random.default_rng(92)
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    for frame in range(6):
+        mn = bounds[:, :3].copy()
+        if frame in (2, 3):   # a third of the objects into the lower corner (an eighth of the volume): groups there grow ~ 3.5 x
+            pick = rng.random(n) < 0.33
+            mn[pick] *= np.float32(0.5)
+        mn = np.minimum(np.maximum(mn + (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)), np.float32(0)), side - size).astype(np.float32)
+        cur = np.ascontiguousarray(np.concatenate([mn, mn + size], axis=1).astype(np.float32))
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, cur, ids); ref.extend(sysb, cur, ids)
+        gpu.par_sort(); ref.par_sort()
+        assert_tree_equal(gpu, ref, "bunching scene, frame %d, par_sort" % frame)
+        assert_pairs_equal(gpu.scan_device().to_numpy(), ref.par_scan(), "bunching scene, frame %d, par_scan" % frame)
+    st = gpu.stats()
+    assert st["tree_sorts_in_cells"] >= 2 and st["sort_repairs"] >= 1, {k: st[k] for k in ("tree_sorts_in_cells", "sort_repairs", "tree_plan_flips")}
+
+
 def test_large_ids_cannot_carry_box_codes_and_still_match():
     # ids >= 2^27: the 5 spare payload bits are not spare, so duplicates cannot be suppressed at the
     # source after the sort; the full pair sort + dedup must produce the identical list
