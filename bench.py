@@ -149,15 +149,20 @@ def cpu_baseline(n_objects, seed):
 
 
 # one kernel per class on the default path (bp_kernel_class of include/bp_layer.h) -> (kernel name, SURVEY 8(d) bytes per launch)
-def kernel_table(n, M, P_raw, P, cells=False):
-    """cells: the timed frames' pair sorts took the cell route (bp_stats.sorts_in_cells: two claiming passes, no stable pass)"""
+def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False):
+    """cells / tree_cells: the timed frames' pair / tree sorts took the cell route (bp_stats.sorts_in_cells, tree_sorts_in_cells:
+    two claiming passes, no stable pass)"""
+    tree_sort = ("radix_claim_kernel<u32, false> + radix_claim_kernel<u32, true> (tree-sort passes: both claim whole aligned lines -- by the "
+                 "high digit, then every high bin into cells laid out from the previous sort's group sizes; no stable pass)") if tree_cells else \
+                ("radix_claim_kernel<u32, false> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, "
+                 "the second is the stable one-sweep pass)")
     pair_sort = ("radix_claim_kernel<NoVal, false> + radix_claim_kernel<NoVal, true> (pair-sort passes: both claim whole aligned lines -- by the "
                  "high digit, then every high bin into cells laid out from the previous frame's group sizes; no stable pass)") if cells else \
                 ("radix_claim_kernel<NoVal, false> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, "
                  "the second is the stable one-sweep pass)")
     return {
         "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)", 28.0 * n + 12.0 * M),
-        "tree_sort": ("radix_claim_kernel<u32, false> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, the second is the stable one-sweep pass)", 24.0 * M),
+        "tree_sort": (tree_sort, 24.0 * M),
         "tree_finish": ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
         "pair_sort": (pair_sort, 16.0 * P_raw),
@@ -205,13 +210,14 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     st = layer.stats()
     table = kernel_table(n, st["entries"], st["raw_pairs"], st["pairs"])
     dom_cls = max(table, key=lambda c: wprof[c][0])
-    cells0 = layer.stats()["sorts_in_cells"]
+    cells0, tcells0 = layer.stats()["sorts_in_cells"], layer.stats()["tree_sorts_in_cells"]
     # timed region: events only around the dominant class (every event pair costs a few us of stream bubble)
     layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(True)
     syncs0 = layer.stats()["host_syncs"]
     res["ms_per_step"], out = timed(steps)
     res["host_syncs_per_step"] = (layer.stats()["host_syncs"] - syncs0) / steps
     res["cell_route"] = (layer.stats()["sorts_in_cells"] - cells0) == steps   # every timed frame's pair sort took the cell route
+    res["tree_cell_route"] = (layer.stats()["tree_sorts_in_cells"] - tcells0) == steps
     layer.profile_enable(False)
     res["dom_cls"], res["dom_prof"] = dom_cls, layer.profile()[dom_cls]
     if detail:
@@ -276,6 +282,7 @@ def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_la
            "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs",
                                                         "sorts_ahead_missed")},
            "sorts_ahead": st1["sorts_ahead"] - st0["sorts_ahead"], "sorts_in_cells": st1["sorts_in_cells"] - st0["sorts_in_cells"],
+           "tree_sorts_in_cells": st1["tree_sorts_in_cells"] - st0["tree_sorts_in_cells"],
            "plan_events_note": "extend_reruns: extends launched on the previous frame's sizes that had to run again; *_plan_flips: sorts "
                                "whose grouped-finish plan differs from the previous frame's; sort_repairs: deferred tree-sort checks that "
                                "failed (full-width re-sort + second scan); sorts_ahead: frames whose pair sort was enqueued behind the scan on the "
@@ -523,7 +530,7 @@ def single_gpu_line(args, r, np):
     n_pairs = r["n_pairs"]
     M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
     pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
-    table = kernel_table(n, M, P_raw, P, cells=bool(r.get("cell_route")))
+    table = kernel_table(n, M, P_raw, P, cells=bool(r.get("cell_route")), tree_cells=bool(r.get("tree_cell_route")))
     k = r["detail_steps"]
     launches = {c: v[1] / k for c, v in prof.items()}
     per_step_ms = {c: v[0] / k for c, v in prof.items()}
@@ -566,6 +573,7 @@ def single_gpu_line(args, r, np):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,  # the N = 1 point of either curve
         "dtype": "u64", "data": "synthetic",
         "pair_sort_route": "cells (two claiming passes; every timed frame)" if r.get("cell_route") else "claiming pass + stable one-sweep pass",
+        "tree_sort_route": "cells (two claiming passes; every timed frame)" if r.get("tree_cell_route") else "claiming pass + stable one-sweep pass",
         "config": {"workload": ("%s%dM Index64_3D uniform-random AABBs, single MI355X (gen_boxes recipe, density 0.001, "
                                 "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
                                 % ("configs[2]: " if n == 10_000_000 else "", n // 1_000_000)) if n % 1_000_000 == 0
