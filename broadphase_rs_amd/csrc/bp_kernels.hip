@@ -1023,6 +1023,15 @@ __global__ __launch_bounds__(THREADS, RS_MIN_WAVES_PER_EU) void radix_onesweep_k
 //   * the next tile's keys are loaded into the (then dead) key registers as soon as the current tile sits in LDS, the
 //     payload at the top of its tile.
 // The order this pass leaves inside a bin depends on timing; the sort's result does not (the finish orders every tie).
+//
+// CELLS (template flag): the SECOND pass of a sort whose first, claiming pass went by the HIGH digit.  No order to preserve
+// here either, if every high bin can be spread over its 256 cells (high digit, low digit = the finishing kernel's groups)
+// without knowing their sizes -- they are laid out beforehand, with room to spare, from the sizes the PREVIOUS sort of the
+// same kind left behind (launch_cell_layout; CellRoute in bp_kernels.h).  Differences to the plain pass: a workgroup takes a
+// contiguous range of tiles and makes one sub-pass per high bin a tile touches (the input is sorted by the high digit: all
+// but ~1 % of the tiles lie inside one bin); a cell's whole lines are claimed upwards from its start, the workgroup's carry
+// leaves record by record downwards from the cell's end whenever the workgroup moves on to another high bin; what does not
+// fit a cell is dropped and flagged (the caller sorts again the plain way); every range is clipped to the layout's total.
 // =================================================================================================
 #ifndef RS_CUR_STRIDE
 #define RS_CUR_STRIDE 1040  // u32 words between two groups of 16 bin cursors (4160 bytes)
