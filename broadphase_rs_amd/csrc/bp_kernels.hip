@@ -2016,7 +2016,10 @@ __device__ unsigned long long g_sx_wave[8192][4];  // per wave of the last launc
 constexpr int SX_THREADS = 256;
 constexpr int SX_WAVES = SX_THREADS / 64;
 constexpr u32 SX_STAGE = SX_BLOCK + 128;  // per-wave LDS stage: one output block and the most one push can add to it
-constexpr u32 SX_BIG = 16384;           // ranges at least this long go to the work list, in slices of this size
+#ifndef SX_BIG_DEF
+#define SX_BIG_DEF 16384
+#endif
+constexpr u32 SX_BIG = SX_BIG_DEF;      // ranges at least this long go to the work list, in slices of this size
 static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
 
 struct ExpandParams {
@@ -3443,7 +3446,7 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_count_kernel(CellRoute cr, 
             const bool in_range = c >= g0 && c - g0 < n_groups;
             // the two fronts of the cell ran into each other / no finish kernel could take it / a first id outside the range the
             // caller vouched for / the layout failed
-            bad |= (cnt > r.w - r.z || r.w > limit || cnt >= 65536u || (cnt != 0u && !in_range)) ? 1u : 0u;
+            bad |= (r.w < r.z || cnt > r.w - r.z || r.w > limit || cnt >= 65536u || (cnt != 0u && !in_range)) ? 1u : 0u;
             mx = max(mx, cnt);
             over += cnt > cap ? cnt : 0u;
             return cnt;
@@ -3452,7 +3455,12 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_count_kernel(CellRoute cr, 
             if (c >= g0 && c - g0 <= n_groups) bounds[c - g0] = at;  // (bounds[n_groups]: the total -- the cells behind the groups are empty)
             // everything the finish kernel needs of group c - g0 in one 16-byte word: where its whole lines start, where the
             // records claimed downwards start, its offset in the dense output, its size and how much of it is whole lines
-            if (c >= g0 && c - g0 < n_groups) srcs[c - g0] = make_uint4(r.z, r.w - r.y, at, ((cnt & 0xFFFFu) << 16) | ((cnt - r.y) & 0xFFFFu));
+            // (a cell that is not sound -- overflowed, or laid out by a failed layout -- is handed on as EMPTY: the finish kernel runs
+            // before the host has seen the miss, and must not read where the cell claims to be)
+            if (c >= g0 && c - g0 < n_groups) {
+                const bool sound = r.w >= r.z && cnt <= r.w - r.z && r.w <= limit && cnt < 65536u;
+                srcs[c - g0] = sound ? make_uint4(r.z, r.w - r.y, at, ((cnt & 0xFFFFu) << 16) | ((cnt - r.y) & 0xFFFFu)) : make_uint4(0u, 0u, at, 0u);
+            }
         });
     for (int o = 32; o; o >>= 1) {
         mx = max(mx, (u32)__shfl_xor((int)mx, o, 64)); over += (u32)__shfl_xor((int)over, o, 64); bad |= (u32)__shfl_xor((int)bad, o, 64);
