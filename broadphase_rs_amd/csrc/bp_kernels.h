@@ -275,7 +275,7 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 // caller) = records present at the start of block g.  shards (zeroed by the caller): SX_SHARDS block
 // cursors followed by SX_SHARDS pair counts; shard s hands out blocks s, s + SX_SHARDS, ...  The
 // caller derives  pairs = sum(counts),  extent = max(cursor) * SX_SHARDS * SX_BLOCK  and re-runs with
-// more blocks when extent exceeds the capacity.  big_list: scratch for big_cap u64 work items;
+// more blocks when extent exceeds the capacity.  big_list: scratch for big_cap work items of TWO u64 each;
 // KERR_BIGLIST_OVERFLOW in sc->err means the result is incomplete (use scan_fused).
 #ifndef SX_BLOCK_DEF
 #define SX_BLOCK_DEF 256

@@ -2031,7 +2031,7 @@ struct ExpandParams {
     u32* blockfill;    // [out_blocks] zeroed by the host; records present in each block
     u64* shards;       // [SX_SHARDS] block cursors, [SX_SHARDS] pair counts, [SX_SHARDS] candidate counts (zeroed by the host)
     DevScalars* sc;
-    u64* big_list;     // j | slice << 32 (slice s covers candidates [s * SX_BIG, (s + 1) * SX_BIG) of j's range)
+    u64* big_list;     // two words per item: j | slice << 32 (slice s covers candidates [s * SX_BIG, (s + 1) * SX_BIG) of j's range), the range's end
     u32 big_cap;
     u32 n_waves;       // waves of the main kernel's grid (chunk stride)
     const float* filt_bounds;
@@ -2091,6 +2091,51 @@ __device__ __forceinline__ u32 range_end(const u64* __restrict__ keys, u32 m, u3
         else lo = mid;
     }
     return hi;
+}
+
+// The same for ONE range, by the whole wave (every lane calls it with the same arguments): first index > j whose key is >= upper
+// (m if none); keys[j] < upper.  The next 64 keys, then a gallop round (lane k probes j + 4^k) and 64-ary rounds: 1 / ~5 dependent memory round trips
+// for a range of a million entries, where the per-lane search above takes ~40 (and stalls the whole wave as long).
+__device__ __forceinline__ u32 range_end_wave(const u64* __restrict__ keys, u32 m, u32 j, u64 upper) {
+    const u32 lane = (u32)lane_id();
+    {   // most ranges that leave the window end within the next 64 entries: one coalesced load decides those
+        const u64 pos = (u64)j + 1u + lane;
+        const bool in = pos < (u64)m;
+        const u64 v = keys[in ? pos : (u64)m - 1u];
+        const u64 ge = ballot64(!in || v >= upper);
+        if (ge) return (u32)min((u64)j + 1u + (u64)__builtin_ctzll(ge), (u64)m);
+        j += 64u;  // (keys[j] < upper still holds; j < m)
+    }
+    u64 lo = j, hi = m;  // keys[lo] < upper <= keys[hi] (hi == m: virtual +inf)
+    {
+        const u64 pos = (u64)j + (lane < 16u ? (1ull << (2u * lane)) : (1ull << 32));
+        const bool in = pos < (u64)m;
+        const u64 v = keys[in ? pos : (u64)m - 1u];
+        const u64 ge = ballot64(!in || v >= upper) & 0xFFFFull;  // (lane 15 probes j + 2^30: beyond it only for m > 2^30)
+        if (ge) {
+            const int f = __builtin_ctzll(ge);
+            hi = min((u64)j + (1ull << (2 * f)), (u64)m);
+            if (f > 0) lo = (u64)j + (1ull << (2 * (f - 1)));
+        } else {
+            lo = (u64)j + (1ull << 30);
+        }
+    }
+    while (hi - lo > 1) {  // wave-uniform
+        const u64 span = hi - lo;
+        // 64 probes strictly inside (lo, hi), non-decreasing in the lane (a short span: consecutive positions, the last ones clamped)
+        const u64 pos = span <= 65 ? min(lo + 1 + lane, hi - 1) : lo + (span * (u64)(lane + 1)) / 65;
+        const u64 v = keys[pos];
+        const u64 ge = ballot64(v >= upper);
+        const u32 plo = (u32)pos, phi = (u32)(pos >> 32);
+        if (ge) {
+            const int f = __builtin_ctzll(ge);
+            hi = ((u64)(u32)__builtin_amdgcn_readlane((int)phi, f) << 32) | (u32)__builtin_amdgcn_readlane((int)plo, f);
+            if (f > 0) lo = ((u64)(u32)__builtin_amdgcn_readlane((int)phi, f - 1) << 32) | (u32)__builtin_amdgcn_readlane((int)plo, f - 1);
+        } else {
+            lo = ((u64)(u32)__builtin_amdgcn_readlane((int)phi, 63) << 32) | (u32)__builtin_amdgcn_readlane((int)plo, 63);
+        }
+    }
+    return (u32)hi;
 }
 
 template <int KIND> __device__ __forceinline__ u64 cell_upper(u64 key) {
@@ -2324,6 +2369,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         SX_ACC(0, t1 - t0);
         SX_ACC(5, 1);
         u32 c = 0, idj = 0, dj = 0, cbj = 0;
+        u32 end = 0;  // in the window: base + its slot there; SX_WIN + base: not in the window
         if (in0) {
             const u64 wj = pre.w0;
             idj = (u32)(wj >> 32);
@@ -2339,17 +2385,39 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 hi = ge ? mid : hi;
                 lo = ge ? lo : mid;  // mid == lo leaves lo unchanged as well
             }
-            u32 end;
-            if (hi < SX_WIN) end = (u32)base + hi;
-            else if ((u64)base + SX_WIN >= p.m) end = m;
-            else end = range_end(p.keys, m, (u32)base + SX_WIN - 1u, upper);
+            end = (u32)base + hi;
+        }
+        // Ranges that leave the window (rare on a uniform scene, one in most chunks of a mixed-scale one): their end is somewhere
+        // in HBM.  Up to four are searched by the whole wave, one after the other (~5 memory round trips each; the owner's key is
+        // still in the key window); more: every lane for itself (~40 dependent loads each, but all lanes at once).
+        if ((u64)base + SX_WIN >= p.m) {  // (wave-uniform) the window reaches the end of the tree
+            if (in0 && end == (u32)base + SX_WIN) end = m;
+        } else {
+            u64 fm = ballot64(in0 && end == (u32)base + SX_WIN);
+            if (fm != 0) {
+                if (__popcll(fm) <= 4) {
+                    while (fm) {
+                        const int l = __builtin_ctzll(fm);
+                        fm &= fm - 1;
+                        const u32 e = range_end_wave(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(win[l]));
+                        if (lane == l) end = e;
+                    }
+                } else if (in0 && end == (u32)base + SX_WIN) {
+                    end = range_end(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(key));
+                }
+            }
+        }
+        if (in0) {
             c = end - j - 1u;
-            if (GEN == 2 && ((u32)wj & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
-            if (c >= SX_BIG) {
+            if (GEN == 2 && ((u32)pre.w0 & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
+            if (c >= SX_BIG) {  // the work list: one item per slice, each with the range's end (the second kernel searches nothing)
                 const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
                 const u32 at = atomicAdd(&p.sc->big_count, ns);
                 if ((u64)at + ns <= p.big_cap) {
-                    for (u32 sl = 0; sl < ns; ++sl) p.big_list[at + sl] = (u64)j | ((u64)sl << 32);
+                    for (u32 sl = 0; sl < ns; ++sl) {
+                        p.big_list[2 * (size_t)(at + sl)] = (u64)j | ((u64)sl << 32);
+                        p.big_list[2 * (size_t)(at + sl) + 1] = (u64)end;
+                    }
                 } else {
                     atomicOr(&p.sc->err, (u32)KERR_BIGLIST_OVERFLOW);
                 }
@@ -2493,7 +2561,6 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     constexpr int FDIM = (int)KT<KIND>::DIM;
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     __shared__ u32 s_hist[SX_HIST_MAX * 256];
-    __shared__ u32 s_end;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 m = (u32)p.m;
     // an overflowed list has unwritten slots (a lane that did not fit reserved its slices anyway) and the host
@@ -2503,14 +2570,11 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
     sx_hist_clear(s_hist, p);
     WaveStage st{s_stage[w], 0u, (p.n_waves + blockIdx.x * SX_WAVES + (u32)w) % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const u64 item = p.big_list[it];
+        const u64 item = p.big_list[2 * (size_t)it];
         const u32 j = (u32)item, slice = (u32)(item >> 32);
+        const u32 end = min((u32)p.big_list[2 * (size_t)it + 1], m);  // (found by the wave that listed the range)
         const u64 key = p.keys[j];
         const u64 wj = p.idctx[j];
-        __syncthreads();
-        if (threadIdx.x == 0) s_end = range_end(p.keys, m, j, cell_upper<KIND>(key));
-        __syncthreads();
-        const u32 end = s_end;
         const u32 idj = (u32)(wj >> 32), dj = ctx_owner_dj(key_depth<KIND>(key)), cbj = ctx_owner_cbj((u32)wj);
         const u64 first = (u64)j + 1u + (u64)slice * SX_BIG;
         const u64 last = min(first + SX_BIG, (u64)end);

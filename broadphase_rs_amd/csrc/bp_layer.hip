@@ -1501,7 +1501,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         size_t big_cap = std::max<size_t>(65536, L->m / 16);
         if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));  // test hook: force the overflow fallback
         L->big_cap = big_cap;
-        BP_TRY(ensure_dev(L, L->big_list, big_cap * sizeof(uint64_t)));
+        BP_TRY(ensure_dev(L, L->big_list, big_cap * 2 * sizeof(uint64_t)));  // (two words per item)
     }
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -1725,7 +1725,7 @@ int scan_general_expand_device(bp_layer* L, uint32_t coarse_depth, int emit_coar
     size_t big_cap = std::max<size_t>(65536, L->m / 16);
     if (const char* e = getenv("BP_BIGLIST_CAP")) big_cap = std::max<size_t>(1, (size_t)atoll(e));
     L->big_cap = big_cap;
-    BP_TRY(ensure_dev(L, L->big_list, big_cap * sizeof(uint64_t)));
+    BP_TRY(ensure_dev(L, L->big_list, big_cap * 2 * sizeof(uint64_t)));  // (two words per item)
     const size_t shard_bytes = 3 * SX_SHARDS * sizeof(uint64_t);
     BP_TRY(ensure_dev(L, L->shards, shard_bytes));
     BP_TRY(ensure_host(L, L->h_shards, shard_bytes));

@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 lib = ctypes.CDLL(os.environ["BP_LIBRARY"])
 lib.bp_debug_sx_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 dev = torch.device("cuda:0")
-sysb, bounds, ids = scenes.gen_boxes(n, seed=1)
+sysb, bounds, ids = scenes.gen_boxes_powerlaw(n, seed=0, alpha=2.5) if os.environ.get("SX_POWERLAW") else scenes.gen_boxes(n, seed=1)
 d_bounds = torch.from_numpy(bounds).to(dev)
 d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
 L = bp.LayerBuilder.new().with_min_depth(0).with_device(0).build(bp.Index64_3D)
