@@ -3930,6 +3930,12 @@ static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hi
     if (rows < 0 || rows > SX_HIST_MAX) return hipErrorInvalidValue;
     if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS, sx_hist_bytes(p));
     unsigned res = std::min(resident[rows], resident_cap(SX_WAVES_PER_EU ? SX_WAVES_PER_EU * 4 / SX_WAVES : 64));
+    // small trees: a wave should have a dozen chunks to amortise its prologue, its last partial block and the counters' flush
+    // (1 M objects: 1536 workgroups 0.421 ms per frame, 1024 0.412, 768 0.414, 512 0.428); never fewer workgroups than CUs
+    {
+        const size_t chunks = (p.m + 63) / 64;
+        res = (unsigned)std::min<size_t>(res, std::max<size_t>(resident_cap(1), chunks / ((size_t)SX_WAVES * 12)));
+    }
     if (const char* e = getenv("BP_SX_GRID")) res = (unsigned)atoi(e);  // (measurement knob: workgroups of the persistent grid)
     const unsigned grid = (unsigned)std::min<size_t>(max_grid, res);
     p.n_waves = grid * SX_WAVES;
