@@ -3417,6 +3417,9 @@ __device__ __forceinline__ u32 cell_capacity(u32 cnt) { return cnt ? (cnt + cnt 
 constexpr int CELL_WGS = 64, CELL_THREADS = 256, CELL_PER_THREAD = (int)CELL_COUNT / (CELL_WGS * CELL_THREADS);
 static_assert(CELL_PER_THREAD == 4, "cell walk geometry");
 constexpr u64 CELL_SUM_MASK = (1ull << 40) - 1ull;
+// (the wait for an earlier workgroup's sum is bounded like the radix look-back's: it cannot run out while workgroups are dispatched
+// in order, and must not hang the device should that ever not hold -- a wait that does run out poisons the prefix with 2^39, which
+// every later workgroup then runs into as well: the last one's total fails every caller's check)
 template <class Load, class Value, class Emit>
 __device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Value&& value, Emit&& emit) {
     __shared__ u32 s_ws[CELL_THREADS / 64];
@@ -3442,9 +3445,11 @@ __device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Val
     if (t < 64u) {  // wave 0: the sums of the workgroups before this one
         u64 mine = 0;
         if (t < b) {
+            u32 spins = 0;
             for (;;) {
                 const u64 w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((u32)(w >> 40) == tag) { mine = w & CELL_SUM_MASK; break; }
+                if (++spins > LOOKBACK_SPIN_LIMIT) { mine = 1ull << 39; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
