@@ -149,6 +149,9 @@ def cpu_baseline(n_objects, seed):
 
 
 # one kernel per class on the default path (bp_kernel_class of include/bp_layer.h) -> (kernel name, SURVEY 8(d) bytes per launch)
+EVENT_EVERY = 4   # the timed region's HIP events bracket the dominant class in every 4th frame (run_single)
+
+
 def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False):
     """cells / tree_cells: the timed frames' pair / tree sorts took the cell route (bp_stats.sorts_in_cells, tree_sorts_in_cells:
     two claiming passes, no stable pass)"""
@@ -170,8 +173,11 @@ def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False):
     }
 
 
-def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, aabb_filter=False, detail=True):
-    """steady-state frames of one layer on one GPU -> dict of measurements (all times in ms)"""
+def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, aabb_filter=False, detail=True, events=True):
+    """steady-state frames of one layer on one GPU -> dict of measurements (all times in ms).
+    events: the dominant class is timed with HIP events inside the timed region (the roofline's duration) -- in every
+    EVENT_EVERY-th frame (every 2nd of a short run): an event pair costs ~5 us of stream bubble, four of them per frame would be 1 % of the 10 M step
+    and 5 % of the 1 M frame.  A run that reports no roofline (events=False) records none."""
     sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
     d_bounds = torch.from_numpy(bounds).to(dev)
     d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
@@ -212,9 +218,13 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     dom_cls = max(table, key=lambda c: wprof[c][0])
     cells0, tcells0 = layer.stats()["sorts_in_cells"], layer.stats()["tree_sorts_in_cells"]
     # timed region: events only around the dominant class (every event pair costs a few us of stream bubble)
-    layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(True)
+    layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(events)
+    every = EVENT_EVERY if steps >= 4 * EVENT_EVERY else 2 if steps >= 4 else 1   # (at least two timed frames)
+    layer.profile_sample(every)
+    res["event_every"] = every if events else 0
     syncs0 = layer.stats()["host_syncs"]
     res["ms_per_step"], out = timed(steps)
+    layer.profile_sample(1)
     res["host_syncs_per_step"] = (layer.stats()["host_syncs"] - syncs0) / steps
     res["cell_route"] = (layer.stats()["sorts_in_cells"] - cells0) == steps   # every timed frame's pair sort took the cell route
     res["tree_cell_route"] = (layer.stats()["tree_sorts_in_cells"] - tcells0) == steps
@@ -331,7 +341,7 @@ def main():
         line["set_hash"] = set_hash_torch(r["out"].as_torch()) if r["n_pairs"] else [0, 0, 0]
         del r["out"]
         if not args.no_1m and args.objects != 1_000_000 and not args.aabb_filter:
-            r1 = run_single(bp, scenes, torch, np, dev, local_rank, 1_000_000, args.seed, 5, 50, detail=False)
+            r1 = run_single(bp, scenes, torch, np, dev, local_rank, 1_000_000, args.seed, 5, 50, detail=False, events=False)
             line["config_1m"] = {"workload": "configs[1]: 1M Index64_3D uniform-random AABBs, single MI355X, clear+extend+par_sort+par_scan",
                                  "ms_per_step": r1["ms_per_step"], "pairs": r1["n_pairs"],
                                  "value": r1["n_pairs"] / (r1["ms_per_step"] * 1e-3), "unit": "pairs/s",
@@ -582,7 +592,11 @@ def single_gpu_line(args, r, np):
                    "tree_sort_passes": pk, "pair_sort_passes": pp, "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
-                     "avg_launch_ms": per_launch_ms, "launches_per_step": dom_prof[1] / steps if dom_prof[1] else 0.0,
+                     "avg_launch_ms": per_launch_ms,
+                     "launches_per_step": dom_prof[1] * max(1, r.get("event_every", 1)) / steps if dom_prof[1] else 0.0,
+                     "timed_launches": dom_prof[1],
+                     "event_sampling": "HIP events on the layer's stream inside the timed region, around every launch of the class in every "
+                                       "%d-th frame (an event pair costs ~5 us of stream bubble)" % max(1, r.get("event_every", 1)),
                      "chosen_by": "largest total time per step over all kernel classes (warm-up pass with every class timed); a radix class is "
                                   "one launch per pass (two different kernels): achieved = bytes per pass / the passes' mean duration",
                      "bytes_model": "SURVEY.md 8(d) per-unit figures x this run's N / M / P_raw / P"},

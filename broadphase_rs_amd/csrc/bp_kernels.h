@@ -53,6 +53,15 @@ enum : unsigned {
     KERR_ENCODE_OVERFLOW = 32u,  // encode_emit launched on a PREDICTED capacity that was too small (nothing was written)
 };
 
+// Where a kernel leaves results for a host that is waiting for them: pinned, host-coherent memory (hipHostMalloc; the pointers are
+// its device addresses).  The kernel writes the data to dst, then -- behind a system-scope release -- seq to *flag; seq is a number
+// the host has not used for this flag before.
+struct Published {
+    void* dst;
+    unsigned int* flag;
+    unsigned int seq;
+};
+
 // per-workgroup partial results of encode_count, folded into DevScalars by scan_block_sums
 struct BlockAux {
     unsigned long long key_or, key_and;
@@ -106,9 +115,15 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
 // partials are folded into *sc as well (single workgroup, no atomics)
 // init (with aux): *sc starts from *init before the partials are folded in (no separate reset); zero_a / zero_b: 64-bit arrays
 // zero-filled by the same launch (the histograms the following emit kernel adds into)
+// pub: the final *sc also goes to pinned host memory, followed by the launch's number (struct Published)
 hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
                                   hipStream_t stream, const DevScalars* init = nullptr, unsigned long long* zero_a = nullptr,
-                                  size_t n_a = 0, unsigned long long* zero_b = nullptr, size_t n_b = 0);
+                                  size_t n_a = 0, unsigned long long* zero_b = nullptr, size_t n_b = 0, const struct Published* pub = nullptr);
+// `bytes` (a multiple of 4) of device memory -> pub.dst, then pub.seq -> *pub.flag: a host that spins on the flag has what a D2H
+// copy + hipStreamSynchronize would give it (everything enqueued before this launch has completed), a few microseconds sooner
+// (src2: a second block of bytes2 bytes, to pub.dst + dst_off2)
+hipError_t launch_publish(const void* src, size_t bytes, const struct Published& pub, hipStream_t stream, const void* src2 = nullptr,
+                          size_t bytes2 = 0, size_t dst_off2 = 0);
 
 // OR/AND/depth-mask reduction over an existing tree (set_tree / append_entries)
 hipError_t launch_tree_reduce(int kind, const uint64_t* keys, const uint32_t* ids, size_t m, DevScalars* sc,
@@ -178,6 +193,9 @@ struct CellRoute {
     uint32_t* out_vals;         //   key-only sorts leave it in keys0 (both null)
     unsigned long long* status; // [64] scratch of the two cell walks (zero once, when allocated)
     uint32_t tag;               // an even number the caller never repeats for this `status` (launch_cell_layout tags its walk with it, launch_cell_count with tag + 1)
+    // the layout folded into the sort's first kernel (radix_sort with ready_hist; one launch less): launch_cell_layout's arguments,
+    // layout_prev_bounds == nullptr when the caller has run launch_cell_layout itself
+    const uint32_t* layout_prev_bounds; uint32_t layout_g0, layout_groups; size_t layout_limit;
 };
 // cell_base from the group bounds of the previous sort (prev_bounds[g] = start of group prev_g0 + g, g = 0 .. prev_groups; cell
 // index = group index = first id >> 8): capacity = count + 25 % + 64, rounded to whole lines (an empty cell: one line);

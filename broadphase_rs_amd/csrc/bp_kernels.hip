@@ -442,12 +442,18 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
     }
     return v;
 }
+// results the host waits for, written straight into pinned host memory: the data first, then (system-scope release) the number
+// of the launch in *flag -- the host spins on the flag (bp_layer.hip: wait_published)
+__device__ __forceinline__ void publish_flag(const Published& pub) {
+    __threadfence_system();
+    __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // Between the count and the emit kernel of an extend this kernel is also where the frame's small resets ride along: *sc starts
 // from `init` (set_init) instead of an H2D copy, and the histograms the emit kernel adds into are zero-filled here (zero_a / zero_b).
 __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __restrict__ sums, size_t n,
                                                                      const BlockAux* __restrict__ aux, DevScalars* sc, DevScalars init,
                                                                      int set_init, u64* __restrict__ zero_a, u32 n_a, u64* __restrict__ zero_b,
-                                                                     u32 n_b) {
+                                                                     u32 n_b, Published pub) {
     for (u32 k = threadIdx.x; k < n_a; k += SBS_THREADS) zero_a[k] = 0ull;
     for (u32 k = threadIdx.x; k < n_b; k += SBS_THREADS) zero_b[k] = 0ull;
     __shared__ u64 s_wave[SBS_THREADS / 64];
@@ -515,8 +521,25 @@ __global__ __launch_bounds__(SBS_THREADS) void scan_block_sums_kernel(u64* __res
             }
         }
     }
-    if (threadIdx.x == 0) sc->total = s_carry;
+    if (threadIdx.x == 0) {
+        sc->total = s_carry;
+        if (pub.dst) {  // the host polls pinned memory for this launch's number instead of waiting for a copy behind the kernel
+            *reinterpret_cast<DevScalars*>(pub.dst) = *sc;
+            publish_flag(pub);
+        }
+    }
 }
+// a block of device words -> pinned host memory, then the launch's number (Published): what a D2H copy + stream synchronisation does,
+// without the copy engine's hand-over and the completion interrupt
+__global__ __launch_bounds__(256) void publish_kernel(const u32* __restrict__ src, u32 words, Published pub, const u32* __restrict__ src2, u32 words2,
+                                                      u32 off2) {
+    u32* dst = reinterpret_cast<u32*>(pub.dst);
+    for (u32 k = threadIdx.x; k < words; k += 256u) dst[k] = src[k];
+    for (u32 k = threadIdx.x; k < words2; k += 256u) dst[off2 + k] = src2[k];
+    __syncthreads();  // (every thread's stores precede thread 0's fence in program order of the workgroup: the fence below is device-wide)
+    if (threadIdx.x == 0) publish_flag(pub);
+}
+
 
 // OR / AND / depth mask over an existing tree (set_tree, append_entries)
 template <int KIND>
@@ -651,10 +674,9 @@ constexpr int RS_TICKETS = 1;  // ticket counters per pass
 // The front end of a sort in one launch (blockIdx.x = pass): digit counts (summed over the producer's copies, or already
 // in `hist`), their exclusive prefix = the bins' bases, the pass's tile ticket back to zero and -- optionally -- the
 // scalars the sort's kernels report into reset to `sc_init`.
-__global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
-                                                                u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
-                                                                DevScalars sc_init, int set_sc, u32* __restrict__ cursors = nullptr,
-                                                                ScanFinalize fin = ScanFinalize{}) {
+__device__ __forceinline__ void radix_prepare_body(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
+                                                   u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
+                                                   const DevScalars& sc_init, int set_sc, u32* __restrict__ cursors, const ScanFinalize& fin) {
     __shared__ u64 s_wave[RS_BINS / 64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     // the sizes of the scan this sort was enqueued behind (fin.sc may be the very scalars thread 0 resets below: read first)
@@ -686,6 +708,12 @@ __global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __res
         for (int j = 0; j < RS_TICKETS; ++j) counters[blockIdx.x * RS_TICKETS + j] = 0;
         if (set_sc && blockIdx.x == 0) *sc = sc_init;
     }
+}
+__global__ __launch_bounds__(RS_BINS) void radix_prepare_kernel(const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
+                                                                u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
+                                                                DevScalars sc_init, int set_sc, u32* __restrict__ cursors = nullptr,
+                                                                ScanFinalize fin = ScanFinalize{}) {
+    radix_prepare_body(copies, n_copies, hist, bin_base, counters, sc, sc_init, set_sc, cursors, fin);
 }
 
 // digit functors: what a one-sweep pass buckets by
@@ -3321,14 +3349,20 @@ static unsigned resident_blocks(Kern kernel, int threads, size_t dyn_lds = 0) {
     return (unsigned)(cus * per_cu);
 }
 
+hipError_t launch_publish(const void* src, size_t bytes, const Published& pub, hipStream_t stream, const void* src2, size_t bytes2, size_t dst_off2) {
+    if (!pub.dst || !pub.flag || ((bytes | bytes2 | dst_off2) & 3u) != 0 || bytes > (1u << 20) || bytes2 > (1u << 20)) return hipErrorInvalidValue;
+    if (src2 && dst_off2 < bytes) return hipErrorInvalidValue;
+    publish_kernel<<<1, 256, 0, stream>>>((const u32*)src, (u32)(bytes / 4), pub, (const u32*)src2, src2 ? (u32)(bytes2 / 4) : 0u, (u32)(dst_off2 / 4));
+    return hipGetLastError();
+}
 hipError_t launch_scan_block_sums(unsigned long long* sums, size_t n, const BlockAux* aux, DevScalars* sc,
                                   hipStream_t stream, const DevScalars* init, unsigned long long* zero_a, size_t n_a,
-                                  unsigned long long* zero_b, size_t n_b) {
+                                  unsigned long long* zero_b, size_t n_b, const Published* pub) {
     if (n_a >= 0xFFFFFFFFull || n_b >= 0xFFFFFFFFull || (init && !aux)) return hipErrorInvalidValue;
     DevScalars iv = {};
     if (init) iv = *init;
     scan_block_sums_kernel<<<1, SBS_THREADS, 0, stream>>>(sums, n, aux, sc, iv, init ? 1 : 0, (u64*)zero_a, zero_a ? (u32)n_a : 0u,
-                                                          (u64*)zero_b, zero_b ? (u32)n_b : 0u);
+                                                          (u64*)zero_b, zero_b ? (u32)n_b : 0u, pub ? *pub : Published{});
     return hipGetLastError();
 }
 
@@ -3463,10 +3497,10 @@ __device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Val
     for (int k = 0; k < CELL_PER_THREAD; ++k) emit(b * 1024u + (u32)k * CELL_THREADS + t, (u32)before + row[k] + ex[k], v[k], raw[k]);
     return before + wg_total;  // (the last workgroup: the grand total)
 }
-__global__ __launch_bounds__(CELL_THREADS) void cell_layout_kernel(const u32* __restrict__ prev_bounds, u32 prev_g0, u32 prev_groups,
-                                                                   u32* __restrict__ cell_base, u32* __restrict__ line_cur,
-                                                                   u32* __restrict__ frag_cur, u32* __restrict__ miss, u64 limit,
-                                                                   u64* status, u32 tag) {
+__device__ __forceinline__ void cell_layout_body(const u32* __restrict__ prev_bounds, u32 prev_g0, u32 prev_groups,
+                                                 u32* __restrict__ cell_base, u32* __restrict__ line_cur,
+                                                 u32* __restrict__ frag_cur, u32* __restrict__ miss, u64 limit,
+                                                 u64* status, u32 tag) {
     // (capacities are clamped: prev_bounds may be anything when the caller's bookkeeping was wrong -- the total then fails the
     // limit and *miss is set: the sort's kernels drop what does not fit its cell, nothing is written out of bounds as long as
     // limit <= the buffer, because cell_base[CELL_COUNT] is what every range is clipped to)
@@ -3488,6 +3522,23 @@ __global__ __launch_bounds__(CELL_THREADS) void cell_layout_kernel(const u32* __
         cell_base[CELL_COUNT] = (u32)(fits ? total : 0ull);
         *miss = fits ? 0u : 1u;
     }
+}
+__global__ __launch_bounds__(CELL_THREADS) void cell_layout_kernel(const u32* __restrict__ prev_bounds, u32 prev_g0, u32 prev_groups,
+                                                                   u32* __restrict__ cell_base, u32* __restrict__ line_cur,
+                                                                   u32* __restrict__ frag_cur, u32* __restrict__ miss, u64 limit,
+                                                                   u64* status, u32 tag) {
+    cell_layout_body(prev_bounds, prev_g0, prev_groups, cell_base, line_cur, frag_cur, miss, limit, status, tag);
+}
+// the sort's first kernel and the layout of its cells in one launch (the two are independent of each other and both tiny: a
+// launch costs ~5 us whatever it does): CELL_WGS workgroups, the first n_passes of which also do radix_prepare_kernel's work
+static_assert(CELL_THREADS == RS_BINS, "the fused launch runs both bodies with one workgroup shape");
+__global__ __launch_bounds__(RS_BINS) void radix_prepare_layout_kernel(int n_passes, const u64* __restrict__ copies, int n_copies, u64* __restrict__ hist,
+                                                                       u64* __restrict__ bin_base, u32* __restrict__ counters, DevScalars* sc,
+                                                                       DevScalars sc_init, int set_sc, u32* __restrict__ cursors, ScanFinalize fin,
+                                                                       CellRoute cr) {
+    if ((int)blockIdx.x < n_passes) radix_prepare_body(copies, n_copies, hist, bin_base, counters, sc, sc_init, set_sc, cursors, fin);  // (workgroup-uniform)
+    cell_layout_body(cr.layout_prev_bounds, cr.layout_g0, cr.layout_groups, (u32*)cr.cell_base, cr.line_cur, cr.frag_cur, cr.miss, (u64)cr.layout_limit,
+                     (u64*)cr.status, cr.tag);
 }
 hipError_t launch_cell_layout(const uint32_t* prev_bounds, uint32_t prev_g0, uint32_t prev_groups, uint32_t* cell_base, uint32_t* line_cur,
                               uint32_t* frag_cur, uint32_t* miss, size_t limit, unsigned long long* status, uint32_t tag, hipStream_t stream) {
@@ -3644,9 +3695,15 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
     }
     DevScalars init = {};
     if (sc_init) init = *sc_init;
+    if (cells && cells->layout_prev_bounds && !ready_hist) return hipErrorInvalidValue;  // (the folded layout lives in the ready-histogram kernel)
     if (ready_hist) {  // the producer of the records already counted the digits of this plan
-        radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
-                                                         claim ? cursors : nullptr, finalize ? *finalize : ScanFinalize{});
+        if (cells && cells->layout_prev_bounds)
+            radix_prepare_layout_kernel<<<CELL_WGS, RS_BINS, 0, stream>>>(np, (const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init,
+                                                                          sc_init ? 1 : 0, claim ? cursors : nullptr,
+                                                                          finalize ? *finalize : ScanFinalize{}, *cells);
+        else
+            radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>((const u64*)ready_hist, ready_copies, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
+                                                             claim ? cursors : nullptr, finalize ? *finalize : ScanFinalize{});
     } else {
         if (epoch_io) {  // the counting kernel adds into the histogram
             e = hipMemsetAsync(hist, 0, (size_t)np * RS_BINS * sizeof(u64), stream);

@@ -41,6 +41,10 @@ struct bp_layer {
     hipStream_t stream = nullptr;
     hipEvent_t fence_ev = nullptr;   // bp_layer_wait_stream: orders this layer's stream after a producer's
     hipEvent_t early_ev = nullptr;   // extend on predicted sizes: the scalars' copy, waited for while encode_emit already runs
+    // results the host waits for in the per-frame path arrive in pinned host memory, written by the kernels themselves (struct
+    // Published): [0, PUB_FLAGS_OFF) the data, then the flag word; pub_seq numbers the launches
+    void* pub = nullptr;
+    uint32_t pub_seq = 0;
 
     // persistent state: tree (src/layer.rs:49-50)
     DevBuf keys[2], ids[2];
@@ -143,7 +147,8 @@ struct bp_layer {
     struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; } enc_hint;
     // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
     // NEXT host round trip (the scan's) instead of one of their own
-    struct { bool on = false; int src = 0; bool ride = false; bool cells = false; } sort_pend;
+    // copied: the sort's scalars are on their way to h_sort_sc (a deferred check leaves that to the fetch it rides on: sort_sc_fetch)
+    struct { bool on = false; int src = 0; bool ride = false; bool cells = false; bool copied = false; } sort_pend;
     // cell route of the grouped tree sort (CellRoute with a payload): laid out from the group bounds the previous sort of the same
     // plan left in tgrp_bounds; its gapped result goes to tcell_keys / tcell_ids, the finish kernel writes the dense tree
     struct { bool valid = false; unsigned long long g0 = 0; uint32_t n_groups = 0; int gshift = 0; size_t m = 0; } tcell;
@@ -158,6 +163,7 @@ struct bp_layer {
     HostBuf h_sort_sc;
     int filt_shape = FILT_AABB;         // row shape of the built-in narrow phase during scan_filtered_*
     uint32_t prof_mask = 0xFFFFFFFFu;   // kernel classes that get event pairs while prof_on
+    uint32_t prof_every = 1, prof_frame = 0;  // event pairs only in every prof_every-th frame (frames are counted by bp_layer_clear)
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     int prof_open = -1;
@@ -271,6 +277,7 @@ void prof_mark(void* ctx, int cls) {
     if (!L->prof_on) return;
     if (cls >= 0) {
         if (!((L->prof_mask >> cls) & 1u)) return;  // class not selected: no events, no stream bubbles
+        if (L->prof_every > 1 && (L->prof_frame % L->prof_every) != 0) return;  // not a sampled frame
         L->prof_open = cls;
         L->prof_open_ev = prof_event(L);
         if (L->prof_open_ev) (void)hipEventRecord(L->prof_open_ev, L->stream);
@@ -302,9 +309,14 @@ struct ProfScope {
     ~ProfScope() { prof_mark(L, -1); }
 };
 
+int after_sync(bp_layer* L);
 int sync_stream(bp_layer* L) {
     ++L->stats.host_syncs;
     HIP_TRY(L, hipStreamSynchronize(L->stream));
+    return after_sync(L);
+}
+// what follows every completed wait for the stream (also a wait on a published flag behind everything enqueued)
+int after_sync(bp_layer* L) {
     prof_collect(L);
     if (L->part_pend) {  // an enqueue-only partition pass has completed by now: its error word
         L->part_pend = false;
@@ -312,6 +324,44 @@ int sync_stream(bp_layer* L) {
         if (err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out in the entry partition pass (its buckets were incomplete)");
     }
     return BP_OK;
+}
+
+// ---- results published by kernels into pinned host memory (struct Published) -------------------------------
+constexpr size_t PUB_FLAG_OFF = 4096, PUB_BYTES = PUB_FLAG_OFF + 64, PUB_SORT_OFF = 3072;  // (a second block: the tree sort's scalars)
+int pub_next(bp_layer* L, Published* out) {
+    if (!L->pub) {
+        void* q = nullptr;
+        hipError_t e = hipHostMalloc(&q, PUB_BYTES, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) return fail(L, BP_ERR_OOM, "hipHostMalloc", e);
+        std::memset(q, 0, PUB_BYTES);
+        L->pub = q;
+        L->pub_seq = 0;
+    }
+    if (++L->pub_seq == 0) L->pub_seq = 1;  // (0 is the flag's initial value)
+    void* dev = nullptr;
+    HIP_TRY(L, hipHostGetDevicePointer(&dev, L->pub, 0));
+    out->dst = dev;
+    out->flag = (unsigned int*)((char*)dev + PUB_FLAG_OFF);
+    out->seq = L->pub_seq;
+    return BP_OK;
+}
+// spins until the launch `seq` has published (a host round trip like any other: counted); the stream is looked at now and then, so
+// that a failed launch or a device error ends the wait
+int pub_wait(bp_layer* L, uint32_t seq) {
+    ++L->stats.host_syncs;
+    const unsigned int* flag = (const unsigned int*)((const char*)L->pub + PUB_FLAG_OFF);
+    for (unsigned long long spins = 1;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return BP_OK;
+        if ((spins & 0x3FFFull) == 0) {
+            const hipError_t q = hipStreamQuery(L->stream);
+            if (q == hipSuccess) {  // everything has run: the flag is there, or the publishing launch never happened
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return BP_OK;
+                return fail(L, BP_ERR_KERNEL, "a kernel's published results did not arrive");
+            }
+            if (q != hipErrorNotReady) return fail(L, BP_ERR_HIP, "hipStreamQuery", q);
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 // ---- device scalars ---------------------------------------------------------------------------------
@@ -322,6 +372,14 @@ DevScalars neutral_scalars() {  // neutral elements for every reduction
     n.id_and = 0xFFFFFFFFu;
     n.id_min = 0xFFFFFFFFu;
     return n;
+}
+// a tree sort whose check was deferred: its scalars join the D2H traffic of the round trip that settles it
+int sort_sc_fetch(bp_layer* L) {
+    if (L->sort_pend.on && !L->sort_pend.copied) {
+        HIP_TRY(L, hipMemcpyAsync(L->h_sort_sc.p, L->d_sort_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
+        L->sort_pend.copied = true;
+    }
+    return BP_OK;
 }
 int sc_reset(bp_layer* L) {
     DevScalars* h = (DevScalars*)L->h_sc.p;
@@ -339,6 +397,7 @@ const uint32_t* sc_sizes_host(bp_layer* L) { return (const uint32_t*)((const cha
 uint64_t* sc_shards_dev(bp_layer* L) { return (uint64_t*)((char*)L->d_sc.p + SC_SHARDS_OFF); }
 const uint64_t* sc_shards_host(bp_layer* L) { return (const uint64_t*)((const char*)L->h_sc.p + SC_SHARDS_OFF); }
 int sc_fetch(bp_layer* L, DevScalars* out, bool with_shards = false) {  // D2H + sync
+    BP_TRY(sort_sc_fetch(L));
     HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, with_shards ? SC_SIZES_OFF : sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
     BP_TRY(sync_stream(L));
     *out = *(DevScalars*)L->h_sc.p;
@@ -468,19 +527,23 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
                                        (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS,
                                        count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, cell_bytes / sizeof(unsigned long long)));
     }
+    static const bool no_early = getenv("BP_NO_EARLY_FETCH") != nullptr;  // A/B switches
+    static const bool no_publish = getenv("BP_NO_PUBLISH") != nullptr;
+    const bool early = !no_early && !count_cells;
+    Published early_pub{};
+    if (early && !no_publish) BP_TRY(pub_next(L, &early_pub));
     {
         ProfScope ps(L, BP_K_MISC);
         const DevScalars init = neutral_scalars();
         HIP_TRY(L, launch_scan_block_sums((unsigned long long*)L->block_sums.p, nb, (const BlockAux*)L->aux.p, (DevScalars*)L->d_sc.p, L->stream,
-                                          &init, nullptr, 0, nullptr, 0));
+                                          &init, nullptr, 0, nullptr, 0, early_pub.dst ? &early_pub : nullptr));
     }
     // The entry total and the facts are final once the block sums are scanned: their copy is enqueued BEFORE encode_emit and
     // the host waits for that copy alone (an event), while encode_emit is already running behind it -- the round trip costs
     // the GPU no idle time, and the sort's kernels queue up behind the emit pass.  (The emit pass's own capacity guard is
-    // evaluated on the host from the same total.)
-    static const bool no_early = getenv("BP_NO_EARLY_FETCH") != nullptr;  // A/B switch
-    const bool early = !no_early && !count_cells;
-    if (early) {
+    // evaluated on the host from the same total.)  Better still, scan_block_sums PUBLISHES them (struct Published): no copy sits
+    // between the two kernels (a D2H copy + event cost the stream 6 - 13 us there) and the host polls memory.
+    if (early && !early_pub.dst) {
         if (!L->early_ev && hipEventCreateWithFlags(&L->early_ev, hipEventDisableTiming) != hipSuccess) return fail(L, BP_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
         HIP_TRY(L, hipEventRecord(L->early_ev, L->stream));
@@ -505,9 +568,14 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     }
     DevScalars sc;
     if (early) {
-        ++L->stats.host_syncs;  // a host round trip all the same (the GPU stays busy through it)
-        HIP_TRY(L, hipEventSynchronize(L->early_ev));
-        sc = *(const DevScalars*)L->h_sc.p;
+        if (early_pub.dst) {
+            BP_TRY(pub_wait(L, early_pub.seq));  // a host round trip all the same (the GPU stays busy through it)
+            sc = *(const DevScalars*)L->pub;
+        } else {
+            ++L->stats.host_syncs;
+            HIP_TRY(L, hipEventSynchronize(L->early_ev));
+            sc = *(const DevScalars*)L->h_sc.p;
+        }
         if (sc.err & KERR_COUNT_OVERFLOW)
             return fail(L, BP_ERR_TOO_LARGE, "an object expands to more than 2^20 cells (min_depth too high for its size)");
         if ((size_t)sc.total > capacity) sc.err |= KERR_ENCODE_OVERFLOW;  // what the emit pass's guard concludes from the same total
@@ -833,8 +901,12 @@ int sort_tree_by_merge(bp_layer* L, int* handled) {
 int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     if (redone) *redone = false;
     if (!L->sort_pend.on) return BP_OK;
+    if (!already_synced) {
+        BP_TRY(sort_sc_fetch(L));
+        BP_TRY(sync_stream(L));
+    }
+    if (!L->sort_pend.copied) return fail(L, BP_ERR_KERNEL, "internal: a deferred sort check was settled without its scalars");
     L->sort_pend.on = false;
-    if (!already_synced) BP_TRY(sync_stream(L));
     const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     const bool tgrp_before = L->tgrp_ok;
@@ -936,8 +1008,8 @@ int sort_tree(bp_layer* L, bool defer_check) {
                     L->tcell_tag = 2;
                 }
                 cr.tag = L->tcell_tag;
-                HIP_TRY(L, launch_cell_layout((const uint32_t*)L->tgrp_bounds.p, cell0, gp.n_groups, (uint32_t*)cr.cell_base, cr.line_cur, cr.frag_cur,
-                                              cr.miss, slots, cr.status, cr.tag, L->stream));
+                // (the layout runs inside the sort's first kernel)
+                cr.layout_prev_bounds = (const uint32_t*)L->tgrp_bounds.p; cr.layout_g0 = cell0; cr.layout_groups = gp.n_groups; cr.layout_limit = slots;
             }
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, d_ssc,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
@@ -974,13 +1046,12 @@ int sort_tree(bp_layer* L, bool defer_check) {
             }
             // (optimistic, like the rest of the state below: tgrp_bounds will hold this sort's group bounds)
             L->tcell.valid = true; L->tcell.g0 = gp.g0; L->tcell.n_groups = gp.n_groups; L->tcell.gshift = gp.gshift; L->tcell.m = L->m;
-            HIP_TRY(L, hipMemcpyAsync(L->h_sort_sc.p, L->d_sort_sc.p, sizeof(DevScalars), hipMemcpyDeviceToHost, L->stream));
             // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
             L->cur = dst;
             L->box_valid = ride;
             if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0; }
             L->ids_packed = false;
-            L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride; L->sort_pend.cells = tcell;
+            L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride; L->sort_pend.cells = tcell; L->sort_pend.copied = false;
             static const bool no_defer = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
             if (defer_check && !no_defer) {  // no host round trip here: the check rides on the caller's next one
                 L->sorted = true;
@@ -1577,10 +1648,9 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                     cr.src = (uint4*)cw;  // (16-byte aligned: first)
                     cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
                     cr.miss = d_sizes + SIZES_CELL_MISS;
-                    // (no timed region of its own: one more event pair per frame made the NEXT frame's first regions -- encode --
-                    // read 76 us longer in the per-class table, the kernels themselves unchanged in the trace)
-                    HIP_TRY(L, launch_cell_layout((const uint32_t*)L->grp_bounds.p, h.first_lo >> 8, h.n_groups, (uint32_t*)cr.cell_base, cr.line_cur, cr.frag_cur, cr.miss,
-                                                  out_blocks * SX_BLOCK, cr.status, cr.tag, L->stream));
+                    // (the layout runs inside the sort's first kernel)
+                    cr.layout_prev_bounds = (const uint32_t*)L->grp_bounds.p; cr.layout_g0 = h.first_lo >> 8; cr.layout_groups = h.n_groups;
+                    cr.layout_limit = out_blocks * SX_BLOCK;
                 }
                 int res = 0;
                 {
@@ -1599,8 +1669,29 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                                    (DevScalars*)L->d_sc.p, L->stream, group_stats_words((DevScalars*)L->d_sc.p),
                                                    (uint32_t)(h.varying & 0xFFFFFFFFull), d_sizes, cell_route ? &cr : nullptr));
                 }
-                HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, SC_BLOCK_BYTES, hipMemcpyDeviceToHost, L->stream));
-                BP_TRY(sync_stream(L));
+                static const bool no_publish = getenv("BP_NO_PUBLISH") != nullptr;  // A/B switch
+                if (!no_publish) {
+                    // the frame's one blocking round trip: the last kernel publishes the scalars block into pinned memory and the host
+                    // polls for it (a D2H copy + hipStreamSynchronize: the copy's hand-over and the completion interrupt on top)
+                    static_assert(SC_BLOCK_BYTES <= PUB_SORT_OFF && PUB_SORT_OFF + sizeof(DevScalars) <= PUB_FLAG_OFF && SC_BLOCK_BYTES % 4 == 0 &&
+                                  sizeof(DevScalars) % 4 == 0, "published block layout");
+                    Published fp{};
+                    BP_TRY(pub_next(L, &fp));
+                    // (the scalars of a tree sort whose check is still pending ride along)
+                    const bool with_sort = L->sort_pend.on && !L->sort_pend.copied;
+                    HIP_TRY(L, launch_publish(L->d_sc.p, SC_BLOCK_BYTES, fp, L->stream, with_sort ? L->d_sort_sc.p : nullptr, sizeof(DevScalars), PUB_SORT_OFF));
+                    BP_TRY(pub_wait(L, fp.seq));
+                    std::memcpy(L->h_sc.p, L->pub, SC_BLOCK_BYTES);
+                    if (with_sort) {
+                        std::memcpy(L->h_sort_sc.p, (const char*)L->pub + PUB_SORT_OFF, sizeof(DevScalars));
+                        L->sort_pend.copied = true;
+                    }
+                    BP_TRY(after_sync(L));
+                } else {
+                    BP_TRY(sort_sc_fetch(L));
+                    HIP_TRY(L, hipMemcpyAsync(L->h_sc.p, L->d_sc.p, SC_BLOCK_BYTES, hipMemcpyDeviceToHost, L->stream));
+                    BP_TRY(sync_stream(L));
+                }
                 ++L->stats.sorts_ahead;
                 if (cell_route) ++L->stats.sorts_in_cells;
                 {
@@ -1942,6 +2033,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);
     if (L->early_ev) (void)hipEventDestroy(L->early_ev);
+    if (L->pub) (void)hipHostFree(L->pub);
     if (L->fence_ev) (void)hipEventDestroy(L->fence_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
@@ -1987,6 +2079,7 @@ int bp_layer_clear(bp_layer_t* L) {
     L->sort_pend.on = false;  // a sort whose result is dropped needs no check (its kernels stay ordered on the stream)
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
+    ++L->prof_frame;
     L->m = 0;
     L->sorted = true;  // src/layer.rs:84-88
     reset_tree_facts(L);
@@ -2911,6 +3004,12 @@ int bp_layer_profile_enable(bp_layer_t* L, int on) { if (!L) return BP_ERR_INVAL
 int bp_layer_profile_select(bp_layer_t* L, uint32_t class_mask) {
     if (!L) return BP_ERR_INVALID_ARG;
     L->prof_mask = class_mask;
+    return BP_OK;
+}
+int bp_layer_profile_sample(bp_layer_t* L, uint32_t every) {
+    if (!L || every == 0) return BP_ERR_INVALID_ARG;
+    L->prof_every = every;
+    L->prof_frame = 0;
     return BP_OK;
 }
 int bp_layer_profile_reset(bp_layer_t* L) {

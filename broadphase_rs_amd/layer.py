@@ -77,7 +77,7 @@ EXPORTS = [
     "bp_layer_tree", "bp_layer_tree_device", "bp_layer_set_tree", "bp_layer_append_entries", "bp_layer_len",
     "bp_layer_is_sorted", "bp_layer_min_depth", "bp_layer_index_kind", "bp_layer_device",
     "bp_layer_scan_shard_device", "bp_layer_sort_unique_pairs_device", "bp_layer_stats",
-    "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
+    "bp_layer_profile_enable", "bp_layer_profile_select", "bp_layer_profile_sample", "bp_layer_profile_reset", "bp_layer_profile_get", "bp_version",
     "bp_layer_append_entries_assume", "bp_layer_cell_histogram", "bp_layer_partition_entries_device",
     "bp_layer_scan_raw_shard_device", "bp_layer_partition_pairs_device", "bp_layer_scan_shard_partition_device",
     "bp_layer_set_coarse_emit_range",
@@ -211,6 +211,7 @@ def load_library():
     L.bp_layer_wait_stream.argtypes = [vp, vp]
     L.bp_layer_stream.argtypes = [vp, C.POINTER(vp)]
     L.bp_layer_profile_select.argtypes = [vp, C.c_uint32]
+    L.bp_layer_profile_sample.argtypes = [vp, C.c_uint32]
     L.bp_layer_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
     for name in EXPORTS:
         if name not in ("bp_version", "bp_status_string", "bp_layer_last_error"):
@@ -749,6 +750,10 @@ class Layer:
         """restrict kernel timing to the named classes (None: all)"""
         mask = 0xFFFFFFFF if classes is None else sum(1 << KERNEL_CLASSES.index(c) for c in classes)
         self._check(self._L.bp_layer_profile_select(self._h, mask))
+
+    def profile_sample(self, every=1):
+        """time only every `every`-th frame (frames are counted by clear())"""
+        self._check(self._L.bp_layer_profile_sample(self._h, every))
 
     def profile_reset(self):
         self._check(self._L.bp_layer_profile_reset(self._h))

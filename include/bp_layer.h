@@ -346,6 +346,9 @@ int bp_layer_profile_enable(bp_layer_t *layer, int on);
 /* restrict the event pairs to the classes whose bit (1 << class) is set (default: all).  Every
  * event pair costs a few microseconds of stream bubble, so a timed run selects only what it reports */
 int bp_layer_profile_select(bp_layer_t *layer, uint32_t class_mask);
+/* time only every `every`-th frame (frames are counted by bp_layer_clear; 1 = every frame, the default): a timed run
+ * that reports one kernel's duration samples it instead of paying the bubbles in every frame */
+int bp_layer_profile_sample(bp_layer_t *layer, uint32_t every);
 int bp_layer_profile_reset(bp_layer_t *layer);
 /* total device milliseconds and number of launches accumulated for one class */
 int bp_layer_profile_get(bp_layer_t *layer, int kernel_class, double *total_ms, uint64_t *launches);
