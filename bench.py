@@ -287,6 +287,7 @@ def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_la
     rec = {"workload": "the same %d objects, every frame re-placed by a seeded jitter of +-0.5 x its size per axis (device-side, outside "
                        "the timed region); %d frames, each timed on its own (clear+extend+par_sort+par_scan)" % (n, frames),
            "frames": frames, "ms_per_step": sum(times) / len(times), "ms_min": min(times), "ms_max": max(times),
+           "ms_frames": [round(t, 4) for t in times],
            "pairs_mean": sum(pairs) / len(pairs), "value": sum(pairs) / (sum(times) * 1e-3), "unit": "pairs/s",
            "host_syncs_per_step": (st1["host_syncs"] - st0["host_syncs"]) / frames,
            "plan_events": {k: st1[k] - st0[k] for k in ("extend_reruns", "tree_plan_flips", "pair_plan_flips", "sort_repairs",

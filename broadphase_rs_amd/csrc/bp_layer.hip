@@ -218,7 +218,10 @@ struct DeviceGuard {
 // grow-only device buffer; preserve keeps the first keep_bytes bytes
 int ensure_dev(bp_layer* L, DevBuf& b, size_t bytes, size_t keep_bytes = 0) {
     if (bytes <= b.cap) return BP_OK;
-    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    // (1/16 of head room on top of the request: a scene whose sizes drift by a fraction of a percent from frame to frame -- a frame
+    // loop that moves its objects -- must not outgrow an exactly-sized first allocation one frame later: hipFree + hipMalloc of a
+    // gigabyte is 0.25 ms, seen as one slow frame in bench.py's moving record)
+    size_t want = std::max(bytes + bytes / 16, b.cap + b.cap / 2);
     want = (want + 255) / 256 * 256;
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, want);
