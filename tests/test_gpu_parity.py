@@ -595,6 +595,49 @@ def test_status_word_tags_wrap_around():
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("switch", ["", "BP_NO_PUBLISH", "BP_NO_EARLY_FETCH", "BP_NO_SORT_AHEAD", "BP_NO_CELL_SORT", "BP_NO_TREE_CELL_SORT",
+                                    "BP_NO_PREDICTED_EXTEND", "BP_NO_DEFERRED_SORT_CHECK"])
+def test_every_route_switch_of_the_frame_loop_gives_the_same_lists(switch):
+    """the per-frame fast path is a stack of routes, each with an environment switch that takes it out (read once per process,
+    hence the child process): six moving frames at 200 k objects -- enough for two digits of first ids, so the cell routes
+    apply once BP_RADIX_CLAIM_MIN_TILES=1 lets small inputs into the claiming passes -- with one switch set (or none: then the
+    counters must show that the routes were taken), tree and pair list against the oracle in every frame; the scalars arrive published in
+    pinned memory or by copy, the sort goes out ahead of the scan's sizes or after them, into cells or through the stable pass"""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, oracle, broadphase_rs_amd as bp\n"
+        "from broadphase_rs_amd import scenes\n"
+        "sysb, base, ids = scenes.gen_boxes(200000, seed=11)\n"
+        "size = base[:, 3:] - base[:, :3]; side = np.float32(sysb[1][0])\n"
+        "gpu = bp.Layer(bp.Index64_3D, 0)\n"
+        # (the pair sort's cells need a raw-pair buffer of n + n / 4 + 5.2 M slots: one larger frame first leaves the layer with it)
+        "sb1, b1, i1 = scenes.gen_boxes(1000000, seed=5); gpu.extend(sb1, b1, i1); assert len(gpu.par_scan()) > 0; gpu.clear(); gpu.reset_plan_hints()\n"
+        "for f in range(6):\n"
+        "    rng = np.random.default_rng(100 + f)\n"
+        "    mn = np.minimum(np.maximum(base[:, :3] + (rng.random((len(ids), 3), dtype=np.float32) - np.float32(0.5)) * size, 0), side - size).astype(np.float32)\n"
+        "    b = np.concatenate([mn, mn + size], axis=1).astype(np.float32)\n"
+        "    ref = oracle.OracleLayer(2, 0); gpu.clear(); gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)\n"
+        "    gpu.par_sort(); ref.sort()\n"
+        "    got = np.array(gpu.par_scan()); exp = ref.scan()\n"
+        "    assert got.shape == exp.shape and np.array_equal(got, exp), f\n"
+        "    gk, gi = gpu.tree(); rk, ri = ref.keys, ref.ids\n"
+        "    assert np.array_equal(gk, rk) and np.array_equal(gi, ri), f\n"
+        "st = gpu.stats()\n"
+        "print({k: st[k] for k in ('sorts_ahead', 'sorts_in_cells', 'tree_sorts_in_cells', 'host_syncs')})\n"
+        "import os\n"
+        "if os.environ.get('BP_TEST_EXPECT_ROUTES'):\n"   # no switch set: the frames did take the routes the switches remove
+        "    assert st['sorts_ahead'] >= 3 and st['sorts_in_cells'] >= 2 and st['tree_sorts_in_cells'] >= 1, st\n"
+        "print('ok')\n")
+    env = dict(os.environ, BP_RADIX_CLAIM_MIN_TILES="1")  # (the claiming passes and with them the cell routes start at ~2 M records by default)
+    if switch:
+        env[switch] = "1"
+    else:
+        env["BP_TEST_EXPECT_ROUTES"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+
+
 def _clustered_scene(n, n_cluster, seed, frac):
     """uniform scene whose first n_cluster objects are squeezed into a cube of `frac` of the system side"""
     sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
