@@ -1115,6 +1115,18 @@ __device__ __forceinline__ BinGeom bin_geom(const u64* __restrict__ bin_base, u3
 }
 __device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.head ? g.B + q : g.E - 1u - (q - g.head); }
 
+#ifndef RC_PREFETCH_LATE
+#define RC_PREFETCH_LATE 0          // 1: the next tile's keys are requested behind this tile's key stores instead of in front of them
+#endif
+#ifndef RC_OVERLAP
+#define RC_OVERLAP 1                // the prefetch behind the owners' claims, the holes' masks at the top of the tile: nothing waits for the prefetch before the next tile
+#endif
+#ifndef RC_DRAIN_CELLS
+#define RC_DRAIN_CELLS 1            // (CELLS: fetch's partial-tile path leaves loads pending into registers the store loop reuses)
+#endif
+#ifndef RC_DRAIN_BEFORE_STORES
+#define RC_DRAIN_BEFORE_STORES (!RC_OVERLAP)
+#endif
 #ifndef SW_EXP
 #define SW_EXP 0  // timing experiments (results are WRONG): 1 no key stores
 #endif
@@ -1168,8 +1180,13 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
 
     K key[ITEMS];
     u32 vmask = 0;  // bit r: record r of this lane exists
+    // RC_OVERLAP: the fills of the fetched tile's blocks stay in registers until the tile is processed (apply_holes): consumed inside
+    // fetch, behind the key loads, they cost a wait for everything in flight -- the prefetch would not overlap anything
+    u32 fill[WAVE_BLOCKS];
+    bool holes_pending = false;
     auto fetch = [&](u32 tile) {  // load the keys of a tile (the previous tile's are dead)
         vmask = 0;
+        holes_pending = false;
         if (tile >= n_tiles) return;
         const u32 wb = opaque(wbase);
         const size_t base = (size_t)tile * TILE;
@@ -1177,7 +1194,6 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         // block-structured input: the fills of the wave's blocks first (wave-uniform, and OLDER than the key loads, so that
         // waiting for them does not wait for the keys); the keys of a hole are read like any other slot (the slots exist)
         // and masked out afterwards
-        u32 fill[WAVE_BLOCKS];
         if (a.blockfill) {
             const size_t blk0 = (size_t)uniform_u32((u32)((base + (size_t)w * (64 * ITEMS)) / HOLE_BLOCK));
             const size_t n_blk = (n + HOLE_BLOCK - 1) / HOLE_BLOCK;
@@ -1198,12 +1214,22 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             }
         }
         if (a.blockfill) {
+            if (RC_OVERLAP) { holes_pending = true; return; }
             const u32 in_block = wb & (HOLE_BLOCK - 1u);  // (wb + r * 64) % HOLE_BLOCK = in_block + (r * 64) % HOLE_BLOCK
             u32 keep = 0;
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) keep |= (in_block + (u32)((r * 64) % (int)HOLE_BLOCK)) < fill[r * 64 / (int)HOLE_BLOCK] ? (1u << r) : 0u;
             vmask &= keep;
         }
+    };
+    auto apply_holes = [&]() {  // (workgroup-uniform condition)
+        if (!holes_pending) return;
+        holes_pending = false;
+        const u32 in_block = opaque(wbase) & (HOLE_BLOCK - 1u);
+        u32 keep = 0;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) keep |= (in_block + (u32)((r * 64) % (int)HOLE_BLOCK)) < fill[r * 64 / (int)HOLE_BLOCK] ? (1u << r) : 0u;
+        vmask &= keep;
     };
     // CELLS: a workgroup takes a CONTIGUOUS range of tiles (it stays inside a high bin for as long as possible: its carry
     // is flushed whenever it leaves one); otherwise the tiles are dealt round robin
@@ -1255,6 +1281,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
 
     u32 it = 0;
     for (; tile < tile_end; tile += tile_step) {
+      if (RC_OVERLAP) apply_holes();
       // CELLS: the tile's records are sorted by the high digit: one sub-pass per high bin it touches (all but ~1 % of the
       // tiles lie inside one)
       u32 hb_lo = 0, hb_hi = 0;
@@ -1379,7 +1406,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             }
         }
         // the next tile's keys: in flight under this tile's stores (CELLS: the keys are still needed by the tile's next sub-pass)
-        if (last_sub) fetch_next(tile + tile_step);
+        if (!RC_OVERLAP && RC_PREFETCH_LATE == 0 && last_sub) fetch_next(tile + tile_step);
 
         // ---- the claimed lines' positions --------------------------------------------------------------------------
         bool over = false;  // owner: its claim reaches beyond the bin's interior (at most one line per bin and launch)
@@ -1389,6 +1416,10 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             if (over) s_over = 1u;
             if (CELLS && over) *a.miss = 1u;  // the cell was laid out too small: the lines beyond it are dropped
         }
+        // RC_OVERLAP: the prefetch goes out BEHIND the owners' wait for their claims (a returning atomic, older than these loads: the
+        // compiler cannot count across fetch's branches and waits for everything in flight, the prefetch included -- and the barrier
+        // below then holds every other wave for it as well)
+        if (RC_OVERLAP && RC_PREFETCH_LATE == 0 && last_sub) fetch_next(tile + tile_step);
         __syncthreads();
 
         // ---- stream the lines out: 8 consecutive threads write one aligned 128-byte line, TWO records (16 bytes) per thread --
@@ -1397,6 +1428,11 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         // instructions.  (A line starts at an even stage slot and at a 128-byte aligned address: both halves of the pair
         // belong to one bin and the 16-byte store is aligned.)
         const bool any_over = s_over != 0u;
+        // Every iteration of the store loop is conditional, so the compiler cannot know inside one that an earlier one has waited for
+        // the loads still in flight (the owners' claims, the prefetch) and waits AGAIN in each -- s_waitcnt vmcnt(0), which also waits
+        // for the stores issued so far: the six stores of a thread left one round trip apart.  One unconditional wait in front of the
+        // loop (what the first iteration did anyway) tells it that nothing is pending: the stores go out back to back.
+        if (RC_DRAIN_BEFORE_STORES || (CELLS && RC_DRAIN_CELLS)) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         u32 odg[HAS_VAL ? (RC_OUT_ITERS + 3) / 4 : 1];  // the written pairs' digits, one byte each (payload phase)
         const u32 otid = opaque((u32)tid);
 #pragma unroll
@@ -1424,6 +1460,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             over_q = atomicAdd(a.frag_cur + sw_cursor_slot((u32)tid), cnt);
             for (u32 i = 0; i < cnt; ++i) keys_out[frag_pos(g, over_q + i)] = s_stage[over_at + i];
         }
+        if (RC_PREFETCH_LATE == 1 && last_sub) fetch_next(tile + tile_step);
         if constexpr (CELLS) load_vals();
         // what stays: back into the carry slots
 #pragma unroll

@@ -45,6 +45,7 @@ struct bp_layer {
     // Published): [0, PUB_FLAGS_OFF) the data, then the flag word; pub_seq numbers the launches
     void* pub = nullptr;
     uint32_t pub_seq = 0;
+    size_t pairs_want_slots = 0;       // raw-pair buffer size the cell route of the pair sort asked for (scan_fused_device)
 
     // persistent state: tree (src/layer.rs:49-50)
     DevBuf keys[2], ids[2];
@@ -221,7 +222,8 @@ int ensure_dev(bp_layer* L, DevBuf& b, size_t bytes, size_t keep_bytes = 0) {
     // (1/16 of head room on top of the request: a scene whose sizes drift by a fraction of a percent from frame to frame -- a frame
     // loop that moves its objects -- must not outgrow an exactly-sized first allocation one frame later: hipFree + hipMalloc of a
     // gigabyte is 0.25 ms, seen as one slow frame in bench.py's moving record)
-    size_t want = std::max(bytes + bytes / 16, b.cap + b.cap / 2);
+    static const bool exact = getenv("BP_ALLOC_EXACT") != nullptr;  // A/B switch: no head room
+    size_t want = std::max(exact ? bytes : bytes + bytes / 16, b.cap + b.cap / 2);
     want = (want + 255) / 256 * 256;
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, want);
@@ -1314,6 +1316,11 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
         L->ahead.n_raw = n; L->ahead.extent = L->raw_extent; L->ahead.m = L->m;
         L->ahead.n_groups = n_groups; L->ahead.first_lo = first_range[0]; L->ahead.first_hi = first_range[1];
         L->ahead.varying = varying; L->ahead.plan = plan;
+        // (should the sort that goes out ahead take the cell route, the scan's buffer must hold the gapped layout: scan_fused_device)
+        const size_t nb = n + n / 8 + 4096;
+        if (plan.n_passes == 2 && !plan.from_val[0] && !plan.from_val[1] && plan.shift[0] == 40 && plan.shift[1] == 48 && (first_range[1] >> 24) == 0 &&
+            radix_claim_applies(std::max(L->raw_extent + L->raw_extent / 8, nb)))
+            L->pairs_want_slots = std::max(L->pairs_want_slots, cell_layout_capacity(nb) + cell_layout_capacity(nb) / 16);
     }
     return BP_OK;
 }
@@ -1578,6 +1585,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         BP_TRY(ensure_dev(L, L->big_list, big_cap * 2 * sizeof(uint64_t)));  // (two words per item)
     }
     size_t cap = std::max<size_t>(L->pairs[0].cap / sizeof(uint64_t), 6 * L->m);
+    cap = std::max(cap, L->pairs_want_slots);  // (what the previous frame's cell route would have needed: below)
     for (int attempt = 0; attempt < 4; ++attempt) {
         BP_TRY(ensure_dev(L, L->pairs[0], cap * sizeof(uint64_t)));
         cap = L->pairs[0].cap / sizeof(uint64_t);
@@ -1632,9 +1640,17 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 // a claiming and a stable pass + the search for the group bounds.  A cell that outgrows its range is a miss.
                 static const bool no_cells = getenv("BP_NO_CELL_SORT") != nullptr;  // A/B switch for measurements
                 if (L->cell_off) --L->cell_off;
-                const bool cell_route = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
-                                        h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 &&
-                                        radix_claim_applies(extent_bound) && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
+                const bool cells_apply = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
+                                         h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 && radix_claim_applies(extent_bound);
+                const bool cell_route = cells_apply && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
+                // the gapped layout needs n + n / 4 + 80 slots per cell: more than the raw stream's buffer holds when the scene is small
+                // (5.2 M slots for the 65536 cells alone).  The NEXT frame's buffer is sized for it (one reallocation, 42 MB at most
+                // beyond what the pairs need) -- before, a small scene took this route or not depending on how its buffer had grown
+                if (cells_apply && !cell_route) L->pairs_want_slots = cell_layout_capacity(n_bound) + cell_layout_capacity(n_bound) / 16;
+                if (getenv("BP_DEBUG_AHEAD"))
+                    fprintf(stderr, "sort ahead: cells %d (off %u, passes %d shifts %d %d, first_hi %x, claim %d, capacity %zu <= %zu) n_bound %zu extent_bound %zu\n",
+                            (int)cell_route, L->cell_off, h.plan.n_passes, h.plan.shift[0], h.plan.shift[1], h.first_hi, (int)radix_claim_applies(extent_bound),
+                            cell_layout_capacity(n_bound), out_blocks * SX_BLOCK, n_bound, extent_bound);
                 CellRoute cr{};
                 if (cell_route) {
                     const bool fresh = L->cell_ws.p == nullptr;

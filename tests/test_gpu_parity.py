@@ -610,8 +610,6 @@ def test_every_route_switch_of_the_frame_loop_gives_the_same_lists(switch):
         "sysb, base, ids = scenes.gen_boxes(200000, seed=11)\n"
         "size = base[:, 3:] - base[:, :3]; side = np.float32(sysb[1][0])\n"
         "gpu = bp.Layer(bp.Index64_3D, 0)\n"
-        # (the pair sort's cells need a raw-pair buffer of n + n / 4 + 5.2 M slots: one larger frame first leaves the layer with it)
-        "sb1, b1, i1 = scenes.gen_boxes(1000000, seed=5); gpu.extend(sb1, b1, i1); assert len(gpu.par_scan()) > 0; gpu.clear(); gpu.reset_plan_hints()\n"
         "for f in range(6):\n"
         "    rng = np.random.default_rng(100 + f)\n"
         "    mn = np.minimum(np.maximum(base[:, :3] + (rng.random((len(ids), 3), dtype=np.float32) - np.float32(0.5)) * size, 0), side - size).astype(np.float32)\n"
