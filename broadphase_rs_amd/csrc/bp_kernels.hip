@@ -2217,6 +2217,9 @@ template <int KIND> __device__ __forceinline__ u64 cell_upper(u64 key) {
 // independent cursors (shard s owns blocks s, s + SX_SHARDS, ...), so the atomics spread over 64
 // addresses.  Only a wave's last block is partial (blockfill says how much of it exists) and the
 // shards end a few blocks apart; the first pass of the pair sort reads around those holes.
+#ifndef SX_STATS_IN_VGPR
+#define SX_STATS_IN_VGPR 1
+#endif
 struct WaveStage {
     u64* buf;      // LDS, SX_STAGE slots
     u32 wp;        // pairs staged and not yet written: < SX_BLOCK between pushes (wave-uniform)
@@ -2285,6 +2288,7 @@ struct WaveStage {
         write_block<OWNER>(p, SX_BLOCK);
         const u32 over = wp - SX_BLOCK;  // wave-uniform
         total += SX_BLOCK;
+        if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(total));
         wp = over;
         if (over) {
             const u32 l = (u32)lane_id();
@@ -2394,36 +2398,38 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     // a chunk's global loads (clamped addresses: every load is unconditional, validity is decided at use)
     struct Pre { u64 k0, k1, w0, w1; };
-    auto prefetch = [&](size_t base) -> Pre {
+    // (m < 2^32 - 1, checked by the host: the chunk loop's state is 32-bit -- scalar registers are what this kernel runs out of)
+    auto prefetch = [&](u32 base) -> Pre {
         Pre r;
-        if (base + SX_WIN <= p.m) {  // wave-uniform: every chunk but the last one or two -- no clamping, scalar base + lane offset
+        if (m - base >= SX_WIN) {  // wave-uniform: every chunk but the last one or two -- no clamping, scalar base + lane offset
             const u64* __restrict__ k = p.keys + base;
             const u64* __restrict__ c = p.idctx + base;
             r.k0 = k[lane]; r.k1 = k[64 + lane]; r.w0 = c[lane]; r.w1 = c[64 + lane];
         } else {
-            const size_t last = p.m - 1;
-            const size_t a = base + (size_t)lane, b = a + 64;
-            r.k0 = p.keys[a < last ? a : last];
-            r.k1 = p.keys[b < last ? b : last];
-            r.w0 = p.idctx[a < last ? a : last];
-            r.w1 = p.idctx[b < last ? b : last];
+            const u32 last = m - 1u;
+            const u32 a = min(base + (u32)lane, last), b = min(base + 64u + (u32)lane, last);  // (clamped: lanes beyond the tree are masked at use)
+            r.k0 = p.keys[a];
+            r.k1 = p.keys[b];
+            r.w0 = p.idctx[a];
+            r.w1 = p.idctx[b];
         }
         return r;
     };
-    size_t base = (size_t)gw * 64;
+    u32 base = gw * 64u;
+    const u32 chunk_step = (u32)p.n_waves * 64u;
 #ifdef SX_STAMPS
     u64 sx_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const u64 sx_begin = __builtin_readcyclecounter();
 #endif
     Pre cur_pre{};
-    if (base < p.m) cur_pre = prefetch(base);
-    for (; base < p.m; base += (size_t)p.n_waves * 64) {  // wave-uniform
+    if (base < m) cur_pre = prefetch(base);
+    for (bool more = base < m; more; base += chunk_step) {  // wave-uniform (the last increment may wrap: `more` alone decides)
         SX_T(t0);
         const Pre pre = cur_pre;
-        const size_t nbase = base + (size_t)p.n_waves * 64;
-        if (nbase < p.m) cur_pre = prefetch(nbase);  // the NEXT chunk's loads fly while this chunk is processed
-        const u32 j = (u32)base + (u32)lane;
-        const bool in0 = (size_t)j < p.m, in1 = (size_t)j + 64u < p.m;
+        more = m - base > chunk_step;  // (base < m)
+        if (more) cur_pre = prefetch(base + chunk_step);  // the NEXT chunk's loads fly while this chunk is processed
+        const u32 j = base + (u32)lane;
+        const bool in0 = j < m, in1 = in0 && m - j > 64u;
         const u64 key = in0 ? pre.k0 : ~0ull;
         win[lane] = key;
         win[64 + lane] = in1 ? pre.k1 : ~0ull;
@@ -2455,7 +2461,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         // Ranges that leave the window (rare on a uniform scene, one in most chunks of a mixed-scale one): their end is somewhere
         // in HBM.  Up to four are searched by the whole wave, one after the other (~5 memory round trips each; the owner's key is
         // still in the key window); more: every lane for itself (~40 dependent loads each, but all lanes at once).
-        if ((u64)base + SX_WIN >= p.m) {  // (wave-uniform) the window reaches the end of the tree
+        if (m - base <= SX_WIN) {  // (wave-uniform) the window reaches the end of the tree
             if (in0 && end == (u32)base + SX_WIN) end = m;
         } else {
             u64 fm = ballot64(in0 && end == (u32)base + SX_WIN);
@@ -2501,6 +2507,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
         // popcount and one 16-byte LDS read per lane -- no per-candidate search.
         st.examined += total;
+        if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(st.examined));  // (a statistic: not worth two of the scalar registers this kernel spills)
         // record: {first candidate - lane - 1 (so that a candidate's entry offset is k - x), id, DJ, CBJ}
         if (c > 0)
             s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
