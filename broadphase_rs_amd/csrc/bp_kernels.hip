@@ -1121,8 +1121,14 @@ __device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.
 #ifndef RC_OVERLAP
 #define RC_OVERLAP 1                // the prefetch behind the owners' claims, the holes' masks at the top of the tile: nothing waits for the prefetch before the next tile
 #endif
+#ifndef RC_WAIT_BEFORE_PREFETCH
+#define RC_WAIT_BEFORE_PREFETCH 1
+#endif
+#ifndef RC_CELLS_VALS_EARLY
+#define RC_CELLS_VALS_EARLY 0          // (1: the CELLS pass requests its payload in front of the key stores; measured equal)
+#endif
 #ifndef RC_DRAIN_CELLS
-#define RC_DRAIN_CELLS 1            // (CELLS: fetch's partial-tile path leaves loads pending into registers the store loop reuses)
+#define RC_DRAIN_CELLS 0            // (CELLS: fetch's partial-tile path leaves loads pending into registers the store loop reuses)
 #endif
 #ifndef RC_DRAIN_BEFORE_STORES
 #define RC_DRAIN_BEFORE_STORES (!RC_OVERLAP)
@@ -1419,6 +1425,10 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         // RC_OVERLAP: the prefetch goes out BEHIND the owners' wait for their claims (a returning atomic, older than these loads: the
         // compiler cannot count across fetch's branches and waits for everything in flight, the prefetch included -- and the barrier
         // below then holds every other wave for it as well)
+        // (the claim is issued in one conditional block and read in another: for the compiler a path exists on which it is still in
+        // flight, and it would wait wherever the store loop reuses the register -- one wait HERE, where only the claims can be
+        // outstanding and their owners have just waited for them, says that nothing is)
+        if (RC_OVERLAP && RC_WAIT_BEFORE_PREFETCH) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (RC_OVERLAP && RC_PREFETCH_LATE == 0 && last_sub) fetch_next(tile + tile_step);
         __syncthreads();
 
@@ -1433,6 +1443,9 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
         // for the stores issued so far: the six stores of a thread left one round trip apart.  One unconditional wait in front of the
         // loop (what the first iteration did anyway) tells it that nothing is pending: the stores go out back to back.
         if (RC_DRAIN_BEFORE_STORES || (CELLS && RC_DRAIN_CELLS)) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        // (CELLS: the payload is requested here, in front of the key stores -- the keys have left the registers it takes; behind the
+        // stores its round trip stood between them and the payload's own stores)
+        if constexpr (CELLS && RC_CELLS_VALS_EARLY) load_vals();
         u32 odg[HAS_VAL ? (RC_OUT_ITERS + 3) / 4 : 1];  // the written pairs' digits, one byte each (payload phase)
         const u32 otid = opaque((u32)tid);
 #pragma unroll
@@ -1461,7 +1474,7 @@ __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
             for (u32 i = 0; i < cnt; ++i) keys_out[frag_pos(g, over_q + i)] = s_stage[over_at + i];
         }
         if (RC_PREFETCH_LATE == 1 && last_sub) fetch_next(tile + tile_step);
-        if constexpr (CELLS) load_vals();
+        if constexpr (CELLS && !RC_CELLS_VALS_EARLY) load_vals();
         // what stays: back into the carry slots
 #pragma unroll
         for (int slot = tid; slot < RS_BINS * RC_LINE; slot += T) {
