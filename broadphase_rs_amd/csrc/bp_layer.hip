@@ -42,7 +42,7 @@ struct bp_layer {
     hipEvent_t fence_ev = nullptr;   // bp_layer_wait_stream: orders this layer's stream after a producer's
     hipEvent_t early_ev = nullptr;   // extend on predicted sizes: the scalars' copy, waited for while encode_emit already runs
     // results the host waits for in the per-frame path arrive in pinned host memory, written by the kernels themselves (struct
-    // Published): [0, PUB_FLAGS_OFF) the data, then the flag word; pub_seq numbers the launches
+    // Published): [0, PUB_FLAG_OFF) the data, then the flag word; pub_seq numbers the launches
     void* pub = nullptr;
     uint32_t pub_seq = 0;
     size_t pairs_want_slots = 0;       // raw-pair buffer size the cell route of the pair sort asked for (scan_fused_device)
