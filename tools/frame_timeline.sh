@@ -25,7 +25,7 @@ prev_end = None
 for s, e, n in fr[:-1]:
     gap = (s - prev_end) / 1e3 if prev_end else 0.0
     busy += (e - s)
-    short = n.split("(")[0].replace("void bp::(anonymous namespace)::", "").replace("void bp::", "")[:60]
+    short = n.replace("void ", "").replace("bp::(anonymous namespace)::", "").replace("bp::", "").split("(")[0][:60]
     print("  gap %6.1f  run %6.1f  %s" % (gap, (e - s) / 1e3, short))
     prev_end = max(prev_end or 0, e)
 print("  gap %6.1f  (to the next frame's first kernel)" % ((rows[b][0] - prev_end) / 1e3))
