@@ -80,6 +80,45 @@ struct SysBounds {
     float mx[3];
 };
 
+// ---- compact tree records (round 4) ---------------------------------------------------------------------------------------
+// Where an entry's index value, its id and its 5-bit box code fit ONE 64-bit word, the per-frame path moves the tree through
+// encode -> radix passes -> finish as such words instead of (u64 index, u32 id) pairs: 8 bytes per record and pass instead of 12.
+//   word = (prefix << tbits | tail) << low | id << 5 | code                                     (low = idbits + 5)
+//   prefix = index >> pshift: the Morton bits of the levels 1 .. dmin (dmin = the shallowest depth present; pshift = DEPTH_BITS +
+//            DIM * (AXIS_BITS - dmin)) -- every entry has all of them;
+//   tail   = the levels dmin + 1 .. dmax as a number of T = dmax - dmin digits in base 2^DIM + 1: digit k = 1 + the entry's
+//            octant (quadrant) at level dmin + k while that level is at most the entry's depth, 0 ("the cell ends here") below
+//            it.  This is the pre-order of the tree written as a number: a cell comes before the cells it contains, which come
+//            in Morton order -- exactly the order of the index values (Morton bits above the depth field, src/index.rs:72-78),
+//            with no separate depth field and no bits for levels an entry does not have (at 10 M objects, depths 7 .. 11: 34
+//            bits where Morton bits + depth take 36 -- the difference between fitting 64 bits and not).
+// The id sits above the code, so the unsigned order of the words is the (index, id) order of the entries (src/layer.rs:149).
+struct TreeCompact {
+    int pshift, tbits, T, low, idbits;
+    uint32_t dmin, dmax;
+};
+// the format for depths dmin .. dmax and ids below 2^idbits; false: does not fit 64 bits
+inline bool tree_compact_format(int kind, uint32_t dmin, uint32_t dmax, int idbits, TreeCompact* f) {
+    const KindInfo ki = kind_info(kind);
+    if (dmax > ki.axis_bits || dmin > dmax || idbits < 1 || idbits > 27) return false;
+    const int T = (int)(dmax - dmin);
+    const unsigned long long base = (1ull << ki.dim) + 1ull;
+    unsigned long long span = 1;  // base^T
+    for (int k = 0; k < T; ++k) {
+        span *= base;
+        if (span > 0xFFFFFFFFull) return false;  // (the kernels handle the tail as a 32-bit number: at most 10 levels in 3-D, 13 in 2-D)
+    }
+    int tbits = 0;
+    while ((1ull << tbits) < span) ++tbits;
+    const int total = (int)(ki.dim * dmin) + tbits + idbits + 5;
+    if (total > 64) return false;
+    f->pshift = (int)(ki.depth_bits + ki.dim * (ki.axis_bits - dmin));
+    f->tbits = tbits; f->T = T; f->low = idbits + 5; f->idbits = idbits; f->dmin = dmin; f->dmax = dmax;
+    return true;
+}
+// composites (n of them, in place over `words`) -> index values in words[], id | packed box code << BOX_ID_BITS in ids_out[]
+hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, size_t n, const TreeCompact& fmt, hipStream_t stream);
+
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
@@ -102,7 +141,9 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
                               unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0, DevScalars* sc_guard = nullptr,
-                              size_t capacity = 0);
+                              size_t capacity = 0, const TreeCompact* compact = nullptr);
+// compact (with pack_box, no cell_hist): keys_out receives one composite word per entry (TreeCompact) and nothing else is
+// written; hist_plan's shifts then refer to the composite
 // sc_guard / capacity: launched straight behind launch_scan_block_sums, without the host having read the entry total: if
 // sc_guard->total exceeds `capacity` entries the kernel writes nothing and sets KERR_ENCODE_OVERFLOW in sc_guard->err
 // cell_hist / cell_depth: also count the entries per cell at cell_depth (multi-GPU splitter selection) into
@@ -403,6 +444,12 @@ hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in,
 // cells: keys_in / ids_in are the gapped result of a cell sort (CellRoute::out_keys / out_vals) and the bounds came from
 // launch_cell_count; only where tgroup_composite_applies(gshift, distinct_id_bits) (the composite-key kernel reads gapped input)
 bool tgroup_composite_applies(int gshift, int distinct_id_bits);
+// the same finish for a cell sort of COMPOSITE words (TreeCompact; comp_gshift: the group shift in the composite): reads the gapped
+// words, orders every group by plain unsigned compare and writes index values, ids, box bytes and context words
+bool tgroup_compact_applies(int comp_gshift);  // the composite's group shift leaves room for the finish kernel's bin digit
+hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_groups, int comp_gshift, const TreeCompact& fmt, uint64_t* keys_out,
+                                        uint32_t* ids_out, uint8_t* box_out, DevScalars* sc, hipStream_t stream, int ctx_kind, uint64_t* idctx_out,
+                                        const uint32_t* stats, uint32_t abort_over, const struct CellRoute& cells);
 // distinct_id_bits > 0 (with payload_packed): the caller vouches that the ids are DISTINCT and below 2^distinct_id_bits; where
 // the rest of the key and the id fit one 64-bit word the composite-key kernel runs (a group above the capacity then sets
 // KERR_SEGMENT_TOO_LONG instead of taking the multi-round path)

@@ -264,14 +264,16 @@ template <int DIM> __device__ __forceinline__ u64 dilated_next(u64 m, u32 up) {
     return ((m | ~LANE) + (1ull << (DIM * up))) & LANE;
 }
 
-template <int KIND, bool CELLS>
+// COMPACT (with pack_box): one composite word per entry goes to keys_out (TreeCompact: index bits that vary | id | box code) and
+// nothing to ids_out / box_out; the digits counted are the composite's
+template <int KIND, bool CELLS, bool COMPACT = false>
 __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
                                                                  const uint4* __restrict__ recs,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                  uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
-                                                                 DevScalars* sc_guard, u64 capacity) {
+                                                                 DevScalars* sc_guard, u64 capacity, TreeCompact fmt) {
     // pack_box: the box code rides in bits 27..31 of the id from the start (ids < 2^27, see BOX_ID_BITS) and
     // no box byte is written: the first pass of the tree sort then has no byte stream to gather
     // sc_guard / capacity (launch without a host round trip after the count pass): sc_guard->total is the entry total the
@@ -303,8 +305,35 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     // A round's entries (<= 8 per object unless min_depth forces more) are staged in LDS in output order and
     // stored with consecutive threads on consecutive entries; a round that does not fit stores directly.
     __shared__ u64 s_key[ENC_STAGE];
-    __shared__ u32 s_id[ENC_STAGE];
-    __shared__ uint8_t s_box[ENC_STAGE];
+    __shared__ u32 s_id[COMPACT ? 1 : ENC_STAGE];
+    __shared__ uint8_t s_box[COMPACT ? 1 : ENC_STAGE];
+    // COMPACT: index value -> composite word (TreeCompact): the Morton bits of the levels every entry has, the deeper levels as
+    // digits 1 + octant in base 2^DIM + 1 (0 below the entry's own depth), then id and code.  tail = sum over the levels the entry
+    // has of (1 + octant) BASE^(T - k) = sum over ALL tail levels of octant BASE^(T - k) (the index value has zeros below its
+    // depth) + (BASE^T - BASE^(T - nlev)) / (BASE - 1): two instructions per level and one table read per object
+    constexpr u32 CBASE = (1u << DIM) + 1u;
+    __shared__ u32 s_pow[COMPACT ? 16 : 1];
+    if (COMPACT) {
+        if (threadIdx.x == 0) {
+            u32 pw = 1;
+            for (int k = 0; k <= fmt.T && k < 16; ++k) { s_pow[k] = pw; pw *= CBASE; }
+        }
+        // (visible after the barriers of the first round's block scan)
+    }
+    const int c_tsh = fmt.pshift - (int)DIM * fmt.T;  // the tail levels' Morton bits start here in the index value
+    // depth term of the tail for an entry of depth `depth` (>= dmin: the host checks the frame's depths against the format)
+    auto comp_depth_term = [&](u32 depth) -> u32 {
+        const u32 nlev = min(depth - fmt.dmin, (u32)fmt.T);
+        return (s_pow[fmt.T] - s_pow[(u32)fmt.T - nlev]) >> DIM;
+    };
+    auto comp_of = [&](u64 key, u32 dterm, u32 idcode) -> u64 {
+        const u64 kk = key >> c_tsh;                           // [prefix | Morton bits of the tail levels]
+        const u32 lv = (u32)kk;                                // (DIM * T <= 30 bits of it are the tail's)
+        u32 tail = 0;
+        for (int k = 1; k <= fmt.T; ++k)                       // (wave-uniform trip count)
+            tail = tail * CBASE + ((lv >> ((int)DIM * (fmt.T - k))) & ((1u << DIM) - 1u));
+        return (((kk >> ((int)DIM * fmt.T)) << fmt.tbits | (u64)(tail + dterm)) << fmt.low) | (u64)idcode;
+    };
     size_t round_base = (size_t)block_offs[blockIdx.x];
     for (int round = 0; round < ENC_ROUNDS; ++round) {
         const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
@@ -318,7 +347,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         round_base += total;
         const bool staged = total <= (u32)ENC_STAGE;  // workgroup-uniform
         auto put = [&](u32 local, u64 key, u32 idv, u32 code) {
-            if (staged) {
+            if (COMPACT) {  // (key is the composite already)
+                if (staged) s_key[local] = key; else keys_out[this_base + local] = key;
+            } else if (staged) {
                 s_key[local] = key;
                 s_id[local] = idv;
                 s_box[local] = (uint8_t)code;
@@ -334,8 +365,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             if (rec.w & ENC_REC_OK) {
                 const u32 depth = rec.w & 0xFFu;
                 if (depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
-                    put(local, 0ull, id, 0u);  // box code 0 packs to 0
-                    count_digits(0ull);
+                    const u64 k0 = COMPACT ? comp_of(0ull, comp_depth_term(0u), id << 5) : 0ull;
+                    put(local, k0, id, 0u);  // box code 0 packs to 0
+                    count_digits(k0);
                 } else {
                     // at most two cells per axis: both Morton lanes of every axis once per object (the second from the first by
                     // a dilated increment), an entry is then two ORs; cells in z outer, y, x inner order: src/geom.rs:271-297
@@ -353,6 +385,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                     }
                     // box code of the first cell (ternary, the form that rides in the id) and what a step on each axis adds
                     const u32 t0 = s0 + 3u * s1 + 9u * s2, idp = pack_box ? id : 0u;
+                    if (COMPACT) {
+                        const u32 dterm = comp_depth_term(depth), idc0 = (id << 5) | t0;
+                        for (u32 e = 0; e < cnt; ++e) {
+                            const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
+                            const u64 key = key0 ^ (x ? dx : 0ull) ^ (y ? dy : 0ull) ^ (z ? dz : 0ull);
+                            const u64 comp = comp_of(key, dterm, idc0 + x + 3u * y + 9u * z);
+                            if (staged) s_key[local] = comp; else keys_out[this_base + local] = comp;
+                            count_digits(comp);
+                            ++local;
+                        }
+                    } else
                     for (u32 e = 0; e < cnt; ++e) {
                         const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
                         const u64 key = key0 ^ (x ? dx : 0ull) ^ (y ? dy : 0ull) ^ (z ? dz : 0ull);
@@ -372,7 +415,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 for (u32 z = 0; z < c.n[2]; ++z)
                     for (u32 y = 0; y < c.n[1]; ++y)
                         for (u32 x = 0; x < c.n[0]; ++x) {
-                            const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
+                            u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
+                            if (COMPACT) key = comp_of(key, comp_depth_term(c.depth), (id << 5) | (u32)BOX_PACKED_UNKNOWN);
                             put(local, key, pack_box ? (id | (box_to_packed((u32)BOX_UNKNOWN) << BOX_ID_BITS)) : id, (u32)BOX_UNKNOWN);
                             count_digits(key);
                             ++local;
@@ -383,8 +427,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             __syncthreads();
             for (u32 k = threadIdx.x; k < total; k += ENC_THREADS) {
                 keys_out[this_base + k] = s_key[k];
-                ids_out[this_base + k] = s_id[k];
-                if (box_out) box_out[this_base + k] = s_box[k];
+                if (!COMPACT) {
+                    ids_out[this_base + k] = s_id[k];
+                    if (box_out) box_out[this_base + k] = s_box[k];
+                }
             }
             __syncthreads();  // the stage is reused by the next round
         }
@@ -3275,6 +3321,179 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
     }
 }
 
+// ---- compact tree records (TreeCompact, bp_kernels.h) ---------------------------------------------------------------------
+// composite -> index value, id, packed box code.  The tail's digits are taken three at a time through a table of BASE^3 entries
+// (lut3: bits 0 .. 3 DIM - 1 = the three levels' Morton bits, bits 12 .. 13 = how many of the digits are levels the entry has);
+// lut3 == nullptr: digit by digit
+template <int DIM> struct CompactLut3 {
+    static constexpr u32 BASE = (1u << DIM) + 1u, N = BASE * BASE * BASE, WORDS = (N + 1u) / 2u;
+    unsigned short e[WORDS * 2];
+};
+template <int DIM> constexpr CompactLut3<DIM> make_compact_lut3() {
+    CompactLut3<DIM> l{};
+    constexpr u32 BASE = CompactLut3<DIM>::BASE;
+    for (u32 v = 0; v < CompactLut3<DIM>::N; ++v) {
+        const u32 d0 = v / (BASE * BASE), d1 = (v / BASE) % BASE, d2 = v % BASE;  // most significant digit = the shallowest level
+        const u32 m = ((d0 ? d0 - 1u : 0u) << (2 * DIM)) | ((d1 ? d1 - 1u : 0u) << DIM) | (d2 ? d2 - 1u : 0u);
+        l.e[v] = (unsigned short)(m | (((d0 ? 1u : 0u) + (d1 ? 1u : 0u) + (d2 ? 1u : 0u)) << 12));
+    }
+    return l;
+}
+__constant__ CompactLut3<3> g_compact_lut3_3d = make_compact_lut3<3>();
+__constant__ CompactLut3<2> g_compact_lut3_2d = make_compact_lut3<2>();
+template <int KIND> __device__ __forceinline__ void tree_expand(u64 comp, const TreeCompact& f, u64& key, u32& id, u32& c27,
+                                                                const unsigned short* lut3 = nullptr) {
+    constexpr u32 DIM = KT<KIND>::DIM, BASE = (1u << DIM) + 1u;
+    const u64 kp = comp >> f.low;
+    u32 t = (u32)kp & (u32)((1ull << f.tbits) - 1ull);  // (tbits <= 32: the host limits T so that the tail is a 32-bit number -- see launchers)
+    u64 mort = 0;   // Morton bits of the levels dmin + 1 .. dmax, level dmax lowest
+    u32 nlev = 0;
+    if (lut3) {
+        constexpr u32 N3 = BASE * BASE * BASE;
+        // three levels per table read, deepest first; the usual tail (T <= 6) is two reads and one division
+        u32 q = t / N3;
+        const u32 e0 = lut3[t - q * N3];
+        u32 m32 = e0 & 0xFFFu;
+        nlev = e0 >> 12;
+        if (f.T > 3) {  // (wave-uniform)
+            const u32 r1 = f.T > 6 ? q % N3 : q;
+            const u32 e1 = lut3[r1];
+            m32 |= (e1 & 0xFFFu) << (3 * DIM);
+            nlev += e1 >> 12;
+            mort = m32;
+            if (f.T > 6) {
+                q /= N3;
+                for (int sh = 6 * (int)DIM, left = f.T - 6; left > 0; left -= 3, sh += 3 * (int)DIM) {
+                    const u32 q2 = q / N3, e = lut3[q - q2 * N3];
+                    mort |= (u64)(e & 0xFFFu) << sh;
+                    nlev += e >> 12;
+                    q = q2;
+                }
+            }
+        } else {
+            mort = m32;
+        }
+    } else {
+        for (int k = 0; k < f.T; ++k) {
+            const u32 q = t / BASE, d = t - q * BASE;
+            if (d) { mort |= (u64)(d - 1u) << (DIM * k); ++nlev; }
+            t = q;
+        }
+    }
+    const u32 depth = f.dmin + nlev;
+    key = ((kp >> f.tbits) << f.pshift) | (mort << (f.pshift - (int)DIM * f.T)) | (u64)depth;
+    id = (u32)(comp >> 5) & ((1u << f.idbits) - 1u);
+    c27 = (u32)comp & 31u;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ words, u32* __restrict__ ids_out, size_t n, TreeCompact f) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u64 key; u32 id, c27;
+        tree_expand<KIND>(words[i], f, key, id, c27);
+        words[i] = key;
+        ids_out[i] = id | (c27 << BOX_ID_BITS);
+    }
+}
+// Grouped finish of a cell sort of composite words: tgroup_finish2_kernel<.., GAPPED> with ONE word per record -- one load per
+// entry, the bin and the rank straight from the word (inside a group the bits above comp_gshift are equal, inside a bin the next
+// TG2_BIN_BITS as well: the plain unsigned order of the words is the (index, id) order), expansion to index value / id / box byte /
+// context word while writing out.  ids_out / box_out may be null (a caller that derives them later).
+template <int CTX_KIND>
+__global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
+                                                                      u64* __restrict__ keys_out, u32* __restrict__ ids_out,
+                                                                      uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
+                                                                      DevScalars* sc, const u32* __restrict__ stats, u32 abort_over,
+                                                                      const uint4* __restrict__ cell_src) {
+    static_assert(CTX_KIND >= 0 && CTX_KIND <= 2, "the compact route always writes the context words (CTX_KIND = the index kind)");
+    constexpr int XK = CTX_KIND;
+    __shared__ u64 s_comp[TGRP_CAP];  // words grouped by bin while ranking, then in final order
+    __shared__ __attribute__((aligned(16))) u32 s_cnt[TG2_BINS];
+    __shared__ __attribute__((aligned(16))) u32 s_off[TG2_BINS + 4];
+    __shared__ u32 s_ws[TGRP_THREADS / 64];
+    __shared__ u32 s_lut[CTX_LUT_WORDS];
+    constexpr int XDIM = (int)KT<XK>::DIM;
+    __shared__ __attribute__((aligned(4))) unsigned short s_lut3[CompactLut3<XDIM>::WORDS * 2];  // three tail digits -> their Morton bits and level count
+    for (int q = (int)threadIdx.x; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];  // visible after the barriers below
+    {
+        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
+        for (u32 q = threadIdx.x; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
+    }
+    const u32 g = blockIdx.x, tid = threadIdx.x;
+    if (stats && stats[1] > abort_over) {
+        if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
+    const uint4 si = cell_src[g];
+    const u32 src_a = si.x, src_b = si.y, lo = si.z, ng = si.w >> 16, src_nf = si.w & 0xFFFFu;
+    if (ng == 0) return;  // workgroup-uniform
+    if (ng > (u32)TGRP_CAP) {
+        if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
+        return;
+    }
+    const int bshift = gshift - TG2_BIN_BITS;  // the host guarantees bshift >= 0
+    reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    u64 c[TGRP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        c[i] = x < ng ? words_in[x < src_nf ? (size_t)src_a + x : (size_t)src_b + (x - src_nf)] : 0ull;
+    }
+    __syncthreads();
+    u32 slot[TGRP_ITEMS];  // arrival ticket inside the bin, then the scatter slot, then the final position
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        slot[i] = 0;
+        if (x < ng)
+            slot[i] = __hip_atomic_fetch_add(&s_cnt[(u32)(c[i] >> bshift) & (TG2_BINS - 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 1024 bin counts: four consecutive bins per thread
+        const uint4 n4 = reinterpret_cast<const uint4*>(s_cnt)[tid];
+        u32 total;
+        const u32 excl = block_excl_scan_u32<TGRP_THREADS>(n4.x + n4.y + n4.z + n4.w, s_ws, total);
+        reinterpret_cast<uint4*>(s_off)[tid] = make_uint4(excl, excl + n4.x, excl + n4.x + n4.y, excl + n4.x + n4.y + n4.z);
+        if (tid == 0) s_off[TG2_BINS] = ng;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        if (x < ng) {
+            slot[i] += s_off[(u32)(c[i] >> bshift) & (TG2_BINS - 1u)];
+            s_comp[slot[i]] = c[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        if (x < ng) {
+            const u32 b = (u32)(c[i] >> bshift) & (TG2_BINS - 1u);
+            const u32 start = s_off[b], end = s_off[b + 1];
+            u32 rank = 0;
+#pragma unroll 2
+            for (u32 y = start; y < end; ++y) rank += s_comp[y] < c[i] ? 1u : 0u;
+            slot[i] = start + rank;
+        }
+    }
+    __syncthreads();  // every rank is known: the buffer now takes the group in final order
+#pragma unroll
+    for (int i = 0; i < TGRP_ITEMS; ++i) {
+        const u32 x = (u32)i * TGRP_THREADS + tid;
+        if (x < ng) s_comp[slot[i]] = c[i];
+    }
+    __syncthreads();
+    for (u32 y = tid; y < ng; y += TGRP_THREADS) {
+        u64 ky; u32 id, c27;
+        tree_expand<XK>(s_comp[y], fmt, ky, id, c27, s_lut3);
+        keys_out[(size_t)lo + y] = ky;
+        if (ids_out) ids_out[(size_t)lo + y] = id;
+        if (box_out) box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
+        idctx_out[(size_t)lo + y] = ((u64)id << 32) | (u64)entry_ctx_lut<CTX_KIND>(ky, c27, 0u, s_lut);
+    }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void filter_pairs_aabb_kernel(const u64* __restrict__ in, size_t n, const float* __restrict__ bounds, int shape,
                                                                 u64* __restrict__ out, DevScalars* sc) {
@@ -3350,8 +3569,9 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               uint32_t min_depth, const void* recs, const unsigned long long* block_offs,
                               uint64_t* keys_out, uint32_t* ids_out, uint8_t* box_out, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
-                              uint32_t cell_depth, DevScalars* sc_guard, size_t capacity) {
+                              uint32_t cell_depth, DevScalars* sc_guard, size_t capacity, const TreeCompact* compact) {
     if (n == 0) return hipSuccess;
+    if (compact && (!pack_box || cell_hist)) return hipErrorInvalidValue;
     const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
     const KindInfo ki = kind_info(kind);
@@ -3372,12 +3592,15 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
             for (int q = 0; q < hist_plan->n_passes; ++q) dc.shift[q] = hist_plan->shift[q];
         }
     }
-    if (dc.cell_hist) {
+    if (compact) {
+        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
+                                                                                              block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, *compact)));
+    } else if (dc.cell_hist) {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
-                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
+                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, TreeCompact{})));
     } else {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
-                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
+                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, TreeCompact{})));
     }
     return hipGetLastError();
 }
@@ -5080,6 +5303,27 @@ hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in,
     return hipGetLastError();
 }
 bool tgroup_composite_applies(int gshift, int distinct_id_bits) { return distinct_id_bits > 0 && tgroup_composite_fits(gshift, distinct_id_bits); }
+bool tgroup_compact_applies(int comp_gshift) { return comp_gshift >= TG2_BIN_BITS && comp_gshift <= 63; }
+hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_groups, int comp_gshift, const TreeCompact& fmt, uint64_t* keys_out,
+                                        uint32_t* ids_out, uint8_t* box_out, DevScalars* sc, hipStream_t stream, int ctx_kind, uint64_t* idctx_out,
+                                        const uint32_t* stats, uint32_t abort_over, const CellRoute& cells) {
+    if (n_groups == 0) return hipSuccess;
+    // (the kernel takes the index kind from its context-word instantiation: the compact route always writes the context words)
+    if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || ctx_kind < 0 || ctx_kind > 2 || !cells.src) return hipErrorInvalidValue;
+#define BP_TGC_LAUNCH(K)                                                                                                                   \
+    tgroup_finishc_kernel<K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, box_out, \
+                                                                    (u64*)idctx_out, sc, stats, abort_over, cells.src)
+    if (ctx_kind == 0) BP_TGC_LAUNCH(0);
+    else if (ctx_kind == 1) BP_TGC_LAUNCH(1);
+    else BP_TGC_LAUNCH(2);
+#undef BP_TGC_LAUNCH
+    return hipGetLastError();
+}
+hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, size_t n, const TreeCompact& fmt, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    BP_DISPATCH_KIND(kind, (tree_expand_kernel<K><<<grid_for(n, 256, 4096), 256, 0, stream>>>((u64*)words, ids_out, n, fmt)));
+    return hipGetLastError();
+}
 int tgroup_capacity() { return TGRP_CAP; }
 int tgroup_bin_bits() { return TGRP_BIN_BITS; }
 

@@ -53,6 +53,11 @@ struct bp_layer {
     bool box_valid = true;       // box[cur] describes the entries in their current order
     bool box_all_known = true;   // no BOX_UNKNOWN code present
     bool ids_packed = false;     // ids[cur] still carry box codes in bits 27..31 (bp_layer_commit_entries)
+    // compact records (TreeCompact, bp_kernels.h; between a predicted extend and the sort that follows it): keys[cur] holds ONE
+    // composite word per entry -- the index bits that vary, the id, the box code -- and ids[cur] / box[cur] nothing; the cell route
+    // of the tree sort moves these 8-byte records (ensure_plain expands them for every other consumer)
+    bool tree_compact = false;
+    TreeCompact cfmt{};
     int cur = 0;
     size_t m = 0;
     bool sorted = true;
@@ -145,11 +150,11 @@ struct bp_layer {
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
     // extend without a host round trip between its kernels: what the previous extend into the empty layer produced
     // predicts what the next one needs
-    struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; } enc_hint;
+    struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; uint32_t depth_mask = 0, id_or = 0; } enc_hint;
     // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
     // NEXT host round trip (the scan's) instead of one of their own
     // copied: the sort's scalars are on their way to h_sort_sc (a deferred check leaves that to the fetch it rides on: sort_sc_fetch)
-    struct { bool on = false; int src = 0; bool ride = false; bool cells = false; bool copied = false; } sort_pend;
+    struct { bool on = false; int src = 0; bool ride = false; bool cells = false; bool copied = false; bool compact = false; } sort_pend;
     // cell route of the grouped tree sort (CellRoute with a payload): laid out from the group bounds the previous sort of the same
     // plan left in tgrp_bounds; its gapped result goes to tcell_keys / tcell_ids, the finish kernel writes the dense tree
     struct { bool valid = false; unsigned long long g0 = 0; uint32_t n_groups = 0; int gshift = 0; size_t m = 0; } tcell;
@@ -450,6 +455,7 @@ void reset_tree_facts(bp_layer* L) {
     L->box_valid = true;
     L->box_all_known = true;
     L->ids_packed = false;
+    L->tree_compact = false;
 }
 
 uint64_t* cur_keys(bp_layer* L) { return (uint64_t*)L->keys[L->cur].p; }
@@ -463,10 +469,28 @@ int ensure_tree_capacity(bp_layer* L, size_t entries) {
 }
 
 int settle_sort(bp_layer* L, bool already_synced = false, bool* redone = nullptr);
+// compact records -> index values in keys[buf], ids with their box codes packed in ids[buf] (the form a packing extend leaves)
+int expand_compact(bp_layer* L, int buf, size_t m) {
+    BP_TRY(ensure_dev(L, L->ids[buf], std::max<size_t>(m, 1) * sizeof(uint32_t)));
+    HIP_TRY(L, launch_tree_expand(L->kind, (uint64_t*)L->keys[buf].p, (uint32_t*)L->ids[buf].p, m, L->cfmt, L->stream));
+    ++L->stats.tree_expands;
+    return BP_OK;
+}
+// a tree that an extend left as compact records is expanded before anything but the compact sort reads it
+int ensure_plain(bp_layer* L) {
+    if (!L->tree_compact) return BP_OK;
+    BP_TRY(expand_compact(L, L->cur, L->m));
+    L->tree_compact = false;
+    L->ids_packed = true;
+    L->box_valid = false;
+    L->tree_hist_valid = false;  // (the digit counts were the composite's)
+    return BP_OK;
+}
 // ids committed with their box codes still packed are split before anything but the sort reads them; a tree sort whose
 // check was deferred is settled first (every accessor of the tree comes through here)
 int ensure_unpacked(bp_layer* L) {
     if (L->sort_pend.on) BP_TRY(settle_sort(L));
+    BP_TRY(ensure_plain(L));
     if (!L->ids_packed) return BP_OK;
     if (L->m) {
         BP_TRY(ensure_dev(L, L->box[L->cur], L->m));
@@ -481,6 +505,50 @@ int ensure_unpacked(bp_layer* L) {
 bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, int* seg_shift_out);
 struct TreeGroupPlan { RadixPlan plan; int gshift; uint32_t n_groups; unsigned long long g0; };
 bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out);
+// ---- compact route of the per-frame tree sort (TreeCompact, bp_kernels.h) ------------------------------------------------------
+// would the grouped tree sort of m entries under plan gp take the cell route (what sort_tree checks before its radix passes)?
+// before_sort: asked ahead of that sort (its back-off counter has not been stepped yet)
+bool tree_cells_possible(const bp_layer* L, size_t m, const TreeGroupPlan& gp, bool before_sort) {
+    static const bool no_tcells = getenv("BP_NO_TREE_CELL_SORT") != nullptr;  // A/B switch
+    const uint32_t cell0 = (uint32_t)(gp.g0 & 0xFFFFu);
+    const bool off_ok = before_sort ? L->tcell_off <= 1 : L->tcell_off == 0;
+    return !no_tcells && off_ok && L->tcell.valid && L->tcell.g0 == gp.g0 && L->tcell.n_groups == gp.n_groups && L->tcell.gshift == gp.gshift &&
+           gp.plan.n_passes == 2 && (size_t)cell0 + gp.n_groups <= CELL_COUNT && radix_claim_applies(m) && m <= L->tcell.m + L->tcell.m / 16 &&
+           m + m / 16 >= L->tcell.m;
+}
+// the grouped plan gp (shifts in the index value) restated for composite words of format fmt: the groups are the same -- the
+// group shift must lie inside the Morton bits the format keeps
+struct CompactPlan { TreeCompact fmt; RadixPlan plan; int comp_gshift; };
+bool compact_plan(const TreeGroupPlan& gp, const TreeCompact& fmt, CompactPlan* out) {
+    if (gp.gshift < fmt.pshift || gp.plan.n_passes != 2) return false;
+    const int cg = gp.gshift - fmt.pshift + fmt.tbits + fmt.low;
+    if (!tgroup_compact_applies(cg) || cg + 8 >= 64) return false;
+    out->fmt = fmt;
+    out->comp_gshift = cg;
+    out->plan.n_passes = 2;
+    for (int i = 0; i < RS_MAX_PASSES; ++i) { out->plan.shift[i] = 0; out->plan.from_val[i] = 0; }
+    out->plan.shift[0] = cg; out->plan.shift[1] = cg + 8;
+    return true;
+}
+// the format an extend chooses from what the PREVIOUS frame looked like (depths present, id bits), with a level of head room
+// on either side where 64 bits allow it -- a frame that leaves the format all the same runs again on the plain path
+bool compact_choose(int kind, uint32_t depth_mask, uint32_t id_or, const TreeGroupPlan& gp, CompactPlan* out) {
+    static const bool disabled = getenv("BP_NO_COMPACT_TREE") != nullptr;  // A/B switch
+    if (disabled || depth_mask == 0) return false;
+    const KindInfo ki = kind_info(kind);
+    const uint32_t dlo = (uint32_t)__builtin_ctz(depth_mask), dhi = 31u - (uint32_t)__builtin_clz(depth_mask);
+    const int idbits = std::max(1, 32 - __builtin_clz(id_or | 1u));
+    // (every level of the digit tail costs the encode and the finish a few instructions per entry: head room below the
+    // shallowest depth only where the deeper side has none to give)
+    const uint32_t lo_m = dlo ? dlo - 1u : 0u, hi_m = std::min(dhi + 1u, ki.axis_bits);
+    const uint32_t tries[4][2] = {{dlo, hi_m}, {dlo, dhi}, {lo_m, hi_m}, {lo_m, dhi}};
+    for (const auto& t : tries) {
+        TreeCompact f;
+        if (tree_compact_format(kind, t[0], t[1], idbits, &f) && compact_plan(gp, f, out)) return true;
+    }
+    return false;
+}
+
 
 // ---- extend -------------------------------------------------------------------------------------------
 // Extend into the EMPTY layer (the per-frame pattern) when an earlier extend left a prediction: count, block sums and
@@ -509,15 +577,24 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     RadixPlan hist_plan;
     int seg_shift_unused = 0;
     bool count_digits = tree_partial_plan(pred_m, h.key_or ^ h.key_and, &hist_plan, &seg_shift_unused) && hist_plan.n_passes <= SX_HIST_MAX;
+    const KindInfo kic = kind_info(L->kind);
+    const bool count_cells = L->cell_fuse_depth > 0 && kic.dim * L->cell_fuse_depth <= 9;
+    // compact records: when the coming sort will most likely take the cell route and the previous frame's depths and ids leave
+    // room in 64 bits, the emit pass writes one composite word per entry and counts the composite's digits
+    bool compact = false;
+    CompactPlan cp{};
     {
         TreeGroupPlan gp;
         if (L->tgrp_ok && tree_group_plan(pred_m, h.key_and, h.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
             hist_plan = gp.plan;
             count_digits = true;
+            if (pack && !count_cells && tree_cells_possible(L, pred_m, gp, /*before_sort=*/true) &&
+                compact_choose(L->kind, h.depth_mask, h.id_or, gp, &cp)) {
+                compact = true;
+                hist_plan = cp.plan;
+            }
         }
     }
-    const KindInfo kic = kind_info(L->kind);
-    const bool count_cells = L->cell_fuse_depth > 0 && kic.dim * L->cell_fuse_depth <= 9;
     const size_t cell_bytes = count_cells ? (size_t)HIST_COPIES * (((size_t)1 << (kic.dim * L->cell_fuse_depth)) + 1) * sizeof(unsigned long long) : 0;
     // the histograms encode_emit adds into and the scalars are reset by scan_block_sums (between count and emit): no fills, no H2D copy
     if (count_cells) BP_TRY(ensure_dev(L, L->cell_hist_dev, cell_bytes));
@@ -560,7 +637,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
                                       pack ? nullptr : (uint8_t*)L->box[L->cur].p, L->stream, count_digits ? &hist_plan : nullptr,
                                       count_digits ? (unsigned long long*)L->tree_hist.p : nullptr, pack ? 1 : 0,
                                       count_cells ? (unsigned long long*)L->cell_hist_dev.p : nullptr, L->cell_fuse_depth,
-                                      (DevScalars*)L->d_sc.p, capacity));
+                                      (DevScalars*)L->d_sc.p, capacity, compact ? &cp.fmt : nullptr));
     }
     // the cell histogram counted on the way (multi-GPU splitter): summed on the device and brought back by THIS round trip,
     // so that bp_layer_cell_histogram costs none of its own
@@ -589,9 +666,14 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     }
     const size_t add = (size_t)sc.total;
     const bool can_pack = !(sc.flags & EXT_IDS_REPEAT) && (sc.id_or >> BOX_ID_BITS) == 0;
-    if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack)) {
+    // (compact records: every depth and id of THIS frame must lie inside the format chosen from the last one)
+    const bool compact_fits = !compact || add == 0 ||
+                              (sc.depth_mask != 0 && (uint32_t)__builtin_ctz(sc.depth_mask) >= cp.fmt.dmin &&
+                               31u - (uint32_t)__builtin_clz(sc.depth_mask) <= cp.fmt.dmax && (sc.id_or >> cp.fmt.idbits) == 0);
+    if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack) || !compact_fits) {
         // the prediction failed: remember the truth for the next frame and redo this one on the plain path
         L->enc_hint.entries = add; L->enc_hint.n = n; L->enc_hint.pack = can_pack;
+        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
         ++L->stats.extend_reruns;
         return BP_OK;
     }
@@ -608,6 +690,7 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;
     L->enc_hint.pack = can_pack && !no_emit_pack;
     L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
+    L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
     if (add == 0) return BP_OK;
     if (count_cells) {
         L->cell_dev_valid = true;
@@ -616,7 +699,8 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
         L->cell_hist_depth = L->cell_fuse_depth;
         L->cell_hist_valid = true;
     }
-    if (pack) { L->ids_packed = true; L->box_valid = false; }
+    if (compact) { L->tree_compact = true; L->cfmt = cp.fmt; L->box_valid = false; }
+    else if (pack) { L->ids_packed = true; L->box_valid = false; }
     L->tail_run = false;
     if (count_digits) { L->tree_hist_valid = true; L->tree_hist_plan = hist_plan; L->tree_hist_m = add; }
     L->m += add;
@@ -722,6 +806,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     if (was_empty) {  // what this extend produced predicts the next frame's (one-pass extend)
         L->enc_hint.valid = true; L->enc_hint.n = n; L->enc_hint.entries = add; L->enc_hint.pack = pack;
         L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
+        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
     }
     L->m += add;
     L->sorted = false;  // src/layer.rs:119 (at least one valid object was appended)
@@ -756,7 +841,7 @@ int absorb_raw_entries(bp_layer* L, const uint64_t* d_keys, const uint32_t* d_id
 
 // ---- sort -----------------------------------------------------------------------------------------------
 bool box_can_ride(const bp_layer* L) {  // the box codes travel in the id payload's bits 27..31
-    return (L->box_valid || L->ids_packed) && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
+    return (L->box_valid || L->ids_packed || L->tree_compact) && L->order_ok && L->ids_distinct && (L->id_or >> BOX_ID_BITS) == 0;
 }
 
 // full-width LSD sort (every varying key bit, ids first when the order fact is missing)
@@ -924,6 +1009,8 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
         if (L->sort_pend.cells) L->tcell_off = 16;
         L->tcell.valid = false;
         L->cur = L->sort_pend.src;
+        // (a compact sort: the first pass's dense output is composite words -- the repair sorts (index, id) records)
+        if (L->sort_pend.compact) BP_TRY(expand_compact(L, L->cur, L->m));
         L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
         ++L->epoch;
         // the first radix pass placed records of equal digit in no particular order: equal keys are no longer in id order,
@@ -939,6 +1026,34 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     return BP_OK;
 }
 
+// the cell route of a grouped tree sort: its gapped output buffers, the cells' workspace and the launch tag of the cell walks;
+// the cells are laid out (inside the sort's first kernel) from the group bounds the previous sort left in tgrp_bounds
+int tcell_setup(bp_layer* L, const TreeGroupPlan& gp, bool with_vals, CellRoute* out) {
+    CellRoute& cr = *out;
+    const size_t slots = cell_layout_capacity(L->m);
+    BP_TRY(ensure_dev(L, L->tcell_keys, slots * sizeof(uint64_t)));
+    if (with_vals) BP_TRY(ensure_dev(L, L->tcell_ids, slots * sizeof(uint32_t)));
+    const bool fresh = L->tcell_ws.p == nullptr;
+    BP_TRY(ensure_dev(L, L->tcell_ws, (7 * (size_t)CELL_COUNT + 16 + 128 + 16) * sizeof(uint32_t)));
+    uint32_t* const cw = (uint32_t*)L->tcell_ws.p;
+    cr.src = (uint4*)cw;
+    cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
+    cr.status = (unsigned long long*)(cw + 7 * (size_t)CELL_COUNT + 16);
+    cr.miss = cw + 7 * (size_t)CELL_COUNT + 16 + 128;
+    cr.out_keys = (uint64_t*)L->tcell_keys.p; cr.out_vals = with_vals ? (uint32_t*)L->tcell_ids.p : nullptr;
+    if (fresh) { HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream)); L->tcell_tag = 0; }
+    L->tcell_tag += 2;
+    if (L->tcell_tag >= (1u << 23)) {
+        HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream));
+        L->tcell_tag = 2;
+    }
+    cr.tag = L->tcell_tag;
+    // (the layout runs inside the sort's first kernel)
+    cr.layout_prev_bounds = (const uint32_t*)L->tgrp_bounds.p; cr.layout_g0 = (uint32_t)(gp.g0 & 0xFFFFu); cr.layout_groups = gp.n_groups;
+    cr.layout_limit = slots;
+    return BP_OK;
+}
+
 int sort_tree(bp_layer* L, bool defer_check) {
     if (L->sort_pend.on) {
         if (defer_check && L->sorted) return BP_OK;  // still pending: this caller settles it at its own host round trip
@@ -946,6 +1061,17 @@ int sort_tree(bp_layer* L, bool defer_check) {
     }
     if (L->sorted) return ensure_unpacked(L);  // src/layer.rs:148, 161
     ++L->epoch;
+    // compact records (what the frame's extend wrote, expecting this sort to take the cell route): sorted as they are if that still
+    // holds, expanded for every other plan
+    bool compact_go = false;
+    CompactPlan ccp{};
+    if (L->tree_compact) {
+        TreeGroupPlan gpc;
+        compact_go = L->m > 1 && !L->tail_run && L->tgrp_ok && tree_group_plan(L->m, L->key_and, L->key_or, &gpc) &&
+                     tree_cells_possible(L, L->m, gpc, /*before_sort=*/true) && compact_plan(gpc, L->cfmt, &ccp) && L->tree_hist_valid &&
+                     L->tree_hist_m == L->m && same_plan(ccp.plan, L->tree_hist_plan);
+        if (!compact_go) BP_TRY(ensure_plain(L));
+    }
     if (L->tail_run && L->m > 1) {
         int handled = 0;
         BP_TRY(sort_tree_by_merge(L, &handled));
@@ -961,7 +1087,59 @@ int sort_tree(bp_layer* L, bool defer_check) {
         bool done = false;
         TreeGroupPlan gp;
         const bool group_able = tree_group_plan(L->m, L->key_and, L->key_or, &gp);
-        if (group_able && L->tgrp_ok) {  // one pass fewer; the groups of equal prefix are ordered in LDS
+        if (group_able && L->tgrp_ok && compact_go) {
+            // the cell route on compact records: key-only claiming passes over composite words (16 bytes per record and pass instead
+            // of 24), the finish expands them into index values, ids, box bytes and context words
+            L->stats.tree_sort_passes = 2;
+            const int other = L->cur ^ 1, dst = L->cur;
+            BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
+            BP_TRY(ensure_dev(L, L->ids[dst], L->m * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->box[dst], L->m));
+            BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
+            uint32_t* ws_epoch = nullptr;
+            BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(L->m, 2), &ws_epoch));
+            BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
+            BP_TRY(ensure_dev(L, L->d_sort_sc, sizeof(DevScalars)));
+            BP_TRY(ensure_host(L, L->h_sort_sc, sizeof(DevScalars)));
+            const DevScalars ssc_init = neutral_scalars();
+            DevScalars* const d_ssc = (DevScalars*)L->d_sort_sc.p;
+            L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
+            if (L->tcell_off) --L->tcell_off;
+            const uint32_t cell0 = (uint32_t)(gp.g0 & 0xFFFFu);
+            CellRoute cr{};
+            BP_TRY(tcell_setup(L, gp, /*with_vals=*/false, &cr));
+            int res = 0;
+            HIP_TRY(L, radix_sort((uint64_t*)L->keys[L->cur].p, (uint64_t*)L->keys[other].p, nullptr, nullptr, L->m, ccp.plan, L->radix_ws.p,
+                                  L->radix_ws.cap, d_ssc, &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT, nullptr, nullptr, nullptr, 0,
+                                  (const unsigned long long*)L->tree_hist.p, HIST_COPIES, /*unstable_first=*/1, ws_epoch, &ssc_init, nullptr, nullptr, &cr));
+            {
+                ProfScope ps(L, BP_K_TREE_FINISH);
+                HIP_TRY(L, launch_cell_count(cr, cell0, gp.n_groups, (uint32_t*)L->tgrp_bounds.p, (uint32_t)tgroup_capacity(), group_stats_words(d_ssc),
+                                             nullptr, L->stream, &d_ssc->err, (uint32_t)KERR_SEGMENT_TOO_LONG, (uint32_t)L->m));
+                HIP_TRY(L, launch_tgroup_finish_compact((const uint64_t*)L->tcell_keys.p, gp.n_groups, ccp.comp_gshift, L->cfmt, (uint64_t*)L->keys[dst].p,
+                                                        (uint32_t*)L->ids[dst].p, (uint8_t*)L->box[dst].p, d_ssc, L->stream, L->kind, (uint64_t*)L->idctx.p,
+                                                        group_stats_words(d_ssc), (uint32_t)(L->m / 4), cr));
+                ++L->stats.tree_sorts_in_cells;
+                ++L->stats.tree_sorts_compact;
+            }
+            L->tcell.valid = true; L->tcell.g0 = gp.g0; L->tcell.n_groups = gp.n_groups; L->tcell.gshift = gp.gshift; L->tcell.m = L->m;
+            // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
+            L->cur = dst;
+            L->tree_compact = false;
+            L->box_valid = true;
+            L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0;
+            L->ids_packed = false;
+            L->sort_pend.on = true; L->sort_pend.src = other; L->sort_pend.ride = true; L->sort_pend.cells = true; L->sort_pend.copied = false;
+            L->sort_pend.compact = true;
+            static const bool no_defer_c = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
+            if (defer_check && !no_defer_c) {
+                L->sorted = true;
+                L->order_ok = true;
+                return BP_OK;
+            }
+            BP_TRY(settle_sort(L));
+            done = true;
+        } else if (group_able && L->tgrp_ok) {  // one pass fewer; the groups of equal prefix are ordered in LDS
             L->stats.tree_sort_passes = (uint32_t)gp.plan.n_passes;
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
@@ -994,28 +1172,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
                                tgroup_composite_applies(gp.gshift, distinct_bits) && (size_t)cell0 + gp.n_groups <= CELL_COUNT &&
                                radix_claim_applies(L->m) && L->m <= L->tcell.m + L->tcell.m / 16 && L->m + L->m / 16 >= L->tcell.m;
             CellRoute cr{};
-            if (tcell) {
-                const size_t slots = cell_layout_capacity(L->m);
-                BP_TRY(ensure_dev(L, L->tcell_keys, slots * sizeof(uint64_t)));
-                BP_TRY(ensure_dev(L, L->tcell_ids, slots * sizeof(uint32_t)));
-                const bool fresh = L->tcell_ws.p == nullptr;
-                BP_TRY(ensure_dev(L, L->tcell_ws, (7 * (size_t)CELL_COUNT + 16 + 128 + 16) * sizeof(uint32_t)));
-                uint32_t* const cw = (uint32_t*)L->tcell_ws.p;
-                cr.src = (uint4*)cw;
-                cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
-                cr.status = (unsigned long long*)(cw + 7 * (size_t)CELL_COUNT + 16);
-                cr.miss = cw + 7 * (size_t)CELL_COUNT + 16 + 128;
-                cr.out_keys = (uint64_t*)L->tcell_keys.p; cr.out_vals = (uint32_t*)L->tcell_ids.p;
-                if (fresh) { HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream)); L->tcell_tag = 0; }
-                L->tcell_tag += 2;
-                if (L->tcell_tag >= (1u << 23)) {
-                    HIP_TRY(L, hipMemsetAsync(cr.status, 0, 64 * sizeof(unsigned long long), L->stream));
-                    L->tcell_tag = 2;
-                }
-                cr.tag = L->tcell_tag;
-                // (the layout runs inside the sort's first kernel)
-                cr.layout_prev_bounds = (const uint32_t*)L->tgrp_bounds.p; cr.layout_g0 = cell0; cr.layout_groups = gp.n_groups; cr.layout_limit = slots;
-            }
+            if (tcell) BP_TRY(tcell_setup(L, gp, /*with_vals=*/true, &cr));
             HIP_TRY(L, radix_sort(kb[0], kb[1], vb[0], vb[1], L->m, gp.plan, L->radix_ws.p, L->radix_ws.cap, d_ssc,
                                   &res, L->stream, prof_mark, L, BP_K_TREE_HIST, BP_K_TREE_SORT,
                                   (ride && !packed_in) ? (const uint8_t*)L->box[L->cur].p : nullptr, nullptr, nullptr, 0,
@@ -1057,6 +1214,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
             if (with_ctx) { L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0; }
             L->ids_packed = false;
             L->sort_pend.on = true; L->sort_pend.src = src; L->sort_pend.ride = ride; L->sort_pend.cells = tcell; L->sort_pend.copied = false;
+            L->sort_pend.compact = false;
             static const bool no_defer = getenv("BP_NO_DEFERRED_SORT_CHECK") != nullptr;  // A/B switch
             if (defer_check && !no_defer) {  // no host round trip here: the check rides on the caller's next one
                 L->sorted = true;
@@ -2686,6 +2844,7 @@ int bp_layer_cell_histogram(bp_layer_t* L, uint32_t split_depth, uint64_t* hist,
         L->cell_hist_valid = true;
         return BP_OK;
     }
+    BP_TRY(ensure_plain(L));
     BP_TRY(ensure_dev(L, L->block_sums, bytes));
     BP_TRY(ensure_host(L, L->h_raw, bytes));
     HIP_TRY(L, hipMemsetAsync(L->block_sums.p, 0, bytes, L->stream));
@@ -2728,6 +2887,7 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     // while its peers wait for it in the exchange)
     if (pack_box && L->m != 0 && !box_can_ride(L)) return fail(L, BP_ERR_INVALID_ARG, "bp_layer_partition_entries: ids cannot carry box codes");
     DeviceGuard g(L->device);
+    BP_TRY(ensure_plain(L));
     const bool already_packed = pack_box && L->ids_packed;  // extend wrote the codes into the ids: nothing to do
     if (!already_packed) BP_TRY(ensure_unpacked(L));
     const int other = L->cur ^ 1;

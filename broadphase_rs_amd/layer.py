@@ -61,7 +61,7 @@ class _Stats(C.Structure):
                 ("host_syncs", C.c_uint64), ("extend_reruns", C.c_uint32), ("tree_plan_flips", C.c_uint32),
                 ("pair_plan_flips", C.c_uint32), ("sort_repairs", C.c_uint32), ("sorts_ahead", C.c_uint32),
                 ("sorts_ahead_missed", C.c_uint32), ("sorts_in_cells", C.c_uint32),
-                ("tree_sorts_in_cells", C.c_uint32)]
+                ("tree_sorts_in_cells", C.c_uint32), ("tree_sorts_compact", C.c_uint32), ("tree_expands", C.c_uint32)]
 
 
 FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)

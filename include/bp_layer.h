@@ -294,6 +294,10 @@ typedef struct bp_stats {
                                  previous frame's group sizes (no stable pass, no search for the group bounds)            */
     uint32_t tree_sorts_in_cells; /* grouped tree sorts that took the cell route (the same idea for the (index, id) sort: a
                                      cell that outgrows its range is a sort_repair)                                        */
+    uint32_t tree_sorts_compact;  /* ... of which moved 8-byte compact records (index bits that vary | id | box code in one
+                                     word, written by extend) through the passes instead of (u64 index, u32 id) pairs      */
+    uint32_t tree_expands;        /* compact records expanded to (index, id) arrays because something other than that sort
+                                     asked for the tree first (iter / merge / a second extend / a repair ...)              */
 } bp_stats;
 int bp_layer_stats(const bp_layer_t *layer, bp_stats *out);
 

@@ -1,0 +1,192 @@
+"""Compact records of the per-frame tree sort (TreeCompact, csrc/bp_kernels.h): once a layer's frames have settled into the
+cell route, `extend` writes one 64-bit word per entry -- the index bits that vary, the id, the box code -- and the radix passes
+move 8-byte records; the finish expands them into the (index, id) tree.  Everything observable must stay what the reference
+produces (src/layer.rs:94-165, 449-520): the unsorted tree in append order when something asks for it before the sort, the
+sorted tree, the pair list -- against the oracle, frame by frame, for the three index kinds."""
+import numpy as np
+import pytest
+
+import oracle
+import broadphase_rs_amd as bp
+from broadphase_rs_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {0: bp.Index32_2D, 1: bp.Index64_2D, 2: bp.Index64_3D}
+
+
+def base_scene(kind, n, seed):
+    if kind == 2:
+        return scenes.gen_boxes(n, seed=seed)
+    return scenes.gen_circles_2d(n, seed=seed)
+
+
+def moved(kind, sysb, base, frame, amount=0.5):
+    """every object displaced by up to +- amount x its size per axis (seeded), kept inside the system bounds"""
+    dim = 3 if kind == 2 else 2
+    rng = np.random.default_rng(1000 + frame)
+    size = base[:, dim:] - base[:, :dim]
+    lo = np.asarray(sysb[0], dtype=np.float32)[:dim]
+    hi = np.asarray(sysb[1], dtype=np.float32)[:dim]
+    mn = base[:, :dim] + (rng.random((len(base), dim), dtype=np.float32) - np.float32(0.5)) * np.float32(2 * amount) * size
+    mn = np.minimum(np.maximum(mn, lo), hi - size).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([mn, mn + size], axis=1).astype(np.float32))
+
+
+def check_tree(gpu, ref, what):
+    k, i = gpu.tree()
+    assert len(k) == len(ref.keys), "%s: %d entries, oracle %d" % (what, len(k), len(ref.keys))
+    assert np.array_equal(k, ref.keys), "%s: keys differ (first at %d)" % (what, int(np.flatnonzero(k != ref.keys)[0]))
+    assert np.array_equal(i, ref.ids), "%s: ids differ (first at %d)" % (what, int(np.flatnonzero(i != ref.ids)[0]))
+    assert gpu.sorted == ref.sorted, what
+
+
+def check_pairs(got, exp, what):
+    got = np.asarray(got)
+    assert got.shape == exp.shape, "%s: %s pairs, oracle %s" % (what, got.shape, exp.shape)
+    assert np.array_equal(got, exp), what
+
+
+def warm(gpu, kind, sysb, base, ids, frames, first=0):
+    """frames of the moving scene through clear / extend / par_sort / par_scan, each checked against the oracle"""
+    for f in range(first, first + frames):
+        b = moved(kind, sysb, base, f)
+        ref = oracle.OracleLayer(kind, 0)
+        gpu.clear()
+        gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
+        gpu.par_sort(); ref.sort()
+        check_tree(gpu, ref, "frame %d, par_sort" % f)
+        check_pairs(gpu.par_scan(), ref.scan(), "frame %d, par_scan" % f)
+
+
+@pytest.mark.parametrize("kind,n", [(2, 200000), (1, 250000), (0, 250000)])
+def test_compact_records_over_moving_frames(kind, n, monkeypatch):
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")   # (the claiming passes, and with them the cell routes, start at ~2 M records by default)
+    sysb, base, ids = base_scene(kind, n, seed=7 + kind)
+    gpu = bp.Layer(KINDS[kind], 0)
+    warm(gpu, kind, sysb, base, ids, 7)
+    st = gpu.stats()
+    want = ("tree_sorts_in_cells", "tree_sorts_compact", "tree_expands", "extend_reruns", "sort_repairs", "tree_sort_passes")
+    # frame 0 takes the classic plan and probes, frame 1 the grouped plan, frame 2 the cell route; from then on extend may write
+    # compact records -- and nothing but the sort asks for the tree before it is sorted, so nothing is expanded
+    assert st["tree_sorts_compact"] >= 3 and st["tree_expands"] == 0 and st["sort_repairs"] == 0, {k: st[k] for k in want}
+
+
+def test_compact_records_are_expanded_for_every_other_consumer(monkeypatch):
+    """once the layer writes compact records, anything but the frame's own sort that touches the tree first -- iter() of the
+    unsorted tree, a second extend, merge, clone, equality, raw-order scans -- sees exactly the (index, id) entries in append
+    order (src/layer.rs:79-81, 94-138)"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    kind, n = 2, 150000
+    sysb, base, ids = base_scene(kind, n, seed=21)
+    gpu = bp.Layer(KINDS[kind], 0)
+    warm(gpu, kind, sysb, base, ids, 4)
+    assert gpu.stats()["tree_sorts_compact"] >= 1
+
+    def frame(f):
+        b = moved(kind, sysb, base, f)
+        ref = oracle.OracleLayer(kind, 0)
+        gpu.clear()
+        gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
+        return b, ref
+
+    # (a) the unsorted tree, then the rest of the frame
+    e0 = gpu.stats()["tree_expands"]
+    _, ref = frame(10)
+    check_tree(gpu, ref, "unsorted tree after a compact extend")
+    assert gpu.stats()["tree_expands"] == e0 + 1
+    gpu.par_sort(); ref.sort()
+    check_tree(gpu, ref, "sorted after expansion")
+    check_pairs(gpu.par_scan(), ref.scan(), "scan after expansion")
+    warm(gpu, kind, sysb, base, ids, 2, first=11)     # back on the route
+    # (b) a second extend appends to the expanded entries
+    _, ref = frame(13)
+    sysb2, extra, _ = scenes.gen_boxes(5000, seed=99)
+    extra = (extra * np.float32(float(sysb[1][0]) / float(sysb2[1][0]) * 0.999)).astype(np.float32)
+    extra_ids = (np.arange(5000, dtype=np.uint32) + np.uint32(n + 10))
+    gpu.extend(sysb, extra, extra_ids); ref.extend(sysb, extra, extra_ids)
+    check_tree(gpu, ref, "second extend behind a compact one")
+    check_pairs(gpu.par_scan(), ref.scan(), "scan of both extends")
+    warm(gpu, kind, sysb, base, ids, 3, first=14)
+    # (c) merge of a static layer into the frame's layer
+    _, ref = frame(17)
+    stat_gpu = bp.Layer(KINDS[kind], 0); stat_ref = oracle.OracleLayer(kind, 0)
+    stat_gpu.extend(sysb, extra, extra_ids); stat_ref.extend(sysb, extra, extra_ids)
+    stat_gpu.par_sort(); stat_ref.sort()
+    gpu.merge(stat_gpu); ref.merge(stat_ref)
+    check_tree(gpu, ref, "merge into a compact tree")
+    check_pairs(gpu.par_scan(), ref.scan(), "scan after merge")
+    warm(gpu, kind, sysb, base, ids, 3, first=18)
+    # (d) clone and equality
+    _, ref = frame(21)
+    twin = gpu.clone()
+    assert twin == gpu
+    check_tree(twin, ref, "clone of a compact tree")
+    check_pairs(twin.par_scan(), ref.scan(), "scan of the clone")
+    check_pairs(gpu.par_scan(), ref.scan(), "scan of the original")
+    warm(gpu, kind, sysb, base, ids, 3, first=22)
+    # (e) the raw stream in the reference's emission order (the literal scan kernels)
+    _, ref = frame(25)
+    raw_ref, _ = ref.scan_raw()
+    check_pairs(gpu.scan_raw(), raw_ref, "scan_raw straight after a compact extend")
+
+
+def test_a_frame_that_leaves_the_compact_format_runs_again_on_the_plain_path(monkeypatch):
+    """the format is chosen from the PREVIOUS frame's depths and ids (one level of head room either side where 64 bits allow):
+    a frame with much smaller objects (deeper cells) or wider ids does not fit it -- extend must notice from the frame's own
+    facts and run again, and the results stay the oracle's"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    kind, n = 2, 200000
+    sysb, base, ids = base_scene(kind, n, seed=33)
+    gpu = bp.Layer(KINDS[kind], 0)
+    warm(gpu, kind, sysb, base, ids, 4)
+    st0 = gpu.stats()
+    assert st0["tree_sorts_compact"] >= 1
+    # deeper: a handful of objects shrunk by 2^-6 (six levels below anything the last frame had)
+    b = moved(kind, sysb, base, 40)
+    c = (b[:50, :3] + b[:50, 3:]) * np.float32(0.5)
+    h = (b[:50, 3:] - b[:50, :3]) * np.float32(0.5 / 64)
+    b[:50] = np.concatenate([c - h, c + h], axis=1)
+    ref = oracle.OracleLayer(kind, 0)
+    gpu.clear(); gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
+    check_pairs(gpu.par_scan(), ref.scan(), "frame with deeper cells")
+    check_tree(gpu, ref, "frame with deeper cells, tree")
+    st1 = gpu.stats()
+    assert st1["extend_reruns"] == st0["extend_reruns"] + 1, (st0["extend_reruns"], st1["extend_reruns"])
+    warm(gpu, kind, sysb, base, ids, 4, first=41)
+    # wider ids: the same objects under ids that need three more bits (still distinct, ascending, below 2^27)
+    st2 = gpu.stats()
+    wide = (ids.astype(np.uint64) * 8 + 5).astype(np.uint32)
+    b = moved(kind, sysb, base, 50)
+    ref = oracle.OracleLayer(kind, 0)
+    gpu.clear(); gpu.extend(sysb, b, wide); ref.extend(sysb, b, wide)
+    check_pairs(gpu.par_scan(), ref.scan(), "frame with wider ids")
+    check_tree(gpu, ref, "frame with wider ids, tree")
+    assert gpu.stats()["extend_reruns"] == st2["extend_reruns"] + 1
+
+
+def test_compact_switch_off_gives_the_same_lists():
+    """BP_NO_COMPACT_TREE (read once per process: child process) takes the route out; same frames, same lists, no compact sort"""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, oracle, broadphase_rs_amd as bp\n"
+        "from broadphase_rs_amd import scenes\n"
+        "sysb, base, ids = scenes.gen_boxes(200000, seed=11)\n"
+        "size = base[:, 3:] - base[:, :3]; side = np.float32(sysb[1][0])\n"
+        "gpu = bp.Layer(bp.Index64_3D, 0)\n"
+        "for f in range(6):\n"
+        "    rng = np.random.default_rng(100 + f)\n"
+        "    mn = np.minimum(np.maximum(base[:, :3] + (rng.random((len(ids), 3), dtype=np.float32) - np.float32(0.5)) * size, 0), side - size).astype(np.float32)\n"
+        "    b = np.concatenate([mn, mn + size], axis=1).astype(np.float32)\n"
+        "    ref = oracle.OracleLayer(2, 0); gpu.clear(); gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)\n"
+        "    got = np.array(gpu.par_scan()); exp = ref.scan()\n"
+        "    assert got.shape == exp.shape and np.array_equal(got, exp), f\n"
+        "    gk, gi = gpu.tree(); ref.sort()\n"
+        "    assert np.array_equal(gk, ref.keys) and np.array_equal(gi, ref.ids), f\n"
+        "st = gpu.stats()\n"
+        "assert st['tree_sorts_compact'] == 0 and st['tree_sorts_in_cells'] >= 1, st\n"
+        "print('ok')\n")
+    env = dict(os.environ, BP_RADIX_CLAIM_MIN_TILES="1", BP_NO_COMPACT_TREE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
