@@ -2061,7 +2061,7 @@ __device__ __forceinline__ void ctx_lut_load(u32* s_lut) {
     __syncthreads();
 }
 // c27: the box code as it travels in the ids (t_x + 3 t_y + 9 t_z, >= 27: unknown)
-template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
+template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_wide(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
     constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
     const u32 d = key_depth<KIND>(key);
@@ -2090,6 +2090,35 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c2
     const u32 e = s_lut[c27 * 8u + cmp];
     if (d < inactive_below) return CTX_INACTIVE | (e & CTX_CODE_MASK);
     return e | (t0 ? d - f0 : 0u) | ((t1 ? d - f1 : 0u) << 8) | ((t2 ? d - f2 : 0u) << 16);
+}
+// The same word where the entry's DIM * depth Morton bits fit 32 (depth <= 10 in 3-D, <= 16 in 2-D): the three axes' trailing
+// runs come out of ONE 32-bit word -- the lanes of the axes whose run is of ones are flipped, then per axis a mask, a find-first-
+// bit and a minimum with DIM * depth (an empty lane: the run is the whole coordinate).  A third of the wide version's
+// instructions, in kernels that are bound by instruction issue (the finish of the tree sort spends most of its instructions here).
+template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_narrow(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
+    constexpr u32 L0 = DIM == 3 ? 0x49249249u : 0x55555555u, L1 = L0 << 1, L2 = DIM == 3 ? L0 << 2 : 0u;
+    const u32 d = key_depth<KIND>(key);
+    if (c27 >= 27u) return d < inactive_below ? CTX_INACTIVE : 0u;
+    const u32 t2 = (c27 * 57u) >> 9, r = c27 - 9u * t2, t1 = (r * 11u) >> 5, t0 = r - 3u * t1;
+    const u32 nb = DIM * d;                                      // <= 32 (the caller checks)
+    const u32 md = (u32)(key >> (DB + DIM * (AB - d)));         // (depth 0: everything shifts out)
+    const u32 valid = nb >= 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
+    const u32 flip = (t0 == 1u ? L0 : 0u) | (t1 == 1u ? L1 : 0u) | (t2 == 1u ? L2 : 0u);
+    const u32 w = (md ^ flip) & valid;
+    const u32 s0 = w & L0, s1 = w & L1, s2 = w & L2;
+    const u32 p0 = s0 ? (u32)__builtin_ctz(s0) : nb, p1 = s1 ? (u32)__builtin_ctz(s1) : nb, p2 = (DIM == 3 && s2) ? (u32)__builtin_ctz(s2) : nb;
+    const u32 f0 = DIM == 3 ? (p0 * 171u) >> 9 : p0 >> 1, f1 = DIM == 3 ? (p1 * 171u) >> 9 : p1 >> 1, f2 = DIM == 3 ? (p2 * 171u) >> 9 : 0u;
+    const u32 cmp = (f1 >= f0 ? 1u : 0u) | (f2 >= f0 ? 2u : 0u) | (f2 >= f1 ? 4u : 0u);
+    const u32 e = s_lut[c27 * 8u + cmp];
+    if (d < inactive_below) return CTX_INACTIVE | (e & CTX_CODE_MASK);
+    return e | (t0 ? d - f0 : 0u) | ((t1 ? d - f1 : 0u) << 8) | ((t2 ? d - f2 : 0u) << 16);
+}
+template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
+    constexpr u32 DIM = KT<KIND>::DIM;
+    // (wave-uniform choice: one lane whose cell is deeper than 32 Morton bits sends the wave down the wide version)
+    if (ballot64(DIM * key_depth<KIND>(key) > 32u) == 0ull) return entry_ctx_lut_narrow<KIND>(key, c27, inactive_below, s_lut);
+    return entry_ctx_lut_wide<KIND>(key, c27, inactive_below, s_lut);
 }
 // owner-side words of an ancestor entry of depth dd whose own context word is ctx_j
 __device__ __forceinline__ u32 ctx_owner_dj(u32 dd) { return (dd | 32u) * 0x010101u; }
@@ -3341,37 +3370,30 @@ template <int DIM> constexpr CompactLut3<DIM> make_compact_lut3() {
 }
 __constant__ CompactLut3<3> g_compact_lut3_3d = make_compact_lut3<3>();
 __constant__ CompactLut3<2> g_compact_lut3_2d = make_compact_lut3<2>();
-template <int KIND> __device__ __forceinline__ void tree_expand(u64 comp, const TreeCompact& f, u64& key, u32& id, u32& c27,
-                                                                const unsigned short* lut3 = nullptr) {
-    constexpr u32 DIM = KT<KIND>::DIM, BASE = (1u << DIM) + 1u;
+// NSTEP: table reads the tail takes (1: T <= 3, 2: T <= 6 -- compile-time, so that the per-entry code has no branches on the
+// format), 0: any T, by table when lut3 is given, else digit by digit
+template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u64 comp, const TreeCompact& f, u64& key, u32& id, u32& c27,
+                                                                               const unsigned short* lut3 = nullptr) {
+    constexpr u32 DIM = KT<KIND>::DIM, BASE = (1u << DIM) + 1u, N3 = BASE * BASE * BASE;
     const u64 kp = comp >> f.low;
-    u32 t = (u32)kp & (u32)((1ull << f.tbits) - 1ull);  // (tbits <= 32: the host limits T so that the tail is a 32-bit number -- see launchers)
+    u32 t = (u32)kp & (u32)((1ull << f.tbits) - 1ull);  // (tbits <= 32: tree_compact_format keeps the tail a 32-bit number)
     u64 mort = 0;   // Morton bits of the levels dmin + 1 .. dmax, level dmax lowest
     u32 nlev = 0;
-    if (lut3) {
-        constexpr u32 N3 = BASE * BASE * BASE;
-        // three levels per table read, deepest first; the usual tail (T <= 6) is two reads and one division
-        u32 q = t / N3;
-        const u32 e0 = lut3[t - q * N3];
-        u32 m32 = e0 & 0xFFFu;
+    if constexpr (NSTEP == 1) {
+        const u32 e0 = lut3[t];
+        mort = e0 & 0xFFFu;
         nlev = e0 >> 12;
-        if (f.T > 3) {  // (wave-uniform)
-            const u32 r1 = f.T > 6 ? q % N3 : q;
-            const u32 e1 = lut3[r1];
-            m32 |= (e1 & 0xFFFu) << (3 * DIM);
-            nlev += e1 >> 12;
-            mort = m32;
-            if (f.T > 6) {
-                q /= N3;
-                for (int sh = 6 * (int)DIM, left = f.T - 6; left > 0; left -= 3, sh += 3 * (int)DIM) {
-                    const u32 q2 = q / N3, e = lut3[q - q2 * N3];
-                    mort |= (u64)(e & 0xFFFu) << sh;
-                    nlev += e >> 12;
-                    q = q2;
-                }
-            }
-        } else {
-            mort = m32;
+    } else if constexpr (NSTEP == 2) {
+        const u32 q = t / N3;
+        const u32 e0 = lut3[t - q * N3], e1 = lut3[q];
+        mort = (e0 & 0xFFFu) | ((e1 & 0xFFFu) << (3 * DIM));
+        nlev = (e0 >> 12) + (e1 >> 12);
+    } else if (lut3) {
+        for (int sh = 0, left = f.T; left > 0; left -= 3, sh += 3 * (int)DIM) {  // three levels per table read, deepest first
+            const u32 q = t / N3, e = lut3[t - q * N3];
+            mort |= (u64)(e & 0xFFFu) << sh;
+            nlev += e >> 12;
+            t = q;
         }
     } else {
         for (int k = 0; k < f.T; ++k) {
@@ -3397,8 +3419,8 @@ __global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ word
 // Grouped finish of a cell sort of composite words: tgroup_finish2_kernel<.., GAPPED> with ONE word per record -- one load per
 // entry, the bin and the rank straight from the word (inside a group the bits above comp_gshift are equal, inside a bin the next
 // TG2_BIN_BITS as well: the plain unsigned order of the words is the (index, id) order), expansion to index value / id / box byte /
-// context word while writing out.  ids_out / box_out may be null (a caller that derives them later).
-template <int CTX_KIND>
+// context word while writing out.
+template <int CTX_KIND, int NSTEP>
 __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
                                                                       u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                       uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
@@ -3486,10 +3508,10 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64*
     __syncthreads();
     for (u32 y = tid; y < ng; y += TGRP_THREADS) {
         u64 ky; u32 id, c27;
-        tree_expand<XK>(s_comp[y], fmt, ky, id, c27, s_lut3);
+        tree_expand<XK, NSTEP>(s_comp[y], fmt, ky, id, c27, s_lut3);
         keys_out[(size_t)lo + y] = ky;
-        if (ids_out) ids_out[(size_t)lo + y] = id;
-        if (box_out) box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
+        ids_out[(size_t)lo + y] = id;
+        box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
         idctx_out[(size_t)lo + y] = ((u64)id << 32) | (u64)entry_ctx_lut<CTX_KIND>(ky, c27, 0u, s_lut);
     }
 }
@@ -5309,13 +5331,21 @@ hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_gro
                                         const uint32_t* stats, uint32_t abort_over, const CellRoute& cells) {
     if (n_groups == 0) return hipSuccess;
     // (the kernel takes the index kind from its context-word instantiation: the compact route always writes the context words)
-    if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || ctx_kind < 0 || ctx_kind > 2 || !cells.src) return hipErrorInvalidValue;
-#define BP_TGC_LAUNCH(K)                                                                                                                   \
-    tgroup_finishc_kernel<K><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, box_out, \
-                                                                    (u64*)idctx_out, sc, stats, abort_over, cells.src)
-    if (ctx_kind == 0) BP_TGC_LAUNCH(0);
-    else if (ctx_kind == 1) BP_TGC_LAUNCH(1);
-    else BP_TGC_LAUNCH(2);
+    if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || !ids_out || !box_out || ctx_kind < 0 || ctx_kind > 2 || !cells.src)
+        return hipErrorInvalidValue;
+#define BP_TGC_LAUNCH(K, S)                                                                                                                   \
+    tgroup_finishc_kernel<K, S><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, box_out, \
+                                                                       (u64*)idctx_out, sc, stats, abort_over, cells.src)
+#define BP_TGC_STEPS(K)                          \
+    do {                                         \
+        if (fmt.T <= 3) BP_TGC_LAUNCH(K, 1);     \
+        else if (fmt.T <= 6) BP_TGC_LAUNCH(K, 2); \
+        else BP_TGC_LAUNCH(K, 0);                \
+    } while (0)
+    if (ctx_kind == 0) BP_TGC_STEPS(0);
+    else if (ctx_kind == 1) BP_TGC_STEPS(1);
+    else BP_TGC_STEPS(2);
+#undef BP_TGC_STEPS
 #undef BP_TGC_LAUNCH
     return hipGetLastError();
 }
