@@ -3420,26 +3420,33 @@ __global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ word
 // entry, the bin and the rank straight from the word (inside a group the bits above comp_gshift are equal, inside a bin the next
 // TG2_BIN_BITS as well: the plain unsigned order of the words is the (index, id) order), expansion to index value / id / box byte /
 // context word while writing out.
+#ifndef TGC_WAVES_PER_EU
+#define TGC_WAVES_PER_EU 8
+#endif
+constexpr int TGC_CAP = 2044;  // (words per group: with the offsets' 4112 bytes just under the 20480 bytes an eighth of a CU's LDS is)
+static_assert(TGC_CAP <= TGRP_CAP && (size_t)TGC_CAP * 8 + (TG2_BINS + 4) * 4 <= 20480, "tgroup_finishc: eight workgroups per CU");
 template <int CTX_KIND, int NSTEP>
-__global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
+__global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TGC_WAVES_PER_EU, TGC_WAVES_PER_EU))) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
                                                                       u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                       uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
                                                                       DevScalars* sc, const u32* __restrict__ stats, u32 abort_over,
                                                                       const uint4* __restrict__ cell_src) {
     static_assert(CTX_KIND >= 0 && CTX_KIND <= 2, "the compact route always writes the context words (CTX_KIND = the index kind)");
     constexpr int XK = CTX_KIND;
-    __shared__ u64 s_comp[TGRP_CAP];  // words grouped by bin while ranking, then in final order
-    __shared__ __attribute__((aligned(16))) u32 s_cnt[TG2_BINS];
-    __shared__ __attribute__((aligned(16))) u32 s_off[TG2_BINS + 4];
-    __shared__ u32 s_ws[TGRP_THREADS / 64];
-    __shared__ u32 s_lut[CTX_LUT_WORDS];
+    // LDS is what sets this kernel's occupancy, and occupancy its speed (six workgroups per CU: 0.269 ms, seven: 0.228 at 10 M
+    // objects): every array lives in one of two regions.  s_comp: the bins' arrival counters, then the words grouped by bin, then
+    // the words in final order (the counters' last read is the prefix scan's, two barriers before the first word is placed).
+    // s_off: the bins' offsets (+ the block scan's scratch behind them) while ranking, then -- the offsets are dead once every
+    // rank is known -- the two lookup tables of the write-out.  TGC_CAP words + 4112 bytes = 20464: eight workgroups per CU.
     constexpr int XDIM = (int)KT<XK>::DIM;
-    __shared__ __attribute__((aligned(4))) unsigned short s_lut3[CompactLut3<XDIM>::WORDS * 2];  // three tail digits -> their Morton bits and level count
-    for (int q = (int)threadIdx.x; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];  // visible after the barriers below
-    {
-        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
-        for (u32 q = threadIdx.x; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
-    }
+    __shared__ __attribute__((aligned(16))) u64 s_comp[TGC_CAP];
+    u32* const s_cnt = reinterpret_cast<u32*>(s_comp);
+    __shared__ __attribute__((aligned(16))) u32 s_off[TG2_BINS + 4];
+    u32* const s_ws = s_off + TG2_BINS;   // (four words: the block scan's scratch, then s_off[TG2_BINS] = the group's size)
+    u32* const s_lut = s_off;             // after the ranking
+    unsigned short* const s_lut3 = reinterpret_cast<unsigned short*>(s_off + CTX_LUT_WORDS);
+    static_assert((CTX_LUT_WORDS + CompactLut3<XDIM>::WORDS) <= TG2_BINS, "the write-out's tables fit the offsets' storage");
+    static_assert((size_t)TGC_CAP * 8 >= (size_t)TG2_BINS * 4, "the counters fit the words' storage");
     const u32 g = blockIdx.x, tid = threadIdx.x;
     if (stats && stats[1] > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
@@ -3448,7 +3455,7 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64*
     const uint4 si = cell_src[g];
     const u32 src_a = si.x, src_b = si.y, lo = si.z, ng = si.w >> 16, src_nf = si.w & 0xFFFFu;
     if (ng == 0) return;  // workgroup-uniform
-    if (ng > (u32)TGRP_CAP) {
+    if (ng > (u32)TGC_CAP) {
         if (tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
@@ -3475,7 +3482,7 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64*
         u32 total;
         const u32 excl = block_excl_scan_u32<TGRP_THREADS>(n4.x + n4.y + n4.z + n4.w, s_ws, total);
         reinterpret_cast<uint4*>(s_off)[tid] = make_uint4(excl, excl + n4.x, excl + n4.x + n4.y, excl + n4.x + n4.y + n4.z);
-        if (tid == 0) s_off[TG2_BINS] = ng;
+        if (tid == 0) s_off[TG2_BINS] = ng;   // (the scan's scratch is free: its last read lies before the scan's final barrier)
     }
     __syncthreads();
 #pragma unroll
@@ -3499,11 +3506,16 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finishc_kernel(const u64*
             slot[i] = start + rank;
         }
     }
-    __syncthreads();  // every rank is known: the buffer now takes the group in final order
+    __syncthreads();  // every rank is known: the buffer now takes the group in final order, the offsets' storage the tables
 #pragma unroll
     for (int i = 0; i < TGRP_ITEMS; ++i) {
         const u32 x = (u32)i * TGRP_THREADS + tid;
         if (x < ng) s_comp[slot[i]] = c[i];
+    }
+    for (int q = (int)tid; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];
+    {
+        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
+        for (u32 q = tid; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
     }
     __syncthreads();
     for (u32 y = tid; y < ng; y += TGRP_THREADS) {
@@ -5354,7 +5366,7 @@ hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, size
     BP_DISPATCH_KIND(kind, (tree_expand_kernel<K><<<grid_for(n, 256, 4096), 256, 0, stream>>>((u64*)words, ids_out, n, fmt)));
     return hipGetLastError();
 }
-int tgroup_capacity() { return TGRP_CAP; }
+int tgroup_capacity() { return TGC_CAP < TGRP_CAP ? TGC_CAP : TGRP_CAP; }  // (what every finish kernel of the grouped plan takes)
 int tgroup_bin_bits() { return TGRP_BIN_BITS; }
 
 hipError_t launch_tree_segment_finish(const uint64_t* keys_in, const uint32_t* ids_in, size_t m, int seg_shift,
