@@ -152,21 +152,30 @@ def cpu_baseline(n_objects, seed):
 EVENT_EVERY = 4   # the timed region's HIP events bracket the dominant class in every 4th frame (run_single)
 
 
-def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False):
+def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False, tree_compact=False):
     """cells / tree_cells: the timed frames' pair / tree sorts took the cell route (bp_stats.sorts_in_cells, tree_sorts_in_cells:
-    two claiming passes, no stable pass)"""
-    tree_sort = ("radix_claim_kernel<u32, false> + radix_claim_kernel<u32, true> (tree-sort passes: both claim whole aligned lines -- by the "
-                 "high digit, then every high bin into cells laid out from the previous sort's group sizes; no stable pass)") if tree_cells else \
-                ("radix_claim_kernel<u32, false> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, "
-                 "the second is the stable one-sweep pass)")
-    pair_sort = ("radix_claim_kernel<NoVal, false> + radix_claim_kernel<NoVal, true> (pair-sort passes: both claim whole aligned lines -- by the "
+    two claiming passes, no stable pass); tree_compact: the tree went through encode -> passes -> finish as 8-byte compact records
+    (bp_stats.tree_sorts_compact) -- the tree classes' bytes are then what these kernels move (less than SURVEY 8(d)'s 12-byte entries)"""
+    if tree_compact:
+        tree_sort = ("radix_claim_kernel<NoVal, false, 1> + radix_claim_kernel<NoVal, true, 1> (tree-sort passes on compact 8-byte records: index bits | "
+                     "id | box code in one word; both claim whole aligned lines -- by the high digit, then every high bin into cells laid out "
+                     "from the previous sort's group sizes; no stable pass)")
+    elif tree_cells:
+        tree_sort = ("radix_claim_kernel<u32, false, 0> + radix_claim_kernel<u32, true, 0> (tree-sort passes: both claim whole aligned lines -- by the "
+                     "high digit, then every high bin into cells laid out from the previous sort's group sizes; no stable pass)")
+    else:
+        tree_sort = ("radix_claim_kernel<u32, false, 0> + radix_onesweep_kernel<u64,u32> (tree-sort passes: the first claims whole aligned lines, "
+                     "the second is the stable one-sweep pass)")
+    pair_sort = ("radix_claim_kernel<NoVal, false, 0> + radix_claim_kernel<NoVal, true, 0> (pair-sort passes: both claim whole aligned lines -- by the "
                  "high digit, then every high bin into cells laid out from the previous frame's group sizes; no stable pass)") if cells else \
-                ("radix_claim_kernel<NoVal, false> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, "
+                ("radix_claim_kernel<NoVal, false, 0> + radix_onesweep_kernel<u64,NoVal> (pair-sort passes: the first claims whole aligned lines, "
                  "the second is the stable one-sweep pass)")
     return {
-        "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)", 28.0 * n + 12.0 * M),
-        "tree_sort": (tree_sort, 24.0 * M),
-        "tree_finish": ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
+        "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)",
+                   28.0 * n + (8.0 if tree_compact else 12.0) * M),
+        "tree_sort": (tree_sort, (16.0 if tree_compact else 24.0) * M),
+        "tree_finish": ("tgroup_finishc_kernel (LDS finish of the tree sort: compact records in, index values + ids + context words out)", 8.0 * M + 12.0 * M)
+                       if tree_compact else ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
         "pair_sort": (pair_sort, 16.0 * P_raw),
         "dedup": ("group_finish_kernel (LDS finish of the pair sort + dedup)", 8.0 * P_raw + 8.0 * P),
@@ -216,7 +225,7 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     st = layer.stats()
     table = kernel_table(n, st["entries"], st["raw_pairs"], st["pairs"])
     dom_cls = max(table, key=lambda c: wprof[c][0])
-    cells0, tcells0 = layer.stats()["sorts_in_cells"], layer.stats()["tree_sorts_in_cells"]
+    cells0, tcells0, tcomp0 = layer.stats()["sorts_in_cells"], layer.stats()["tree_sorts_in_cells"], layer.stats()["tree_sorts_compact"]
     # timed region: events only around the dominant class (every event pair costs a few us of stream bubble)
     layer.profile_reset(); layer.profile_select([dom_cls]); layer.profile_enable(events)
     every = EVENT_EVERY if steps >= 4 * EVENT_EVERY else 2 if steps >= 4 else 1   # (at least two timed frames)
@@ -228,6 +237,7 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
     res["host_syncs_per_step"] = (layer.stats()["host_syncs"] - syncs0) / steps
     res["cell_route"] = (layer.stats()["sorts_in_cells"] - cells0) == steps   # every timed frame's pair sort took the cell route
     res["tree_cell_route"] = (layer.stats()["tree_sorts_in_cells"] - tcells0) == steps
+    res["tree_compact_route"] = (layer.stats()["tree_sorts_compact"] - tcomp0) == steps
     layer.profile_enable(False)
     res["dom_cls"], res["dom_prof"] = dom_cls, layer.profile()[dom_cls]
     if detail:
@@ -541,7 +551,8 @@ def single_gpu_line(args, r, np):
     n_pairs = r["n_pairs"]
     M, P_raw, P = st["entries"], st["raw_pairs"], st["pairs"]
     pk, pp = st["tree_sort_passes"], st["pair_sort_passes"]
-    table = kernel_table(n, M, P_raw, P, cells=bool(r.get("cell_route")), tree_cells=bool(r.get("tree_cell_route")))
+    compact = bool(r.get("tree_compact_route"))
+    table = kernel_table(n, M, P_raw, P, cells=bool(r.get("cell_route")), tree_cells=bool(r.get("tree_cell_route")), tree_compact=compact)
     k = r["detail_steps"]
     launches = {c: v[1] / k for c, v in prof.items()}
     per_step_ms = {c: v[0] / k for c, v in prof.items()}
@@ -563,9 +574,10 @@ def single_gpu_line(args, r, np):
     achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     # bytes this pipeline really has to move per step (its own kernels' reads + writes)
     moved = {
-        "encode": 28.0 * n + 4.0 * n + 12.0 * M,                 # bounds + ids read once, entries written (box code rides in the id)
-        "tree_sort": 24.0 * M * pk,
-        "tree_finish": 12.0 * M + 21.0 * M,                       # key + id read; key, id, box byte, {id, ctx} word written
+        # (compact records: one 8-byte word per entry from the emit pass to the finish instead of a 12-byte (index, id) entry)
+        "encode": 28.0 * n + 4.0 * n + 16.0 * n * 2 + (8.0 if compact else 12.0) * M,  # bounds + ids read once, the 16-byte object record written and read, entries written
+        "tree_sort": (16.0 if compact else 24.0) * M * pk,
+        "tree_finish": (8.0 if compact else 12.0) * M + 21.0 * M,  # record read; key, id, box byte, {id, ctx} word written
         "scan_emit": 16.0 * M + 8.0 * P_raw,                      # keys + {id, ctx} words read, packed pairs written
         "pair_sort": 16.0 * P_raw * pp,
         "dedup": 8.0 * P_raw + 8.0 * P,
@@ -584,7 +596,8 @@ def single_gpu_line(args, r, np):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,  # the N = 1 point of either curve
         "dtype": "u64", "data": "synthetic",
         "pair_sort_route": "cells (two claiming passes; every timed frame)" if r.get("cell_route") else "claiming pass + stable one-sweep pass",
-        "tree_sort_route": "cells (two claiming passes; every timed frame)" if r.get("tree_cell_route") else "claiming pass + stable one-sweep pass",
+        "tree_sort_route": ("cells (two claiming passes; every timed frame)" if r.get("tree_cell_route") else "claiming pass + stable one-sweep pass") +
+                           ("; compact 8-byte records (every timed frame)" if compact else ""),
         "config": {"workload": ("%s%dM Index64_3D uniform-random AABBs, single MI355X (gen_boxes recipe, density 0.001, "
                                 "sizes U[1,10)), clear+extend+par_sort+par_scan, inputs and pair list HBM-resident"
                                 % ("configs[2]: " if n == 10_000_000 else "", n // 1_000_000)) if n % 1_000_000 == 0

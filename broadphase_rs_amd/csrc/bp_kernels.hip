@@ -1182,7 +1182,9 @@ __device__ __forceinline__ u32 frag_pos(const BinGeom& g, u32 q) { return q < g.
 #ifndef SW_EXP
 #define SW_EXP 0  // timing experiments (results are WRONG): 1 no key stores
 #endif
-template <typename V, bool CELLS = false>
+// TAG: no effect on the code -- key-only passes over the tree's compact records (TAG = 1) get a kernel name of their own, so
+// that a profile tells them from the pair sort's passes (same template otherwise, 2.6 times the records)
+template <typename V, bool CELLS = false, int TAG = 0>
 __global__ __launch_bounds__(RC_THREADS) void radix_claim_kernel(ClaimArgs a) {
     typedef u64 K;
     constexpr int T = RC_THREADS, ITEMS = RC_ITEMS, TILE = RC_TILE;
@@ -3741,14 +3743,14 @@ size_t radix_workspace_bytes(size_t n, int n_passes) {
 }
 
 // the claiming first pass (radix_claim_kernel): one persistent workgroup per CU
-template <typename V, bool CELLS = false>
+template <typename V, bool CELLS = false, int TAG = 0>
 static hipError_t launch_claim(const ClaimArgs& a, hipStream_t stream) {
 #ifndef RS_GEOMETRY_EXPERIMENT
     static_assert(RC_TILE == RS_THREADS_DEF * RS_ITEMS_DEF, "the pass kernels share the tile size (holes, workspace)");
 #endif
-    static const unsigned resident = resident_blocks(radix_claim_kernel<V, CELLS>, RC_THREADS);
+    static const unsigned resident = resident_blocks(radix_claim_kernel<V, CELLS, TAG>, RC_THREADS);
     const unsigned grid = a.n_tiles < resident ? a.n_tiles : resident;
-    radix_claim_kernel<V, CELLS><<<grid, RC_THREADS, 0, stream>>>(a);
+    radix_claim_kernel<V, CELLS, TAG><<<grid, RC_THREADS, 0, stream>>>(a);
     return hipGetLastError();
 }
 
@@ -4053,7 +4055,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         a.n_tiles = (u32)rs_num_tiles(a.n);
         a.dev_sizes = dev_sizes;
         if (mark) mark(mark_ctx, class_sort);
-        e = vals0 ? launch_claim<u32>(a, stream) : launch_claim<NoVal>(a, stream);
+        const bool tree_words = !vals0 && cells->out_keys != nullptr;  // (the tree's compact records: a kernel name of their own)
+        e = vals0 ? launch_claim<u32>(a, stream) : tree_words ? launch_claim<NoVal, false, 1>(a, stream) : launch_claim<NoVal>(a, stream);
         if (mark) mark(mark_ctx, -1);
         if (e != hipSuccess) return e;
         // the gapped result: in keys0 (key-only sorts) or in the buffers the caller set aside for it
@@ -4068,7 +4071,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
         b.cell_base = cells->cell_base; b.cell_line_cur = cells->line_cur; b.cell_frag_cur = cells->frag_cur; b.miss = cells->miss;
         if (((size_t)gk & 127u) != 0) return hipErrorInvalidValue;  // cell bases are whole lines of a line-aligned buffer
         if (mark) mark(mark_ctx, class_sort);
-        e = vals0 ? launch_claim<u32, true>(b, stream) : launch_claim<NoVal, true>(b, stream);
+        e = vals0 ? launch_claim<u32, true>(b, stream) : tree_words ? launch_claim<NoVal, true, 1>(b, stream) : launch_claim<NoVal, true>(b, stream);
         if (mark) mark(mark_ctx, -1);
         if (e != hipSuccess) return e;
         *result_buf = 0;  // (key-only: keys0; with a payload: cells->out_keys / out_vals)
