@@ -4881,20 +4881,25 @@ hipError_t launch_unique_emit(const uint64_t* sorted, size_t n, const unsigned l
 constexpr int GRP_THREADS = GRP_THREADS_MACRO, GRP_CAP = 4096, GRP_ITEMS = GRP_CAP / GRP_THREADS, GRP_MAX_BITS = 8;
 constexpr u32 GRP_SEG_MAX = 4096;  // an id with more pairs than this: fall back (the rank loop is quadratic in it)
 constexpr u32 GRP_SLOW_MAX = 16u * GRP_CAP;
-constexpr u32 GRP_SUB = 4;  // sub-bins per id by the top bits of the second id (fast path)  // larger groups than this are not attempted
+#ifndef GRP_SUB_DEF
+#define GRP_SUB_DEF 8
+#endif
+constexpr u32 GRP_SUB = GRP_SUB_DEF;  // sub-bins per id by the range of the second id (fast path)
 template <bool GAPPED>
 __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __restrict__ in, const u32* __restrict__ bounds, u32 g0,
-                                                                   int gbits, int sshift, uint2* __restrict__ out, DevScalars* sc,
+                                                                   int gbits, u32 sub_scale, uint2* __restrict__ out, DevScalars* sc,
                                                                    const u32* __restrict__ stats, u32 abort_over,
                                                                    const u32* __restrict__ dev_sizes, CellRoute cells) {
     if (dev_sizes) abort_over = dev_sizes[SIZES_N] / 4u;
-    // bins of the fast path: id within the group x GRP_SUB ranges of the second id (second >> sshift, clamped): shorter
-    // bins, shorter rank loops (their cost is quadratic in the bin length)
+    // bins of the fast path: id within the group x GRP_SUB equal ranges of the second id (second * sub_scale >> 32, clamped):
+    // about one pair per bin -- the rank loops are what this kernel spends its instructions on (their cost is quadratic in the
+    // bin length, and a wave runs to the longest bin of its 64 lanes)
     constexpr u32 NBINS = 256u * GRP_SUB;
-    static_assert(NBINS == 2u * GRP_THREADS, "two bins per thread in the prefix scan");
-    __shared__ u32 s_second[GRP_CAP];  // second ids grouped by bin for the rank loops (then, GRP_DIRECT_STORE 0, the group in final order)
-    __shared__ uint8_t s_binof[GRP_DIRECT_STORE ? 1 : GRP_CAP];
-    __shared__ u32 s_cnt[NBINS], s_off[NBINS + 1], s_cur[NBINS];
+    static_assert(NBINS == 4u * GRP_THREADS, "four bins per thread in the prefix scan");
+    __shared__ u32 s_second[GRP_CAP + 8];  // second ids grouped by bin for the rank loops (+ 8: the rank loop's unconditional reads)
+    __shared__ __attribute__((aligned(16))) u32 s_cnt[NBINS];
+    __shared__ __attribute__((aligned(16))) u32 s_off[NBINS + 4];
+    __shared__ u32 s_cur[256];             // (the rounds of an oversize group)
     __shared__ u32 s_ws[GRP_THREADS / 64];
     const u32 g = blockIdx.x, tid = threadIdx.x;
     // most pairs sit in oversize groups (ids that follow the scene's clusters): rounds over every such group would cost far
@@ -4973,11 +4978,10 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         return;
     }
     auto bin_of = [&](u64 v) {
-        const u32 sub = min((u32)v >> sshift, GRP_SUB - 1u);
+        const u32 sub = min(__umulhi((u32)v, sub_scale), GRP_SUB - 1u);  // (monotone in the second id)
         return (((u32)(v >> 32) & bmask) * GRP_SUB) | sub;
     };
-    s_cnt[2u * tid] = 0;
-    s_cnt[2u * tid + 1u] = 0;
+    reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
     u64 v[GRP_ITEMS];
 #pragma unroll
     for (int k = 0; k < GRP_ITEMS; ++k) {
@@ -4997,13 +5001,12 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         }
     }
     __syncthreads();
-    const u32 c0 = s_cnt[2u * tid], c1 = s_cnt[2u * tid + 1u];
+    const uint4 c4 = reinterpret_cast<const uint4*>(s_cnt)[tid];
     u32 total;
-    const u32 excl = block_excl_scan_u32<GRP_THREADS>(c0 + c1, s_ws, total);
-    s_off[2u * tid] = excl;
-    s_off[2u * tid + 1u] = excl + c0;
+    const u32 excl = block_excl_scan_u32<GRP_THREADS>(c4.x + c4.y + c4.z + c4.w, s_ws, total);
+    reinterpret_cast<uint4*>(s_off)[tid] = make_uint4(excl, excl + c4.x, excl + c4.x + c4.y, excl + c4.x + c4.y + c4.z);
     if (tid == 0) s_off[NBINS] = ng;
-    const bool heavy = max(c0, c1) > GRP_SEG_MAX;
+    const bool heavy = max(max(c4.x, c4.y), max(c4.z, c4.w)) > GRP_SEG_MAX;
     if (__any(heavy) && lane_id() == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
     __syncthreads();
 #pragma unroll
@@ -5019,11 +5022,17 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         dst[k] = 0;
         if (x < ng) {
             const u32 b = ticket[k] >> 16, vb = (u32)v[k];
-            const u32 start = s_off[b], end = s_off[b + 1];
-            u32 rank = 0;
-            if (end - start <= GRP_SEG_MAX) {  // longer: the host discards this output
-#pragma unroll 4
-                for (u32 y = start; y < end; ++y) rank += s_second[y] < vb ? 1u : 0u;
+            const u32 start = s_off[b], len = s_off[b + 1] - start;
+            // the bin's first four unconditionally (what lies behind a shorter bin is masked by the length: straight-line code,
+            // no loop for nine bins in ten) -- the general loop the compiler made of this (unrolled by 8, by 4, remainder, each
+            // behind its own exec-mask bookkeeping) cost ~100 instructions per pair for bins of two
+            const u32* const q = s_second + start;
+            const u32 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];  // (all four issued together, whatever the length)
+            u32 rank = ((u32)(len > 0u) & (u32)(q0 < vb)) + ((u32)(len > 1u) & (u32)(q1 < vb)) + ((u32)(len > 2u) & (u32)(q2 < vb)) +
+                       ((u32)(len > 3u) & (u32)(q3 < vb));
+            if (len > 4u && len <= GRP_SEG_MAX) {  // (longer than GRP_SEG_MAX: the host discards this output)
+#pragma unroll 1
+                for (u32 y = 4u; y < len; ++y) rank += q[y] < vb ? 1u : 0u;
             }
             dst[k] = start + rank;
         }
@@ -5043,12 +5052,12 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         const u32 x = (u32)k * GRP_THREADS + tid;
         if (x < ng) {
             s_second[dst[k]] = (u32)v[k];
-            s_binof[dst[k]] = (uint8_t)((u32)(v[k] >> 32) & bmask);
+            reinterpret_cast<uint8_t*>(s_cnt)[dst[k]] = (uint8_t)((u32)(v[k] >> 32) & bmask);  // (the counters are dead: their storage takes the ids)
         }
     }
     __syncthreads();
     const u32 first_base = (g0 + g) << gbits;
-    for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)s_binof[x], s_second[x]);
+    for (u32 x = tid; x < ng; x += GRP_THREADS) out[(size_t)lo + x] = make_uint2(first_base | (u32)reinterpret_cast<const uint8_t*>(s_cnt)[x], s_second[x]);
 #endif
 }
 hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, uint32_t g0, int gbits, uint32_t* bounds,
@@ -5063,14 +5072,14 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
                          : launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream, dev_sizes);
     if (e != hipSuccess) return e;
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
-    int bits = 0;
-    while (bits < 32 && (second_max >> bits) != 0) ++bits;
-    const int sshift = bits > 2 ? bits - 2 : 0;
+    // second ids at most second_max: GRP_SUB equal ranges of them split every id's pairs (second * scale >> 32; larger values are clamped)
+    const unsigned long long scale64 = ((unsigned long long)GRP_SUB << 32) / ((unsigned long long)second_max + 1ull);
+    const u32 sub_scale = scale64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)scale64;
     if (cells)
-        group_finish_kernel<true><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
+        group_finish_kernel<true><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sub_scale, (uint2*)pairs_out, sc, stats,
                                                                         (u32)(n / 4), dev_sizes, *cells);
     else
-        group_finish_kernel<false><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sshift, (uint2*)pairs_out, sc, stats,
+        group_finish_kernel<false><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sub_scale, (uint2*)pairs_out, sc, stats,
                                                                          (u32)(n / 4), dev_sizes, CellRoute{});
     return hipGetLastError();
 }
