@@ -264,16 +264,14 @@ template <int DIM> __device__ __forceinline__ u64 dilated_next(u64 m, u32 up) {
     return ((m | ~LANE) + (1ull << (DIM * up))) & LANE;
 }
 
-// COMPACT (with pack_box): one composite word per entry goes to keys_out (TreeCompact: index bits that vary | id | box code) and
-// nothing to ids_out / box_out; the digits counted are the composite's
-template <int KIND, bool CELLS, bool COMPACT = false>
+template <int KIND, bool CELLS>
 __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, const float* __restrict__ bounds,
                                                                  const u32* __restrict__ ids, size_t n, u32 min_depth,
                                                                  const uint4* __restrict__ recs,
                                                                  const u64* __restrict__ block_offs,
                                                                  u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                  uint8_t* __restrict__ box_out, DigitCount dc, int pack_box,
-                                                                 DevScalars* sc_guard, u64 capacity, TreeCompact fmt) {
+                                                                 DevScalars* sc_guard, u64 capacity) {
     // pack_box: the box code rides in bits 27..31 of the id from the start (ids < 2^27, see BOX_ID_BITS) and
     // no box byte is written: the first pass of the tree sort then has no byte stream to gather
     // sc_guard / capacity (launch without a host round trip after the count pass): sc_guard->total is the entry total the
@@ -305,35 +303,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     // A round's entries (<= 8 per object unless min_depth forces more) are staged in LDS in output order and
     // stored with consecutive threads on consecutive entries; a round that does not fit stores directly.
     __shared__ u64 s_key[ENC_STAGE];
-    __shared__ u32 s_id[COMPACT ? 1 : ENC_STAGE];
-    __shared__ uint8_t s_box[COMPACT ? 1 : ENC_STAGE];
-    // COMPACT: index value -> composite word (TreeCompact): the Morton bits of the levels every entry has, the deeper levels as
-    // digits 1 + octant in base 2^DIM + 1 (0 below the entry's own depth), then id and code.  tail = sum over the levels the entry
-    // has of (1 + octant) BASE^(T - k) = sum over ALL tail levels of octant BASE^(T - k) (the index value has zeros below its
-    // depth) + (BASE^T - BASE^(T - nlev)) / (BASE - 1): two instructions per level and one table read per object
-    constexpr u32 CBASE = (1u << DIM) + 1u;
-    __shared__ u32 s_pow[COMPACT ? 16 : 1];
-    if (COMPACT) {
-        if (threadIdx.x == 0) {
-            u32 pw = 1;
-            for (int k = 0; k <= fmt.T && k < 16; ++k) { s_pow[k] = pw; pw *= CBASE; }
-        }
-        // (visible after the barriers of the first round's block scan)
-    }
-    const int c_tsh = fmt.pshift - (int)DIM * fmt.T;  // the tail levels' Morton bits start here in the index value
-    // depth term of the tail for an entry of depth `depth` (>= dmin: the host checks the frame's depths against the format)
-    auto comp_depth_term = [&](u32 depth) -> u32 {
-        const u32 nlev = min(depth - fmt.dmin, (u32)fmt.T);
-        return (s_pow[fmt.T] - s_pow[(u32)fmt.T - nlev]) >> DIM;
-    };
-    auto comp_of = [&](u64 key, u32 dterm, u32 idcode) -> u64 {
-        const u64 kk = key >> c_tsh;                           // [prefix | Morton bits of the tail levels]
-        const u32 lv = (u32)kk;                                // (DIM * T <= 30 bits of it are the tail's)
-        u32 tail = 0;
-        for (int k = 1; k <= fmt.T; ++k)                       // (wave-uniform trip count)
-            tail = tail * CBASE + ((lv >> ((int)DIM * (fmt.T - k))) & ((1u << DIM) - 1u));
-        return (((kk >> ((int)DIM * fmt.T)) << fmt.tbits | (u64)(tail + dterm)) << fmt.low) | (u64)idcode;
-    };
+    __shared__ u32 s_id[ENC_STAGE];
+    __shared__ uint8_t s_box[ENC_STAGE];
     size_t round_base = (size_t)block_offs[blockIdx.x];
     for (int round = 0; round < ENC_ROUNDS; ++round) {
         const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
@@ -347,9 +318,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
         round_base += total;
         const bool staged = total <= (u32)ENC_STAGE;  // workgroup-uniform
         auto put = [&](u32 local, u64 key, u32 idv, u32 code) {
-            if (COMPACT) {  // (key is the composite already)
-                if (staged) s_key[local] = key; else keys_out[this_base + local] = key;
-            } else if (staged) {
+            if (staged) {
                 s_key[local] = key;
                 s_id[local] = idv;
                 s_box[local] = (uint8_t)code;
@@ -365,9 +334,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             if (rec.w & ENC_REC_OK) {
                 const u32 depth = rec.w & 0xFFu;
                 if (depth == 0) {  // Index::default(): src/geom.rs:203-205 / 261-263
-                    const u64 k0 = COMPACT ? comp_of(0ull, comp_depth_term(0u), id << 5) : 0ull;
-                    put(local, k0, id, 0u);  // box code 0 packs to 0
-                    count_digits(k0);
+                    put(local, 0ull, id, 0u);  // box code 0 packs to 0
+                    count_digits(0ull);
                 } else {
                     // at most two cells per axis: both Morton lanes of every axis once per object (the second from the first by
                     // a dilated increment), an entry is then two ORs; cells in z outer, y, x inner order: src/geom.rs:271-297
@@ -385,17 +353,6 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                     }
                     // box code of the first cell (ternary, the form that rides in the id) and what a step on each axis adds
                     const u32 t0 = s0 + 3u * s1 + 9u * s2, idp = pack_box ? id : 0u;
-                    if (COMPACT) {
-                        const u32 dterm = comp_depth_term(depth), idc0 = (id << 5) | t0;
-                        for (u32 e = 0; e < cnt; ++e) {
-                            const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
-                            const u64 key = key0 ^ (x ? dx : 0ull) ^ (y ? dy : 0ull) ^ (z ? dz : 0ull);
-                            const u64 comp = comp_of(key, dterm, idc0 + x + 3u * y + 9u * z);
-                            if (staged) s_key[local] = comp; else keys_out[this_base + local] = comp;
-                            count_digits(comp);
-                            ++local;
-                        }
-                    } else
                     for (u32 e = 0; e < cnt; ++e) {
                         const u32 x = e & s0, y = (e >> s0) & s1, z = e >> (s0 + s1);
                         const u64 key = key0 ^ (x ? dx : 0ull) ^ (y ? dy : 0ull) ^ (z ? dz : 0ull);
@@ -415,8 +372,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
                 for (u32 z = 0; z < c.n[2]; ++z)
                     for (u32 y = 0; y < c.n[1]; ++y)
                         for (u32 x = 0; x < c.n[0]; ++x) {
-                            u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
-                            if (COMPACT) key = comp_of(key, comp_depth_term(c.depth), (id << 5) | (u32)BOX_PACKED_UNKNOWN);
+                            const u64 key = make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z);
                             put(local, key, pack_box ? (id | (box_to_packed((u32)BOX_UNKNOWN) << BOX_ID_BITS)) : id, (u32)BOX_UNKNOWN);
                             count_digits(key);
                             ++local;
@@ -427,10 +383,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
             __syncthreads();
             for (u32 k = threadIdx.x; k < total; k += ENC_THREADS) {
                 keys_out[this_base + k] = s_key[k];
-                if (!COMPACT) {
-                    ids_out[this_base + k] = s_id[k];
-                    if (box_out) box_out[this_base + k] = s_box[k];
-                }
+                ids_out[this_base + k] = s_id[k];
+                if (box_out) box_out[this_base + k] = s_box[k];
             }
             __syncthreads();  // the stage is reused by the next round
         }
@@ -445,6 +399,202 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_kernel(SysBounds sb, 
     }
     if (dc.passes) {  // workgroup-uniform.  One device atomic per bin per workgroup would serialise on the bin's
         __syncthreads();  // address (~11 ns each): the workgroups spread over HIST_COPIES copies, summed by the sort
+        u64* copy = dc.hist + (size_t)(blockIdx.x % HIST_COPIES) * (SX_HIST_MAX * 256);
+        for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) {
+            const u32 v = s_hist[k];
+            if (v) atomicAdd(&copy[k], (u64)v);
+        }
+    }
+}
+
+// The emit pass for COMPACT records (TreeCompact, bp_kernels.h): one composite word per entry -- index bits | id | box code --
+// goes to words_out and nothing else is written; the digits counted are the composite's.  One thread per ENTRY, not per object:
+// a thread per object runs its cell loop to the wave's longest (eight cells, with 3.4 on average: two lanes in five busy).  Here
+// every lane prepares its object (first cell's index value, what a step on each axis changes in it, id, code, depth term) and
+// leaves it in LDS; the wave's entries -- consecutive in the output -- are then dealt to the lanes 64 at a time, an entry finds
+// its object from a row of end-of-range bits (v_mbcnt: the expanding scan's device) and the words leave coalesced, without a
+// staging pass.  A round with an object of more than two cells on an axis (min_depth forced it) takes the per-object loop.
+template <int KIND>
+__global__ __launch_bounds__(ENC_THREADS) void encode_emit_compact_kernel(SysBounds sb, const float* __restrict__ bounds,
+                                                                          const u32* __restrict__ ids, size_t n, u32 min_depth,
+                                                                          const uint4* __restrict__ recs, const u64* __restrict__ block_offs,
+                                                                          u64* __restrict__ words_out, DigitCount dc, DevScalars* sc_guard,
+                                                                          u64 capacity, TreeCompact fmt, int key_shift_delta) {
+    constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB, CBASE = (1u << DIM) + 1u;
+    if (sc_guard && sc_guard->total > capacity) {  // grid-uniform
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc_guard->err, (u32)KERR_ENCODE_OVERFLOW);
+        return;
+    }
+    constexpr int NW = ENC_THREADS / 64;
+    __shared__ u32 s_ws[NW];
+    __shared__ u32 s_hist[SX_HIST_MAX * 256];
+    __shared__ u32 s_pow[16];
+    __shared__ __attribute__((aligned(16))) uint4 s_obj[NW][3][64];  // per wave and object with entries: {key0, dx} {dy, dz} {id << 5 | code, depth term, first entry | cell bits}
+    __shared__ u64 s_ends[NW][8];                                     // bit e: some object's last entry is the wave's entry e
+    for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) s_hist[k] = 0;  // visible after the scan's barriers
+    if (threadIdx.x == 0) {
+        u32 pw = 1;
+        for (int k = 0; k <= fmt.T && k < 16; ++k) { s_pow[k] = pw; pw *= CBASE; }
+    }
+    auto count_digits = [&](u64 key) {
+#pragma unroll
+        for (int q = 0; q < SX_HIST_MAX; ++q) {
+            if (q < dc.passes)
+                __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(key >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // index value -> composite word: the Morton bits of the levels every entry has, the deeper levels as digits 1 + octant in base
+    // 2^DIM + 1 (0 below the entry's own depth), then id and code.  tail = sum over the levels the entry has of (1 + octant)
+    // BASE^(T - k) = sum over ALL tail levels of octant BASE^(T - k) (the index value has zeros below its depth) + (BASE^T -
+    // BASE^(T - nlev)) / (BASE - 1): two instructions per level and one table read per object
+    const int c_tsh = fmt.pshift - (int)DIM * fmt.T;  // the tail levels' Morton bits start here in the index value
+    auto comp_depth_term = [&](u32 depth) -> u32 {    // (depth >= dmin: the host checks the frame's depths against the format)
+        const u32 nlev = min(depth - fmt.dmin, (u32)fmt.T);
+        return (s_pow[fmt.T] - s_pow[(u32)fmt.T - nlev]) >> DIM;
+    };
+    auto comp_of = [&](u64 key, u32 dterm, u32 idcode) -> u64 {
+        const u64 kk = key >> c_tsh;                           // [prefix | Morton bits of the tail levels]
+        const u32 lv = (u32)kk;                                // (DIM * T <= 30 bits of it are the tail's)
+        u32 tail = 0;
+        for (int k = 1; k <= fmt.T; ++k)                       // (wave-uniform trip count)
+            tail = tail * CBASE + ((lv >> ((int)DIM * (fmt.T - k))) & ((1u << DIM) - 1u));
+        return (((kk >> ((int)DIM * fmt.T)) << fmt.tbits | (u64)(tail + dterm)) << fmt.low) | (u64)idcode;
+    };
+    const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    size_t round_base = (size_t)block_offs[blockIdx.x];
+    // (a round's record and id are loaded a round ahead: the round then starts with its block scan, not with a memory latency)
+    const size_t i0 = (size_t)blockIdx.x * ENC_ROUNDS * ENC_THREADS + threadIdx.x;
+    uint4 rec_next = i0 < n ? recs[i0] : make_uint4(0u, 0u, 0u, 0u);
+    u32 id_next = i0 < n ? ids[i0] : 0u;
+    for (int round = 0; round < ENC_ROUNDS; ++round) {
+        const size_t blk = (size_t)blockIdx.x * ENC_ROUNDS + round;
+        if (blk * ENC_THREADS >= n) break;  // workgroup-uniform
+        const size_t i = blk * ENC_THREADS + threadIdx.x;
+        const uint4 rec = rec_next;
+        const u32 id = id_next;
+        if (round + 1 < ENC_ROUNDS) {
+            const size_t i1 = i + ENC_THREADS;
+            rec_next = i1 < n ? recs[i1] : make_uint4(0u, 0u, 0u, 0u);
+            id_next = i1 < n ? ids[i1] : 0u;
+        }
+        const u32 cnt = enc_rec_count(rec);
+        u32 total;
+        const u32 excl = block_excl_scan_u32<ENC_THREADS>(cnt, s_ws, total);  // (its barriers also fence the previous round's LDS use)
+        const size_t this_base = round_base;
+        round_base += total;
+        if (__syncthreads_or((rec.w & ENC_REC_SLOW) != 0u)) {
+            // an object that spans more than two cells on an axis: every thread walks its own object's cells
+            if (cnt != 0) {
+                u32 local = excl;
+                if (rec.w & ENC_REC_OK) {
+                    const u32 depth = rec.w & 0xFFu;
+                    const u32 n0 = (rec.w >> 8) & 3u, n1 = (rec.w >> 10) & 3u, n2 = DIM == 3 ? (rec.w >> 12) & 3u : 1u;
+                    const u32 dterm = comp_depth_term(depth);
+                    for (u32 z = 0; z < n2; ++z)
+                        for (u32 y = 0; y < n1; ++y)
+                            for (u32 x = 0; x < n0; ++x) {
+                                const u64 key = depth == 0 ? 0ull : make_key<KIND>(depth, rec.x + x, rec.y + y, rec.z + z);
+                                const u32 packed = (n0 - 1u + x) * (n0 > 1u) + 3u * (n1 - 1u + y) * (n1 > 1u) + 9u * (n2 - 1u + z) * (n2 > 1u);
+                                const u64 comp = comp_of(key, dterm, (id << 5) | packed);
+                                words_out[this_base + local] = comp;
+                                count_digits(comp);
+                                ++local;
+                            }
+                } else {
+                    const Cells<KIND> c = object_cells<KIND>(sb, bounds + i * (2 * DIM), min_depth);
+                    const u32 dterm = comp_depth_term(c.depth);
+                    for (u32 z = 0; z < c.n[2]; ++z)
+                        for (u32 y = 0; y < c.n[1]; ++y)
+                            for (u32 x = 0; x < c.n[0]; ++x) {
+                                const u64 comp = comp_of(make_key<KIND>(c.depth, c.lo[0] + x, c.lo[1] + y, c.lo[2] + z), dterm, (id << 5) | (u32)BOX_PACKED_UNKNOWN);
+                                words_out[this_base + local] = comp;
+                                count_digits(comp);
+                                ++local;
+                            }
+                }
+            }
+            continue;
+        }
+        // ---- the wave's objects -> LDS, its entries -> lanes ------------------------------------------------------------
+        const u32 incl = wave_incl_scan_u32(cnt);
+        const u32 wtotal = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const size_t wave_base = this_base + (size_t)(u32)__builtin_amdgcn_readfirstlane((int)(excl - (incl - cnt)));
+        const u64 nz = ballot64(cnt != 0u);
+        if (lane < 8) s_ends[w][lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (cnt != 0u) {
+            const u32 depth = rec.w & 0xFFu;
+            u64 key0 = 0, dx = 0, dy = 0, dz = 0;
+            u32 sbits = 0, t0 = 0;
+            if (depth != 0) {  // (depth 0: Index::default(), one entry, src/geom.rs:203-205 / 261-263)
+                // at most two cells per axis: the first cell's Morton lanes once per object, the second cell of an axis by a dilated
+                // increment; cells in z outer, y, x inner order: src/geom.rs:271-297 (2-D: y outer, x inner: src/geom.rs:213-231)
+                const u32 up = AB - depth;
+                const u32 s0 = ((rec.w >> 8) & 3u) - 1u, s1 = ((rec.w >> 10) & 3u) - 1u, s2 = DIM == 3 ? ((rec.w >> 12) & 3u) - 1u : 0u;
+                const u64 m0 = spread_bits<DIM>((u64)rec.x << up), m1 = spread_bits<DIM>((u64)rec.y << up);
+                dx = (m0 ^ dilated_next<DIM>(m0, up)) << DB;
+                dy = (m1 ^ dilated_next<DIM>(m1, up)) << (DB + 1);
+                key0 = ((m0 | (m1 << 1)) << DB) | (u64)depth;
+                if (DIM == 3) {
+                    const u64 m2 = spread_bits<DIM>((u64)rec.z << up);
+                    key0 |= m2 << (DB + 2);
+                    dz = (m2 ^ dilated_next<DIM>(m2, up)) << (DB + 2);
+                }
+                sbits = s0 | (s1 << 1) | (s2 << 2);
+                t0 = s0 + 3u * s1 + 9u * s2;  // the first cell's code (ternary); a step on an axis adds 1 / 3 / 9
+            }
+            // The digits counted lie in the part of the word that is the index value shifted (the groups' bits: key_shift_delta
+            // takes a digit's shift back to the index value), and an object's cells lie between its first and its far-corner
+            // cell in index order: where those two agree on a digit all of them do -- one LDS add of the cell count for the object
+            // instead of one per entry (five objects in six on the uniform scene; the adds were a third of the LDS pipe's time)
+            u32 per_entry = 0;  // bit q: pass q's digit differs inside the object -- its entries count themselves
+            {
+                const u64 kmax = key0 ^ ((sbits & 1u) ? dx : 0ull) ^ ((sbits & 2u) ? dy : 0ull) ^ ((sbits & 4u) ? dz : 0ull);
+#pragma unroll
+                for (int q = 0; q < SX_HIST_MAX; ++q) {
+                    if (q < dc.passes) {
+                        const int ks = dc.shift[q] + key_shift_delta;
+                        const u32 d0 = (u32)(key0 >> ks) & 255u, d1 = (u32)(kmax >> ks) & 255u;
+                        if (d0 == d1) __hip_atomic_fetch_add(&s_hist[q * 256 + d0], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else per_entry |= 1u << q;
+                    }
+                }
+            }
+            const u32 slot = __builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u));
+            s_obj[w][0][slot] = make_uint4((u32)key0, (u32)(key0 >> 32), (u32)dx, (u32)(dx >> 32));
+            s_obj[w][1][slot] = make_uint4((u32)dy, (u32)(dy >> 32), (u32)dz, (u32)(dz >> 32));
+            s_obj[w][2][slot] = make_uint4((id << 5) | t0, comp_depth_term(depth), (incl - cnt) | (sbits << 16) | (per_entry << 20), 0u);
+            const u32 last = incl - 1u;
+            __hip_atomic_fetch_or(&s_ends[w][last >> 6], 1ull << (last & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 owners_before = 0;  // objects whose entries all lie before the current 64 (wave-uniform)
+        for (u32 e0 = 0; e0 < wtotal; e0 += 64u) {  // wave-uniform
+            const u64 word = s_ends[w][e0 >> 6];
+            const u32 e = e0 + (u32)lane;
+            const u32 o = __builtin_amdgcn_mbcnt_hi((u32)(word >> 32), __builtin_amdgcn_mbcnt_lo((u32)word, owners_before));
+            owners_before += (u32)__popcll(word);
+            if (e < wtotal) {
+                const uint4 c = s_obj[w][2][o], a = s_obj[w][0][o], b = s_obj[w][1][o];
+                const u32 el = e - (c.z & 0xFFFFu), sb3 = (c.z >> 16) & 7u;
+                const u32 s0 = sb3 & 1u, s1 = (sb3 >> 1) & 1u;
+                const u32 x = el & s0, y = (el >> s0) & s1, z = el >> (s0 + s1);
+                const u64 key = (((u64)a.y << 32) | a.x) ^ (x ? (((u64)a.w << 32) | a.z) : 0ull) ^ (y ? (((u64)b.y << 32) | b.x) : 0ull) ^
+                                (z ? (((u64)b.w << 32) | b.z) : 0ull);
+                const u64 comp = comp_of(key, c.y, c.x + x + 3u * y + 9u * z);
+                words_out[wave_base + e] = comp;
+                const u32 pe = c.z >> 20;
+                if (pe) {  // (an object that straddles a digit's boundary)
+#pragma unroll
+                    for (int q = 0; q < SX_HIST_MAX; ++q)
+                        if (q < dc.passes && ((pe >> q) & 1u))
+                            __hip_atomic_fetch_add(&s_hist[q * 256 + ((u32)(comp >> dc.shift[q]) & 255u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    if (dc.passes) {  // (see encode_emit_kernel: the workgroups spread their counts over HIST_COPIES copies)
+        __syncthreads();
         u64* copy = dc.hist + (size_t)(blockIdx.x % HIST_COPIES) * (SX_HIST_MAX * 256);
         for (int k = (int)threadIdx.x; k < dc.passes * 256; k += ENC_THREADS) {
             const u32 v = s_hist[k];
@@ -3501,10 +3651,16 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
         const u32 x = (u32)i * TGRP_THREADS + tid;
         if (x < ng) {
             const u32 b = (u32)(c[i] >> bshift) & (TG2_BINS - 1u);
-            const u32 start = s_off[b], end = s_off[b + 1];
-            u32 rank = 0;
-#pragma unroll 2
-            for (u32 y = start; y < end; ++y) rank += s_comp[y] < c[i] ? 1u : 0u;
+            const u32 start = s_off[b], len = s_off[b + 1] - start;
+            // about one word per bin: the first three are read whatever the bin's length and masked by it (straight-line code),
+            // the loop only runs for the few longer bins (group_finish_kernel has the same shape, and the same reason for it)
+            const u64* const q = s_comp + start;
+            const u64 q0 = q[0], q1 = q[1], q2 = q[2];
+            u32 rank = ((u32)(len > 0u) & (u32)(q0 < c[i])) + ((u32)(len > 1u) & (u32)(q1 < c[i])) + ((u32)(len > 2u) & (u32)(q2 < c[i]));
+            if (len > 3u) {
+#pragma unroll 1
+                for (u32 y = 3u; y < len; ++y) rank += q[y] < c[i] ? 1u : 0u;
+            }
             slot[i] = start + rank;
         }
     }
@@ -3629,14 +3785,18 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
         }
     }
     if (compact) {
-        BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
-                                                                                              block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, *compact)));
+        // (a digit at shift s of the word is the index value's at s + pshift - tbits - low, for shifts inside the word's prefix part)
+        const int ksd = compact->pshift - compact->tbits - compact->low;
+        for (int q = 0; q < dc.passes; ++q)
+            if (dc.shift[q] < compact->tbits + compact->low) return hipErrorInvalidValue;  // (the counted digits lie in the groups' bits)
+        BP_DISPATCH_KIND(kind, (encode_emit_compact_kernel<K><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs, block_offs,
+                                                                                         (u64*)keys_out, dc, sc_guard, (u64)capacity, *compact, ksd)));
     } else if (dc.cell_hist) {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, true><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
-                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, TreeCompact{})));
+                                                                                       block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     } else {
         BP_DISPATCH_KIND(kind, (encode_emit_kernel<K, false><<<g, ENC_THREADS, 0, stream>>>(sb, bounds, ids, n, min_depth, (const uint4*)recs,
-                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity, TreeCompact{})));
+                                                                                        block_offs, (u64*)keys_out, ids_out, box_out, dc, pack_box, sc_guard, (u64)capacity)));
     }
     return hipGetLastError();
 }
