@@ -47,11 +47,11 @@ def check_pairs(got, exp, what):
     assert np.array_equal(got, exp), what
 
 
-def warm(gpu, kind, sysb, base, ids, frames, first=0):
+def warm(gpu, kind, sysb, base, ids, frames, first=0, min_depth=0):
     """frames of the moving scene through clear / extend / par_sort / par_scan, each checked against the oracle"""
     for f in range(first, first + frames):
         b = moved(kind, sysb, base, f)
-        ref = oracle.OracleLayer(kind, 0)
+        ref = oracle.OracleLayer(kind, min_depth)
         gpu.clear()
         gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
         gpu.par_sort(); ref.sort()
@@ -70,6 +70,19 @@ def test_compact_records_over_moving_frames(kind, n, monkeypatch):
     # frame 0 takes the classic plan and probes, frame 1 the grouped plan, frame 2 the cell route; from then on extend may write
     # compact records -- and nothing but the sort asks for the tree before it is sorted, so nothing is expanded
     assert st["tree_sorts_compact"] >= 3 and st["tree_expands"] == 0 and st["sort_repairs"] == 0, {k: st[k] for k in want}
+
+
+def test_compact_records_with_objects_of_more_than_two_cells_per_axis(monkeypatch):
+    """min_depth above the natural depth of the larger objects: they span three or more cells on an axis (geom.rs:299-301 warns),
+    their box code is unknown, and the emit kernel walks such a round object by object instead of dealing entries to lanes --
+    the words, the tree and the pairs stay the oracle's"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    kind, n, min_depth = 2, 200000, 6
+    sysb, base, ids = base_scene(kind, n, seed=51)
+    gpu = bp.Layer(KINDS[kind], min_depth)
+    warm(gpu, kind, sysb, base, ids, 6, min_depth=min_depth)
+    st = gpu.stats()
+    assert st["tree_sorts_compact"] >= 2 and st["sort_repairs"] == 0, {k: st[k] for k in ("tree_sorts_compact", "tree_sorts_in_cells", "tree_expands", "extend_reruns")}
 
 
 def test_compact_records_are_expanded_for_every_other_consumer(monkeypatch):
