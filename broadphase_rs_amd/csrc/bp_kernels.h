@@ -96,6 +96,7 @@ struct SysBounds {
 struct TreeCompact {
     int pshift, tbits, T, low, idbits;
     uint32_t dmin, dmax;
+    uint32_t id_base;  // the id field holds id - id_base (ids of any magnitude whose RANGE fits idbits)
 };
 // the format for depths dmin .. dmax and ids below 2^idbits; false: does not fit 64 bits
 inline bool tree_compact_format(int kind, uint32_t dmin, uint32_t dmax, int idbits, TreeCompact* f) {
@@ -113,11 +114,11 @@ inline bool tree_compact_format(int kind, uint32_t dmin, uint32_t dmax, int idbi
     const int total = (int)(ki.dim * dmin) + tbits + idbits + 5;
     if (total > 64) return false;
     f->pshift = (int)(ki.depth_bits + ki.dim * (ki.axis_bits - dmin));
-    f->tbits = tbits; f->T = T; f->low = idbits + 5; f->idbits = idbits; f->dmin = dmin; f->dmax = dmax;
+    f->tbits = tbits; f->T = T; f->low = idbits + 5; f->idbits = idbits; f->dmin = dmin; f->dmax = dmax; f->id_base = 0;
     return true;
 }
-// composites (n of them, in place over `words`) -> index values in words[], id | packed box code << BOX_ID_BITS in ids_out[]
-hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, size_t n, const TreeCompact& fmt, hipStream_t stream);
+// composites (n of them, in place over `words`) -> index values in words[], ids in ids_out[], box bytes (BOX_*) in box_out[]
+hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, uint8_t* box_out, size_t n, const TreeCompact& fmt, hipStream_t stream);
 
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
@@ -142,7 +143,7 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               const struct RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr, int pack_box = 0,
                               unsigned long long* cell_hist = nullptr, uint32_t cell_depth = 0, DevScalars* sc_guard = nullptr,
                               size_t capacity = 0, const TreeCompact* compact = nullptr);
-// compact (with pack_box, no cell_hist): keys_out receives one composite word per entry (TreeCompact) and nothing else is
+// compact (no cell_hist; pack_box is ignored): keys_out receives one composite word per entry (TreeCompact) and nothing else is
 // written; hist_plan's shifts then refer to the composite
 // sc_guard / capacity: launched straight behind launch_scan_block_sums, without the host having read the entry total: if
 // sc_guard->total exceeds `capacity` entries the kernel writes nothing and sets KERR_ENCODE_OVERFLOW in sc_guard->err

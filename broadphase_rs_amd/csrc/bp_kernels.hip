@@ -471,7 +471,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_compact_kernel(SysBou
         if (blk * ENC_THREADS >= n) break;  // workgroup-uniform
         const size_t i = blk * ENC_THREADS + threadIdx.x;
         const uint4 rec = rec_next;
-        const u32 id = id_next;
+        const u32 id = id_next - fmt.id_base;  // (what the word's id field holds; the host checks the frame's ids against base and width)
         if (round + 1 < ENC_ROUNDS) {
             const size_t i1 = i + ENC_THREADS;
             rec_next = i1 < n ? recs[i1] : make_uint4(0u, 0u, 0u, 0u);
@@ -2591,10 +2591,11 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 }
 
 #ifndef SX_WAVES_PER_EU
-#define SX_WAVES_PER_EU 6  // measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.44 (with the stage cut to fit)
+#define SX_WAVES_PER_EU 7  // measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.390 (69 VGPRs, nothing spilled; round 3's 0.44 for 7 was with the stage cut by half a block)
 #endif
 #if SX_WAVES_PER_EU
-#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(5, SX_WAVES_PER_EU)))  // (the filtering variants need more registers than 7 waves leave)
+// (the filtering variants need more registers than seven waves leave: they keep the range 5 .. 6)
+#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FILT ? 5 : SX_WAVES_PER_EU, FILT ? 6 : SX_WAVES_PER_EU)))
 #else
 #define SX_OCC_ATTR
 #endif
@@ -3556,16 +3557,18 @@ template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u
     }
     const u32 depth = f.dmin + nlev;
     key = ((kp >> f.tbits) << f.pshift) | (mort << (f.pshift - (int)DIM * f.T)) | (u64)depth;
-    id = (u32)(comp >> 5) & ((1u << f.idbits) - 1u);
+    id = ((u32)(comp >> 5) & ((1u << f.idbits) - 1u)) + f.id_base;
     c27 = (u32)comp & 31u;
 }
 template <int KIND>
-__global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ words, u32* __restrict__ ids_out, size_t n, TreeCompact f) {
+__global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ words, u32* __restrict__ ids_out, uint8_t* __restrict__ box_out, size_t n,
+                                                          TreeCompact f) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         u64 key; u32 id, c27;
         tree_expand<KIND>(words[i], f, key, id, c27);
         words[i] = key;
-        ids_out[i] = id | (c27 << BOX_ID_BITS);
+        ids_out[i] = id;
+        box_out[i] = (uint8_t)box_from_packed(c27);
     }
 }
 // Grouped finish of a cell sort of composite words: tgroup_finish2_kernel<.., GAPPED> with ONE word per record -- one load per
@@ -3763,7 +3766,7 @@ hipError_t launch_encode_emit(int kind, SysBounds sb, const float* bounds, const
                               const RadixPlan* hist_plan, unsigned long long* hist, int pack_box, unsigned long long* cell_hist,
                               uint32_t cell_depth, DevScalars* sc_guard, size_t capacity, const TreeCompact* compact) {
     if (n == 0) return hipSuccess;
-    if (compact && (!pack_box || cell_hist)) return hipErrorInvalidValue;
+    if (compact && cell_hist) return hipErrorInvalidValue;
     const unsigned g = (unsigned)enc_blocks(n);
     DigitCount dc;
     const KindInfo ki = kind_info(kind);
@@ -5533,9 +5536,9 @@ hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_gro
 #undef BP_TGC_LAUNCH
     return hipGetLastError();
 }
-hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, size_t n, const TreeCompact& fmt, hipStream_t stream) {
+hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, uint8_t* box_out, size_t n, const TreeCompact& fmt, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    BP_DISPATCH_KIND(kind, (tree_expand_kernel<K><<<grid_for(n, 256, 4096), 256, 0, stream>>>((u64*)words, ids_out, n, fmt)));
+    BP_DISPATCH_KIND(kind, (tree_expand_kernel<K><<<grid_for(n, 256, 4096), 256, 0, stream>>>((u64*)words, ids_out, box_out, n, fmt)));
     return hipGetLastError();
 }
 int tgroup_capacity() { return TGC_CAP < TGRP_CAP ? TGC_CAP : TGRP_CAP; }  // (what every finish kernel of the grouped plan takes)

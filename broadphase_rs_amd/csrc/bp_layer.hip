@@ -150,7 +150,8 @@ struct bp_layer {
     DevBuf grp_bounds;                  // group start offsets of the grouped finish
     // extend without a host round trip between its kernels: what the previous extend into the empty layer produced
     // predicts what the next one needs
-    struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; uint32_t depth_mask = 0, id_or = 0; } enc_hint;
+    struct { bool valid = false; size_t n = 0, entries = 0; bool pack = false; uint64_t key_or = 0, key_and = 0; uint32_t depth_mask = 0, id_min = 0, id_max = 0;
+             bool ids_distinct = false; } enc_hint;
     // deferred check of the grouped tree sort: the sort is enqueued, its error word and group statistics are read at the
     // NEXT host round trip (the scan's) instead of one of their own
     // copied: the sort's scalars are on their way to h_sort_sc (a deferred check leaves that to the fetch it rides on: sort_sc_fetch)
@@ -469,10 +470,11 @@ int ensure_tree_capacity(bp_layer* L, size_t entries) {
 }
 
 int settle_sort(bp_layer* L, bool already_synced = false, bool* redone = nullptr);
-// compact records -> index values in keys[buf], ids with their box codes packed in ids[buf] (the form a packing extend leaves)
+// compact records -> index values in keys[buf], ids in ids[buf], box bytes in box[buf] (the form a non-packing extend leaves)
 int expand_compact(bp_layer* L, int buf, size_t m) {
     BP_TRY(ensure_dev(L, L->ids[buf], std::max<size_t>(m, 1) * sizeof(uint32_t)));
-    HIP_TRY(L, launch_tree_expand(L->kind, (uint64_t*)L->keys[buf].p, (uint32_t*)L->ids[buf].p, m, L->cfmt, L->stream));
+    BP_TRY(ensure_dev(L, L->box[buf], std::max<size_t>(m, 1)));
+    HIP_TRY(L, launch_tree_expand(L->kind, (uint64_t*)L->keys[buf].p, (uint32_t*)L->ids[buf].p, (uint8_t*)L->box[buf].p, m, L->cfmt, L->stream));
     ++L->stats.tree_expands;
     return BP_OK;
 }
@@ -481,8 +483,8 @@ int ensure_plain(bp_layer* L) {
     if (!L->tree_compact) return BP_OK;
     BP_TRY(expand_compact(L, L->cur, L->m));
     L->tree_compact = false;
-    L->ids_packed = true;
-    L->box_valid = false;
+    L->ids_packed = false;
+    L->box_valid = true;
     L->tree_hist_valid = false;  // (the digit counts were the composite's)
     return BP_OK;
 }
@@ -532,19 +534,25 @@ bool compact_plan(const TreeGroupPlan& gp, const TreeCompact& fmt, CompactPlan* 
 }
 // the format an extend chooses from what the PREVIOUS frame looked like (depths present, id bits), with a level of head room
 // on either side where 64 bits allow it -- a frame that leaves the format all the same runs again on the plain path
-bool compact_choose(int kind, uint32_t depth_mask, uint32_t id_or, const TreeGroupPlan& gp, CompactPlan* out) {
+bool compact_choose(int kind, uint32_t depth_mask, uint32_t id_min, uint32_t id_max, const TreeGroupPlan& gp, CompactPlan* out) {
     static const bool disabled = getenv("BP_NO_COMPACT_TREE") != nullptr;  // A/B switch
-    if (disabled || depth_mask == 0) return false;
+    if (disabled || depth_mask == 0 || id_max < id_min) return false;
     const KindInfo ki = kind_info(kind);
     const uint32_t dlo = (uint32_t)__builtin_ctz(depth_mask), dhi = 31u - (uint32_t)__builtin_clz(depth_mask);
-    const int idbits = std::max(1, 32 - __builtin_clz(id_or | 1u));
+    // (the id field holds id - id_min: ids of any magnitude, as long as their range leaves room -- also ids >= 2^27, which cannot
+    // carry their box codes through the (index, id) sort and used to cost the scan its duplicate suppression)
+    const int idbits = std::max(1, 32 - __builtin_clz((id_max - id_min) | 1u));
+    if (idbits > 27) return false;
     // (every level of the digit tail costs the encode and the finish a few instructions per entry: head room below the
     // shallowest depth only where the deeper side has none to give)
     const uint32_t lo_m = dlo ? dlo - 1u : 0u, hi_m = std::min(dhi + 1u, ki.axis_bits);
     const uint32_t tries[4][2] = {{dlo, hi_m}, {dlo, dhi}, {lo_m, hi_m}, {lo_m, dhi}};
     for (const auto& t : tries) {
         TreeCompact f;
-        if (tree_compact_format(kind, t[0], t[1], idbits, &f) && compact_plan(gp, f, out)) return true;
+        if (tree_compact_format(kind, t[0], t[1], idbits, &f)) {
+            f.id_base = id_min;
+            if (compact_plan(gp, f, out)) return true;
+        }
     }
     return false;
 }
@@ -588,8 +596,8 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
         if (L->tgrp_ok && tree_group_plan(pred_m, h.key_and, h.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
             hist_plan = gp.plan;
             count_digits = true;
-            if (pack && !count_cells && tree_cells_possible(L, pred_m, gp, /*before_sort=*/true) &&
-                compact_choose(L->kind, h.depth_mask, h.id_or, gp, &cp)) {
+            if ((pack || h.ids_distinct) && !count_cells && tree_cells_possible(L, pred_m, gp, /*before_sort=*/true) &&
+                compact_choose(L->kind, h.depth_mask, h.id_min, h.id_max, gp, &cp)) {
                 compact = true;
                 hist_plan = cp.plan;
             }
@@ -669,11 +677,13 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     // (compact records: every depth and id of THIS frame must lie inside the format chosen from the last one)
     const bool compact_fits = !compact || add == 0 ||
                               (sc.depth_mask != 0 && (uint32_t)__builtin_ctz(sc.depth_mask) >= cp.fmt.dmin &&
-                               31u - (uint32_t)__builtin_clz(sc.depth_mask) <= cp.fmt.dmax && (sc.id_or >> cp.fmt.idbits) == 0);
+                               31u - (uint32_t)__builtin_clz(sc.depth_mask) <= cp.fmt.dmax && !(sc.flags & EXT_IDS_REPEAT) &&
+                               sc.id_min >= cp.fmt.id_base && ((sc.id_max - cp.fmt.id_base) >> cp.fmt.idbits) == 0);
     if ((sc.err & KERR_ENCODE_OVERFLOW) || (pack && !can_pack) || !compact_fits) {
         // the prediction failed: remember the truth for the next frame and redo this one on the plain path
         L->enc_hint.entries = add; L->enc_hint.n = n; L->enc_hint.pack = can_pack;
-        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
+        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_min = sc.id_min; L->enc_hint.id_max = sc.id_max;
+        L->enc_hint.ids_distinct = !(sc.flags & EXT_IDS_REPEAT);
         ++L->stats.extend_reruns;
         return BP_OK;
     }
@@ -690,7 +700,8 @@ int extend_predicted(bp_layer* L, const SysBounds& sb, const float* d_bounds, co
     static const bool no_emit_pack = getenv("BP_NO_EMIT_PACK") != nullptr;
     L->enc_hint.pack = can_pack && !no_emit_pack;
     L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
-    L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
+    L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_min = sc.id_min; L->enc_hint.id_max = sc.id_max;
+    L->enc_hint.ids_distinct = !(sc.flags & EXT_IDS_REPEAT);
     if (add == 0) return BP_OK;
     if (count_cells) {
         L->cell_dev_valid = true;
@@ -806,7 +817,8 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
     if (was_empty) {  // what this extend produced predicts the next frame's (one-pass extend)
         L->enc_hint.valid = true; L->enc_hint.n = n; L->enc_hint.entries = add; L->enc_hint.pack = pack;
         L->enc_hint.key_or = sc.key_or; L->enc_hint.key_and = sc.key_and;
-        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_or = sc.id_or;
+        L->enc_hint.depth_mask = sc.depth_mask; L->enc_hint.id_min = sc.id_min; L->enc_hint.id_max = sc.id_max;
+        L->enc_hint.ids_distinct = !(sc.flags & EXT_IDS_REPEAT);
     }
     L->m += add;
     L->sorted = false;  // src/layer.rs:119 (at least one valid object was appended)
@@ -1010,13 +1022,18 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
         L->tcell.valid = false;
         L->cur = L->sort_pend.src;
         // (a compact sort: the first pass's dense output is composite words -- the repair sorts (index, id) records)
-        if (L->sort_pend.compact) BP_TRY(expand_compact(L, L->cur, L->m));
+        bool packed_payload = L->sort_pend.ride;
+        if (L->sort_pend.compact) {
+            BP_TRY(expand_compact(L, L->cur, L->m));
+            L->box_valid = true;       // (expanded: plain ids and box bytes, in the first pass's order)
+            packed_payload = false;
+        }
         L->ctx_epoch = 0;              // the context words were written for an order that is not the final one
         ++L->epoch;
         // the first radix pass placed records of equal digit in no particular order: equal keys are no longer in id order,
         // so the full-width sort must order by id as well
         L->order_ok = false;
-        BP_TRY(sort_tree_full(L, L->sort_pend.ride));
+        BP_TRY(sort_tree_full(L, packed_payload));
         L->ids_packed = false;
         BP_TRY(ensure_unpacked(L));
         L->sorted = true;

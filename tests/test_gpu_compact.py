@@ -178,6 +178,31 @@ def test_a_frame_that_leaves_the_compact_format_runs_again_on_the_plain_path(mon
     assert gpu.stats()["extend_reruns"] == st2["extend_reruns"] + 1
 
 
+def test_ids_above_2_27_keep_the_duplicate_suppression_on_the_compact_route(monkeypatch):
+    """ids >= 2^27 have no spare bits for the box code, so through the (index, id) sort the codes are lost and the scan falls back
+    to the reference's emit-every-combo + dedup (twice the raw pairs).  In a compact word the code has its own field and the id
+    field holds id - min(id): once the route engages the raw stream is duplicate-free again, whatever the ids' magnitude"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    kind, n = 2, 200000
+    sysb, base, ids = base_scene(kind, n, seed=61)
+    big = (ids.astype(np.uint64) * 3 + 3_000_000_000).astype(np.uint32)   # distinct, ascending, all >= 2^27, range 600 k
+    assert big.min() >= (1 << 27)
+    gpu = bp.Layer(KINDS[kind], 0)
+    raw = []
+    for f in range(7):
+        b = moved(kind, sysb, base, f)
+        ref = oracle.OracleLayer(kind, 0)
+        gpu.clear()
+        gpu.extend(sysb, b, big); ref.extend(sysb, b, big)
+        check_pairs(gpu.par_scan(), ref.scan(), "big ids, frame %d" % f)
+        check_tree(gpu, (ref.sort(), ref)[1], "big ids, frame %d, tree" % f)
+        st = gpu.stats()
+        raw.append((st["raw_pairs"], st["pairs"]))
+    st = gpu.stats()
+    assert st["tree_sorts_compact"] >= 3, {k: st[k] for k in ("tree_sorts_compact", "tree_sorts_in_cells", "extend_reruns", "tree_expands")}
+    assert raw[0][0] > raw[0][1] and raw[-1][0] == raw[-1][1], raw   # first frame: every combo; on the route: each pair once
+
+
 def test_compact_switch_off_gives_the_same_lists():
     """BP_NO_COMPACT_TREE (read once per process: child process) takes the route out; same frames, same lists, no compact sort"""
     import os, subprocess, sys
