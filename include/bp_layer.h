@@ -22,8 +22,10 @@
  *     byte of the pair side -- 57 % of a frame -- doubles with u64 ids (pairs are sorted as one packed 64-bit word here).  A host
  *     with wider ids keeps a u32 -> ID table on its side (ids are dense per frame in the reference's use).  Two id ranges cost
  *     time, never correctness: ids >= 2^27 (the 5 spare payload bits then cannot carry the box codes through the tree sort, so
- *     duplicates are removed after the pair sort as in the reference: about 2 x the frame time) and ids that repeat across
- *     objects (the reference's skip rule, src/layer.rs:563-565).  Index values travel as u64 for every index kind
+ *     duplicates are removed after the pair sort as in the reference: about 2 x the frame time -- except in the per-frame pattern,
+ *     where from the third frame on the tree travels as compact records with a code field of their own and an id field that holds
+ *     id - min(id): ids of any magnitude whose range is below 2^27 then cost about 10 % more than small ones) and ids that repeat
+ *     across objects (the reference's skip rule, src/layer.rs:563-565).  Index values travel as u64 for every index kind
  *     (Index32_2D is zero-extended);
  *   - no CPU fallback exists: without a usable HIP device every call fails with BP_ERR_NO_DEVICE.
  */
