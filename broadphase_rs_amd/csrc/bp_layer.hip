@@ -543,10 +543,10 @@ bool compact_choose(int kind, uint32_t depth_mask, uint32_t id_min, uint32_t id_
     // carry their box codes through the (index, id) sort and used to cost the scan its duplicate suppression)
     const int idbits = std::max(1, 32 - __builtin_clz((id_max - id_min) | 1u));
     if (idbits > 27) return false;
-    // (every level of the digit tail costs the encode and the finish a few instructions per entry: head room below the
-    // shallowest depth only where the deeper side has none to give)
-    const uint32_t lo_m = dlo ? dlo - 1u : 0u, hi_m = std::min(dhi + 1u, ki.axis_bits);
-    const uint32_t tries[4][2] = {{dlo, hi_m}, {dlo, dhi}, {lo_m, hi_m}, {lo_m, dhi}};
+    // (head room on the deep side only: a level below the shallowest depth would lengthen the digit tail -- a few instructions per
+    // entry in the encode and the finish -- and never costs fewer bits)
+    const uint32_t hi_m = std::min(dhi + 1u, ki.axis_bits);
+    const uint32_t tries[2][2] = {{dlo, hi_m}, {dlo, dhi}};
     for (const auto& t : tries) {
         TreeCompact f;
         if (tree_compact_format(kind, t[0], t[1], idbits, &f)) {
