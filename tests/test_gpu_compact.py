@@ -145,7 +145,7 @@ def test_compact_records_are_expanded_for_every_other_consumer(monkeypatch):
 
 
 def test_a_frame_that_leaves_the_compact_format_runs_again_on_the_plain_path(monkeypatch):
-    """the format is chosen from the PREVIOUS frame's depths and ids (one level of head room either side where 64 bits allow):
+    """the format is chosen from the PREVIOUS frame's depths and ids (one level of head room on the deep side where 64 bits allow):
     a frame with much smaller objects (deeper cells) or wider ids does not fit it -- extend must notice from the frame's own
     facts and run again, and the results stay the oracle's"""
     monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
