@@ -209,7 +209,7 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
 // dev_sizes (with ready_hist only: nothing on the host side reads the records): the sort is enqueued behind a producer
 // nobody has waited for -- n and extent are UPPER BOUNDS (they size grids and the workspace), the kernels take the sizes
 // from dev_sizes[SIZES_N] / dev_sizes[SIZES_EXTENT] (launch_scan_finalize writes them; both 0 = do nothing)
-enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_CELL_MISS = 3, SIZES_WORDS = 8 };
+enum { SIZES_EXTENT = 0, SIZES_N = 1, SIZES_MISS = 2, SIZES_CELL_MISS = 3, SIZES_BIG = 4 /* slices the scan put on its work list */, SIZES_WORDS = 8 };
 // finalize (with dev_sizes): the sort's first kernel also does launch_scan_finalize's job (one launch less): it derives the
 // sizes from the scan's shard words and writes them to `sizes` (== dev_sizes) before any pass reads them
 struct ScanFinalize {
@@ -358,7 +358,9 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,
-                              const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0);
+                              const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0, int mixed_scale = 0);
+// mixed_scale (default kernel only; speed, never results): the tree has ranges long enough for the work list (the previous scan
+// listed some): the kernel instance that keeps six waves per SIMD instead of seven
 // gen (ids that may repeat; idctx from launch_entry_ctx with box == nullptr): 1 = MARK pass (sets the skipped bit of
 // every entry whose id an ancestor carries, src/layer.rs:563-565; emits nothing), 2 = EMIT pass (all combos of two
 // unskipped entries).  Run 1 then 2; the long-range counter in sc must be zero before each.

@@ -861,6 +861,7 @@ __device__ __forceinline__ void scan_finalize_wave(const u64* __restrict__ shard
     sizes[SIZES_EXTENT] = ok ? (u32)extent : 0u;
     sizes[SIZES_N] = ok ? (u32)total : 0u;
     sizes[SIZES_MISS] = ok ? 0u : 1u;
+    sizes[SIZES_BIG] = sc->big_count;  // (the sort's first kernel resets the scalars: what the host wants of them is kept here)
 }
 #ifndef RS_CUR_STRIDE
 #define RS_CUR_STRIDE 1040  // u32 words between two groups of 16 bin cursors (4160 bytes): the groups spread over memory channels
@@ -2594,8 +2595,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #define SX_WAVES_PER_EU 7  // measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.390 (69 VGPRs, nothing spilled; round 3's 0.44 for 7 was with the stage cut by half a block)
 #endif
 #if SX_WAVES_PER_EU
-// (the filtering variants need more registers than seven waves leave: they keep the range 5 .. 6)
-#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FILT ? 5 : SX_WAVES_PER_EU, FILT ? 6 : SX_WAVES_PER_EU)))
+// (the filtering variants need more registers than seven waves leave: they keep the range 5 .. 6.  OCC6: the same for the default
+// variant, chosen at launch for mixed-scale scenes -- with ranges that leave the LDS windows, the seventh wave per SIMD costs the
+// scan 2.5 % (12.5 M power-law objects: 1.15 against 1.12 ms), on the uniform scene it gains as much)
+#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu((FILT || OCC6) ? 5 : SX_WAVES_PER_EU, (FILT || OCC6) ? 6 : SX_WAVES_PER_EU)))
 #else
 #define SX_OCC_ATTR
 #endif
@@ -2610,7 +2613,7 @@ constexpr u32 SX_WIN = 128;  // entries of a chunk's LDS windows: the wave's 64 
 // chunk before they are used (register prefetch across the persistent loop); (2) both 128-entry windows go to LDS:
 // the range ends are bisected in the key window, and a candidate's {id, context} word comes from the word window
 // (nearly every range ends within the 64 entries after its owner) -- only a candidate beyond the window is a global load.
-template <int KIND, bool FILT, bool OWNER, int GEN = 0>
+template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
 #ifndef SX_SUPER_WORDS
@@ -4464,14 +4467,15 @@ hipError_t launch_scan_finalize(const uint64_t* shards, size_t out_blocks, size_
     return hipGetLastError();
 }
 
-template <int KIND, bool FILT, bool OWNER, int GEN = 0>
+template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false>
 static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
     // resident workgroups per dynamic-LDS size (0 .. SX_HIST_MAX rows of counters)
     static unsigned resident[SX_HIST_MAX + 1] = {};
     const int rows = sx_hist_rows(p);
     if (rows < 0 || rows > SX_HIST_MAX) return hipErrorInvalidValue;
-    if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN>, SX_THREADS, sx_hist_bytes(p));
-    unsigned res = std::min(resident[rows], resident_cap(SX_WAVES_PER_EU ? SX_WAVES_PER_EU * 4 / SX_WAVES : 64));
+    if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6>, SX_THREADS, sx_hist_bytes(p));
+    constexpr int occ = (FILT || OCC6) ? (SX_WAVES_PER_EU < 6 ? SX_WAVES_PER_EU : 6) : SX_WAVES_PER_EU;
+    unsigned res = std::min(resident[rows], resident_cap(occ ? occ * 4 / SX_WAVES : 64));
     // small trees: a wave should have a dozen chunks to amortise its prologue, its last partial block and the counters' flush
     // (1 M objects: 1536 workgroups 0.421 ms per frame, 1024 0.412, 768 0.414, 512 0.428); never fewer workgroups than CUs
     {
@@ -4481,19 +4485,20 @@ static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hi
     if (const char* e = getenv("BP_SX_GRID")) res = (unsigned)atoi(e);  // (measurement knob: workgroups of the persistent grid)
     const unsigned grid = (unsigned)std::min<size_t>(max_grid, res);
     p.n_waves = grid * SX_WAVES;
-    scan_expand_kernel<KIND, FILT, OWNER, GEN><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
+    scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
     scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
     return hipGetLastError();
 }
 template <int KIND>
-static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream, int gen) {
+static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream, int gen, bool occ6) {
     if (gen == 1) return launch_scan_expand_variant<KIND, false, false, 1>(p, max_grid, stream);
     if (gen == 2) return launch_scan_expand_variant<KIND, false, false, 2>(p, max_grid, stream);
     const bool owner = p.owner_n >= 0;  // the owner-counting variant is a separate instantiation: the default kernel pays nothing
     if (p.filt_bounds) return owner ? launch_scan_expand_variant<KIND, true, true>(p, max_grid, stream)
                                     : launch_scan_expand_variant<KIND, true, false>(p, max_grid, stream);
-    return owner ? launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream)
-                 : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
+    if (owner) return launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream);
+    return occ6 ? launch_scan_expand_variant<KIND, false, false, 0, true>(p, max_grid, stream)
+                : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
 }
 // digit plans the expanding scan can count while it emits: few enough passes, key digits only, and no digit that
 // straddles the two dwords of a packed pair (the kernel extracts a digit from ONE dword)
@@ -4507,7 +4512,7 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n,
-                              int gen) {
+                              int gen, int mixed_scale) {
     if (m == 0) return hipSuccess;
     // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
@@ -4529,9 +4534,9 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
         for (int i = 0; i < owner_n; ++i) p.owner_bounds[i] = owner_bounds[i];
     }
     switch (kind) {
-        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream, gen);
-        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream, gen);
-        default: return launch_scan_expand_kind<2>(p, max_grid, stream, gen);
+        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream, gen, mixed_scale != 0);
+        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream, gen, mixed_scale != 0);
+        default: return launch_scan_expand_kind<2>(p, max_grid, stream, gen, mixed_scale != 0);
     }
 }
 
