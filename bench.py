@@ -174,7 +174,7 @@ def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False, tree_compact=Fal
         "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)",
                    28.0 * n + (8.0 if tree_compact else 12.0) * M),
         "tree_sort": (tree_sort, (16.0 if tree_compact else 24.0) * M),
-        "tree_finish": ("tgroup_finishc_kernel (LDS finish of the tree sort: compact records in, index values + ids + context words out)", 8.0 * M + 12.0 * M)
+        "tree_finish": ("tgroup_finishc_kernel (LDS finish of the tree sort: compact records in, index values + context words out)", 8.0 * M + 12.0 * M)
                        if tree_compact else ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
         "pair_sort": (pair_sort, 16.0 * P_raw),
@@ -577,7 +577,7 @@ def single_gpu_line(args, r, np):
         # (compact records: one 8-byte word per entry from the emit pass to the finish instead of a 12-byte (index, id) entry)
         "encode": 28.0 * n + 4.0 * n + 16.0 * n * 2 + (8.0 if compact else 12.0) * M,  # bounds + ids read once, the 16-byte object record written and read, entries written
         "tree_sort": (16.0 if compact else 24.0) * M * pk,
-        "tree_finish": (8.0 if compact else 12.0) * M + 21.0 * M,  # record read; key, id, box byte, {id, ctx} word written
+        "tree_finish": (8.0 if compact else 12.0) * M + (16.0 if compact else 21.0) * M,  # record read; key, {id, ctx} word written (+ id, box byte off the compact route, where they are derived from the words on demand)
         "scan_emit": 16.0 * M + 8.0 * P_raw,                      # keys + {id, ctx} words read, packed pairs written
         "pair_sort": 16.0 * P_raw * pp,
         "dedup": 8.0 * P_raw + 8.0 * P,

@@ -449,6 +449,8 @@ hipError_t launch_tgroup_finish(const uint64_t* keys_in, const uint32_t* ids_in,
 bool tgroup_composite_applies(int gshift, int distinct_id_bits);
 // the same finish for a cell sort of COMPOSITE words (TreeCompact; comp_gshift: the group shift in the composite): reads the gapped
 // words, orders every group by plain unsigned compare and writes index values, ids, box bytes and context words
+// ids_out / box_out both null: not written (launch_ids_from_ctx derives them from idctx_out when wanted; every box code must be known)
+hipError_t launch_ids_from_ctx(const uint64_t* idctx, uint32_t* ids_out, uint8_t* box_out, size_t n, hipStream_t stream);
 bool tgroup_compact_applies(int comp_gshift);  // the composite's group shift leaves room for the finish kernel's bin digit
 hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_groups, int comp_gshift, const TreeCompact& fmt, uint64_t* keys_out,
                                         uint32_t* ids_out, uint8_t* box_out, DevScalars* sc, hipStream_t stream, int ctx_kind, uint64_t* idctx_out,

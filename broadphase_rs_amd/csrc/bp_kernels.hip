@@ -3583,7 +3583,9 @@ __global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ word
 #endif
 constexpr int TGC_CAP = 2044;  // (words per group: with the offsets' 4112 bytes just under the 20480 bytes an eighth of a CU's LDS is)
 static_assert(TGC_CAP <= TGRP_CAP && (size_t)TGC_CAP * 8 + (TG2_BINS + 4) * 4 <= 20480, "tgroup_finishc: eight workgroups per CU");
-template <int CTX_KIND, int NSTEP>
+// WRITE_IDS = false: ids_out / box_out are not written -- the caller derives them from the context words when something asks
+// (launch_ids_from_ctx): two of the write-out's four stores and five of its 21 bytes per entry
+template <int CTX_KIND, int NSTEP, bool WRITE_IDS = true>
 __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TGC_WAVES_PER_EU, TGC_WAVES_PER_EU))) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
                                                                       u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                       uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
@@ -3686,8 +3688,10 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
         u64 ky; u32 id, c27;
         tree_expand<XK, NSTEP>(s_comp[y], fmt, ky, id, c27, s_lut3);
         keys_out[(size_t)lo + y] = ky;
-        ids_out[(size_t)lo + y] = id;
-        box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
+        if constexpr (WRITE_IDS) {
+            ids_out[(size_t)lo + y] = id;
+            box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
+        }
         idctx_out[(size_t)lo + y] = ((u64)id << 32) | (u64)entry_ctx_lut<CTX_KIND>(ky, c27, 0u, s_lut);
     }
 }
@@ -5523,11 +5527,18 @@ hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_gro
                                         const uint32_t* stats, uint32_t abort_over, const CellRoute& cells) {
     if (n_groups == 0) return hipSuccess;
     // (the kernel takes the index kind from its context-word instantiation: the compact route always writes the context words)
-    if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || !ids_out || !box_out || ctx_kind < 0 || ctx_kind > 2 || !cells.src)
+    if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || (ids_out == nullptr) != (box_out == nullptr) || ctx_kind < 0 || ctx_kind > 2 ||
+        !cells.src)
         return hipErrorInvalidValue;
-#define BP_TGC_LAUNCH(K, S)                                                                                                                   \
-    tgroup_finishc_kernel<K, S><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, box_out, \
-                                                                       (u64*)idctx_out, sc, stats, abort_over, cells.src)
+#define BP_TGC_LAUNCH(K, S)                                                                                                                         \
+    do {                                                                                                                                            \
+        if (ids_out)                                                                                                                                \
+            tgroup_finishc_kernel<K, S, true><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, \
+                                                                                     box_out, (u64*)idctx_out, sc, stats, abort_over, cells.src);   \
+        else                                                                                                                                        \
+            tgroup_finishc_kernel<K, S, false><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, \
+                                                                                      box_out, (u64*)idctx_out, sc, stats, abort_over, cells.src);  \
+    } while (0)
 #define BP_TGC_STEPS(K)                          \
     do {                                         \
         if (fmt.T <= 3) BP_TGC_LAUNCH(K, 1);     \
@@ -5539,6 +5550,20 @@ hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_gro
     else BP_TGC_STEPS(2);
 #undef BP_TGC_STEPS
 #undef BP_TGC_LAUNCH
+    return hipGetLastError();
+}
+// ids and box bytes from the per-entry context words ({id, context}: the context carries the entry's own code, two bits per axis)
+__global__ __launch_bounds__(256) void ids_from_ctx_kernel(const u64* __restrict__ idctx, u32* __restrict__ ids_out, uint8_t* __restrict__ box_out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const u64 w = idctx[i];
+        const u32 c = (u32)w;
+        ids_out[i] = (u32)(w >> 32);
+        box_out[i] = (uint8_t)(((c >> 6) & 3u) | (((c >> 14) & 3u) << 2) | (((c >> 22) & 3u) << 4));
+    }
+}
+hipError_t launch_ids_from_ctx(const uint64_t* idctx, uint32_t* ids_out, uint8_t* box_out, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    ids_from_ctx_kernel<<<grid_for(n, 256, 4096), 256, 0, stream>>>((const u64*)idctx, ids_out, box_out, n);
     return hipGetLastError();
 }
 hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, uint8_t* box_out, size_t n, const TreeCompact& fmt, hipStream_t stream) {

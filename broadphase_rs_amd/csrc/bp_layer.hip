@@ -58,6 +58,9 @@ struct bp_layer {
     // of the tree sort moves these 8-byte records (ensure_plain expands them for every other consumer)
     bool tree_compact = false;
     TreeCompact cfmt{};
+    // after a compact sort: ids[cur] / box[cur] have NOT been written -- the scan reads the {id, context} words, and whoever wants
+    // the arrays gets them derived from those words first (ensure_ids; every code known, idctx current)
+    bool ids_lazy = false;
     int cur = 0;
     size_t m = 0;
     bool sorted = true;
@@ -458,6 +461,7 @@ void reset_tree_facts(bp_layer* L) {
     L->box_all_known = true;
     L->ids_packed = false;
     L->tree_compact = false;
+    L->ids_lazy = false;
 }
 
 uint64_t* cur_keys(bp_layer* L) { return (uint64_t*)L->keys[L->cur].p; }
@@ -479,6 +483,16 @@ int expand_compact(bp_layer* L, int buf, size_t m) {
     ++L->stats.tree_expands;
     return BP_OK;
 }
+// ids / box bytes a compact sort left unwritten: from the context words (which that sort wrote for exactly this order)
+int ensure_ids(bp_layer* L) {
+    if (!L->ids_lazy) return BP_OK;
+    if (L->ctx_epoch != L->epoch) return fail(L, BP_ERR_KERNEL, "internal: the context words a lazy id array depends on are stale");
+    BP_TRY(ensure_dev(L, L->ids[L->cur], std::max<size_t>(L->m, 1) * sizeof(uint32_t)));
+    BP_TRY(ensure_dev(L, L->box[L->cur], std::max<size_t>(L->m, 1)));
+    HIP_TRY(L, launch_ids_from_ctx((const uint64_t*)L->idctx.p, (uint32_t*)L->ids[L->cur].p, (uint8_t*)L->box[L->cur].p, L->m, L->stream));
+    L->ids_lazy = false;
+    return BP_OK;
+}
 // a tree that an extend left as compact records is expanded before anything but the compact sort reads it
 int ensure_plain(bp_layer* L) {
     if (!L->tree_compact) return BP_OK;
@@ -494,6 +508,7 @@ int ensure_plain(bp_layer* L) {
 int ensure_unpacked(bp_layer* L) {
     if (L->sort_pend.on) BP_TRY(settle_sort(L));
     BP_TRY(ensure_plain(L));
+    BP_TRY(ensure_ids(L));
     if (!L->ids_packed) return BP_OK;
     if (L->m) {
         BP_TRY(ensure_dev(L, L->box[L->cur], L->m));
@@ -1024,6 +1039,7 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
         L->cur = L->sort_pend.src;
         // (a compact sort: the first pass's dense output is composite words -- the repair sorts (index, id) records)
         bool packed_payload = L->sort_pend.ride;
+        L->ids_lazy = false;           // (the repair writes real arrays)
         if (L->sort_pend.compact) {
             BP_TRY(expand_compact(L, L->cur, L->m));
             L->box_valid = true;       // (expanded: plain ids and box bytes, in the first pass's order)
@@ -1110,9 +1126,14 @@ int sort_tree(bp_layer* L, bool defer_check) {
             // of 24), the finish expands them into index values, ids, box bytes and context words
             L->stats.tree_sort_passes = 2;
             const int other = L->cur ^ 1, dst = L->cur;
+            // the id and box arrays are written only on demand (ensure_ids) when every code is known: the scan reads the context words
+            static const bool no_lazy = getenv("BP_NO_LAZY_IDS") != nullptr;  // A/B switch
+            const bool lazy_ids = !no_lazy && L->box_all_known;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
-            BP_TRY(ensure_dev(L, L->ids[dst], L->m * sizeof(uint32_t)));
-            BP_TRY(ensure_dev(L, L->box[dst], L->m));
+            if (!lazy_ids) {
+                BP_TRY(ensure_dev(L, L->ids[dst], L->m * sizeof(uint32_t)));
+                BP_TRY(ensure_dev(L, L->box[dst], L->m));
+            }
             BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             uint32_t* ws_epoch = nullptr;
             BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(L->m, 2), &ws_epoch));
@@ -1135,8 +1156,8 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 HIP_TRY(L, launch_cell_count(cr, cell0, gp.n_groups, (uint32_t*)L->tgrp_bounds.p, (uint32_t)tgroup_capacity(), group_stats_words(d_ssc),
                                              nullptr, L->stream, &d_ssc->err, (uint32_t)KERR_SEGMENT_TOO_LONG, (uint32_t)L->m));
                 HIP_TRY(L, launch_tgroup_finish_compact((const uint64_t*)L->tcell_keys.p, gp.n_groups, ccp.comp_gshift, L->cfmt, (uint64_t*)L->keys[dst].p,
-                                                        (uint32_t*)L->ids[dst].p, (uint8_t*)L->box[dst].p, d_ssc, L->stream, L->kind, (uint64_t*)L->idctx.p,
-                                                        group_stats_words(d_ssc), (uint32_t)(L->m / 4), cr));
+                                                        lazy_ids ? nullptr : (uint32_t*)L->ids[dst].p, lazy_ids ? nullptr : (uint8_t*)L->box[dst].p, d_ssc,
+                                                        L->stream, L->kind, (uint64_t*)L->idctx.p, group_stats_words(d_ssc), (uint32_t)(L->m / 4), cr));
                 ++L->stats.tree_sorts_in_cells;
                 ++L->stats.tree_sorts_compact;
             }
@@ -1144,6 +1165,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
             // optimistic state: the sort succeeded (what a failed check does about it: settle_sort)
             L->cur = dst;
             L->tree_compact = false;
+            L->ids_lazy = lazy_ids;
             L->box_valid = true;
             L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0;
             L->ids_packed = false;
@@ -1739,8 +1761,10 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.filt_bounds = filt_bounds;
     p.filt_rows = filt_rows;
     p.filt_shape = L->filt_shape;
-    p.box = (source_dedup && L->box_valid) ? (const uint8_t*)L->box[L->cur].p : nullptr;
-    L->raw_is_unique = p.box != nullptr && L->box_all_known;
+    // (after a compact sort the box array may not have been written yet -- ensure_ids -- so "codes in use" is a flag, not the pointer)
+    const bool have_box = source_dedup && L->box_valid;
+    p.box = have_box ? (const uint8_t*)L->box[L->cur].p : nullptr;
+    L->raw_is_unique = have_box && L->box_all_known;
     static const bool no_expand = getenv("BP_NO_EXPAND_SCAN") != nullptr;  // A/B switch for measurements
     bool expand = !no_expand;
     if (expand) {
@@ -1748,8 +1772,11 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         const uint32_t thr = emit_coarse == 1 ? 0u : coarse_depth;
         // emit_coarse == 2: coarse entries whose id lies in the layer's range stay active (an empty range otherwise)
         const uint32_t alo = (emit_coarse == 2 && thr) ? L->coarse_lo : 1u, ahi = (emit_coarse == 2 && thr) ? L->coarse_hi : 0u;
-        const bool with_box = p.box != nullptr;
+        const bool with_box = have_box;
         if (L->ctx_epoch != L->epoch || L->ctx_thr != thr || L->ctx_box != with_box || L->ctx_lo != alo || L->ctx_hi != ahi) {
+            BP_TRY(ensure_ids(L));  // (the words are rebuilt from the id / box arrays: those must exist)
+            p.ids = cur_ids(L);
+            if (have_box) p.box = (const uint8_t*)L->box[L->cur].p;
             BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
             ProfScope ps(L, BP_K_SCAN_COUNT);
             HIP_TRY(L, launch_entry_ctx(L->kind, cur_keys(L), cur_ids(L), p.box, L->m, thr, (uint64_t*)L->idctx.p, L->stream, alo, ahi));
@@ -1966,6 +1993,9 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
             cap = extent_blocks * SX_BLOCK + extent_blocks * SX_BLOCK / 16;  // the buffer was too small: grow and redo
             continue;
         }
+        BP_TRY(ensure_ids(L));  // (the per-entry walk reads the id / box arrays)
+        p.ids = cur_ids(L);
+        if (have_box) p.box = (const uint8_t*)L->box[L->cur].p;
         {
             ProfScope ps(L, BP_K_SCAN_EMIT);
             HIP_TRY(L, launch_scan_fused(L->kind, p, (uint64_t*)L->pairs[0].p, cap, (DevScalars*)L->d_sc.p, L->stream));
@@ -1980,7 +2010,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
         if ((size_t)sc.total <= cap) {
             L->n_raw = (size_t)sc.total;
             L->stats.raw_pairs = L->n_raw;
-            L->stats.raw_candidates = p.box ? 0 : L->n_raw;
+            L->stats.raw_candidates = have_box ? 0 : L->n_raw;
             return BP_OK;
         }
         cap = (size_t)sc.total + (size_t)sc.total / 16;  // the buffer was too small: grow and redo

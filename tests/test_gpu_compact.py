@@ -142,6 +142,20 @@ def test_compact_records_are_expanded_for_every_other_consumer(monkeypatch):
     _, ref = frame(25)
     raw_ref, _ = ref.scan_raw()
     check_pairs(gpu.scan_raw(), raw_ref, "scan_raw straight after a compact extend")
+    warm(gpu, kind, sysb, base, ids, 3, first=26)
+    # (f) after the compact SORT the id and box arrays exist only as context words until someone asks: the literal scan kernels,
+    # a clone and the tree accessors ask after the frame's own scan
+    _, ref = frame(29)
+    check_pairs(gpu.par_scan(), ref.scan(), "scan on the compact route")
+    raw_ref, _ = ref.scan_raw()
+    check_pairs(gpu.scan_raw(), raw_ref, "scan_raw after a compact sort (ids from the context words)")
+    _, ref = frame(30)
+    check_pairs(gpu.par_scan(), ref.scan(), "scan on the compact route")
+    twin = gpu.clone()
+    ref.sort()
+    check_tree(twin, ref, "clone after a compact sort")
+    check_tree(gpu, ref, "tree after a compact sort")
+    check_pairs(twin.par_scan(), ref.scan(), "scan of the clone")
 
 
 def test_a_frame_that_leaves_the_compact_format_runs_again_on_the_plain_path(monkeypatch):
