@@ -359,8 +359,10 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,
                               const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0, int mixed_scale = 0);
-// mixed_scale (default kernel only; speed, never results): the tree has ranges long enough for the work list (the previous scan
-// listed some): the kernel instance that keeps six waves per SIMD instead of seven
+// mixed_scale (speed, never results): > 0: the tree has ranges long enough for the work list (the previous scan listed some): the
+// kernel instance that keeps six waves per SIMD instead of seven; < 0: the previous scan listed none -- the work-list kernel is
+// not launched, a range of up to 4 x 16384 candidates stays with its wave and a longer one sets KERR_BIGLIST_OVERFLOW (the caller
+// falls back as for an overflowed list); 0: no expectation (the work-list kernel runs)
 // gen (ids that may repeat; idctx from launch_entry_ctx with box == nullptr): 1 = MARK pass (sets the skipped bit of
 // every entry whose id an ancestor carries, src/layer.rs:563-565; emits nothing), 2 = EMIT pass (all combos of two
 // unskipped entries).  Run 1 then 2; the long-range counter in sc must be zero before each.

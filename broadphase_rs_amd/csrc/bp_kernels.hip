@@ -2349,6 +2349,7 @@ struct ExpandParams {
     DevScalars* sc;
     u64* big_list;     // two words per item: j | slice << 32 (slice s covers candidates [s * SX_BIG, (s + 1) * SX_BIG) of j's range), the range's end
     u32 big_cap;
+    u32 big_inline;    // no work-list kernel follows this launch: ranges up to SX_INLINE_MAX candidates stay with their wave, longer ones fail the scan
     u32 n_waves;       // waves of the main kernel's grid (chunk stride)
     const float* filt_bounds;
     int filt_shape;
@@ -2613,6 +2614,7 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #define SX_OCC_ATTR
 #endif
 constexpr u32 SX_WIN = 128;  // entries of a chunk's LDS windows: the wave's 64 and the 64 that follow
+constexpr u32 SX_INLINE_MAX = 4u * SX_BIG;  // longest range a wave walks itself when no work-list kernel follows (ExpandParams::big_inline)
 // GEN = 0: ids distinct, duplicates suppressed at the source (the default).
 // GEN = 1: ids may repeat, MARK pass: every candidate whose id equals its ancestor's gets CTX_SKIPPED (nothing is emitted).
 // GEN = 2: ids may repeat, EMIT pass: every combo of two unskipped entries (the reference's raw stream as a set).
@@ -2737,7 +2739,13 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             if (GEN == 2 && ((u32)pre.w0 & CTX_SKIPPED)) c = 0;  // a skipped entry never enters the stack
             if (c >= SX_BIG) {  // the work list: one item per slice, each with the range's end (the second kernel searches nothing)
                 const u32 ns = (c + SX_BIG - 1u) / SX_BIG;
-                const u32 at = atomicAdd(&p.sc->big_count, ns);
+                const u32 at = atomicAdd(&p.sc->big_count, ns);  // (counted either way: the host launches the work-list kernel when the last scan had such ranges)
+                if (p.big_inline) {
+                    // the last scan had no range this long, so no work-list kernel was enqueued behind this launch: a moderately
+                    // long range stays in this wave's own stepping loop (a few hundred steps, once -- the next frame has the
+                    // kernel again), a longer one fails the scan and the host runs the per-entry walk for this frame
+                    if (c > SX_INLINE_MAX) { atomicOr(&p.sc->err, (u32)KERR_BIGLIST_OVERFLOW); c = 0; }
+                } else
                 if ((u64)at + ns <= p.big_cap) {
                     for (u32 sl = 0; sl < ns; ++sl) {
                         p.big_list[2 * (size_t)(at + sl)] = (u64)j | ((u64)sl << 32);
@@ -2746,7 +2754,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 } else {
                     atomicOr(&p.sc->err, (u32)KERR_BIGLIST_OVERFLOW);
                 }
-                c = 0;
+                if (!p.big_inline) c = 0;
             }
         }
         __builtin_amdgcn_wave_barrier();  // the key window is dead from here on (s_rec is written below)
@@ -4500,7 +4508,7 @@ static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hi
     const unsigned grid = (unsigned)std::min<size_t>(max_grid, res);
     p.n_waves = grid * SX_WAVES;
     scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
-    scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
+    if (!p.big_inline) scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
     return hipGetLastError();
 }
 template <int KIND>
@@ -4535,6 +4543,8 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
     p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
     p.n_waves = 0; p.filt_bounds = filt_bounds; p.filt_shape = filt_shape;
+    // no work list expected (the last scan listed nothing): the work-list kernel is not launched; gen != 0 (the marking passes) always has it
+    p.big_inline = (mixed_scale < 0 && gen == 0) ? 1u : 0u;
     p.hist = (u64*)hist; p.hist_passes = 0;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     if (hist_plan && hist && scan_can_count(*hist_plan)) {
@@ -4548,9 +4558,9 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
         for (int i = 0; i < owner_n; ++i) p.owner_bounds[i] = owner_bounds[i];
     }
     switch (kind) {
-        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream, gen, mixed_scale != 0);
-        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream, gen, mixed_scale != 0);
-        default: return launch_scan_expand_kind<2>(p, max_grid, stream, gen, mixed_scale != 0);
+        case 0: return launch_scan_expand_kind<0>(p, max_grid, stream, gen, mixed_scale > 0);
+        case 1: return launch_scan_expand_kind<1>(p, max_grid, stream, gen, mixed_scale > 0);
+        default: return launch_scan_expand_kind<2>(p, max_grid, stream, gen, mixed_scale > 0);
     }
 }
 
@@ -4988,7 +4998,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     if (n_queries == 0 || m == 0) return hipSuccess;
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
-    p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0;
+    p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0; p.big_inline = 0;
     p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;

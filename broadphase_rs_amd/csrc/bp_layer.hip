@@ -103,7 +103,9 @@ struct bp_layer {
     DevBuf blockfill, shards;           // ... records per output block; SX_SHARDS block cursors + SX_SHARDS pair counts
     HostBuf h_shards;
     bool raw_holes = false;             // pairs[0] is block-structured (blockfill, raw_extent slots), not dense
-    bool scan_listed = false;           // the last expanding scan put ranges on its work list (a mixed-scale scene: launch_scan_expand's hint)
+    // what the last expanding scan says about the scene's long ranges (launch_scan_expand's hint): 1 it listed some (mixed-scale:
+    // six waves per SIMD), -1 it listed none (the work-list kernel is not launched), 0 nothing known yet (a new layer, forgotten hints)
+    int scan_listed = 0;
     DevBuf tree_hist;                   // digit counts of the tree's keys, accumulated by encode for tree_hist_plan ...
     RadixPlan tree_hist_plan{};
     bool tree_hist_valid = false;       // ... while the tree is exactly what that one extend produced (m == tree_hist_m)
@@ -1823,7 +1825,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                               (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
                                               (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
                                               (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
-                                              count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1, 0, L->scan_listed ? 1 : 0));
+                                              count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1, 0, L->scan_listed));
             }
             if (L->ahead_try && attempt == 0 && count_digits) {
                 // ---- the pair sort and its finish go out behind the scan, sized by the last frame's numbers; ONE round trip ----
@@ -1923,7 +1925,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 }
                 const DevScalars sc = *(const DevScalars*)L->h_sc.p;
                 const uint32_t* sz = sc_sizes_host(L);
-                L->scan_listed = sz[SIZES_BIG] != 0;  // (the scan's own scalars were reset by the sort's first kernel)
+                L->scan_listed = sz[SIZES_BIG] != 0 ? 1 : -1;  // (the scan's own scalars were reset by the sort's first kernel)
                 if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
                 if (sz[SIZES_MISS] || (cell_route && (sz[SIZES_CELL_MISS] || (sc.err & KERR_SEGMENT_TOO_LONG)))) {
                     // the frame outgrew the margins (or overflowed the work list): everything behind the scan idled; or a cell
@@ -1966,9 +1968,12 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 BP_TRY(settle_sort(L, /*already_synced=*/true, &redone));
                 if (redone) return rerun();
             }
-            L->scan_listed = sc.big_count != 0;
-            if (sc.err & KERR_BIGLIST_OVERFLOW) {  // pathological nesting: the per-entry walk handles it
-                expand = false;
+            const bool was_inline = L->scan_listed < 0;  // (this launch went without the work-list kernel)
+            L->scan_listed = sc.big_count != 0 ? 1 : -1;
+            if (sc.err & KERR_BIGLIST_OVERFLOW) {
+                // without the work-list kernel: a range too long for its wave appeared -- once more, with the kernel;
+                // with it: pathological nesting, the per-entry walk handles it
+                if (!was_inline) expand = false;
                 continue;
             }
             const uint64_t* sh = sc_shards_host(L);
@@ -2293,6 +2298,7 @@ int bp_layer_reset_plan_hints(bp_layer_t* L) {
     L->enc_hint.valid = false;
     L->ahead.valid = false; L->cell_off = 0;
     L->tcell.valid = false; L->tcell_off = 0;
+    L->scan_listed = 0;
     return BP_OK;
 }
 int bp_layer_stream(const bp_layer_t* L, void** stream) {

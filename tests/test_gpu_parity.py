@@ -1143,3 +1143,22 @@ def test_cell_histogram_counted_by_extend_matches_the_kernel(kind, depth):
     assert np.array_equal(fused.cell_histogram(depth), plain.cell_histogram(depth))
     fused.clear(); fused.extend(sysb, bounds, ids)                                             # next frame: fused again
     assert np.array_equal(fused.cell_histogram(depth), exp)
+
+
+def test_scan_without_its_work_list_kernel_when_long_ranges_appear():
+    """a scan that lists no long range tells the next one to go without the work-list kernel (launch_scan_expand's mixed_scale < 0):
+    uniform frames, then frames with giant objects whose ranges are far beyond what a wave walks itself (the scan fails over to a
+    launch WITH the kernel), a frame with moderately long ranges (walked inline), uniform frames again -- the oracle's list every time"""
+    sysb, base, ids = scenes.gen_boxes(150000, seed=3)
+    side = float(sysb[1][0])
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    for f in range(9):
+        b = base.copy()
+        if f in (3, 4, 6):
+            k = 40 if f != 6 else 3
+            b[:k, :3] = (0.01 * side * np.arange(1, k + 1, dtype=np.float32) / k)[:, None]
+            b[:k, 3:] = b[:k, :3] + np.float32(0.45 * side if f != 6 else 0.06 * side)
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
+        assert_pairs_equal(gpu.par_scan(), ref.scan(), "frame %d" % f)
