@@ -242,3 +242,56 @@ def test_compact_switch_off_gives_the_same_lists():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_compact_route_on_random_layers(seed, monkeypatch):
+    """random index kind, size, min_depth, id base / stride and object scale; moving frames with a random extra consumer of the tree
+    in some of them (unsorted iter, clone, second extend, scan_raw) -- every tree and pair list against the oracle.  Exercises the
+    format's corners: no tail level (all objects of one depth), depth 0 entries, 2-D digit tails, id fields of 1 .. 27 bits"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    rng = np.random.default_rng(9000 + seed)
+    kind = int(rng.integers(0, 3))
+    n = int(rng.integers(70000, 260000))
+    min_depth = int(rng.choice([0, 0, 0, 3, 5, 6]))
+    sysb, base, ids = base_scene(kind, n, seed=300 + seed)
+    dim = 3 if kind == 2 else 2
+    shape = int(rng.integers(0, 4))
+    if shape == 1:      # every object the same size: one depth, no digit tail
+        c = (base[:, :dim] + base[:, dim:]) * np.float32(0.5)
+        h = np.float32(0.5 * float(np.median(base[:, dim:] - base[:, :dim])))
+        base = np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+    elif shape == 2:    # a few objects as large as the system (depth 0 / 1 entries), the rest as generated
+        k = 5
+        lo = np.asarray(sysb[0], dtype=np.float32)[:dim]; hi = np.asarray(sysb[1], dtype=np.float32)[:dim]
+        base[:k, :dim] = lo + (hi - lo) * np.float32(0.01)
+        base[:k, dim:] = lo + (hi - lo) * np.float32(0.97)
+    stride = int(rng.choice([1, 1, 3, 17]))
+    id_base = int(rng.choice([0, 0, 1 << 20, (1 << 27) + 5, 3_000_000_000]))
+    ids = (np.arange(n, dtype=np.uint64) * stride + id_base).astype(np.uint32)
+    gpu = bp.Layer(KINDS[kind], min_depth)
+    for f in range(7):
+        b = moved(kind, sysb, base, f, amount=0.3) if shape != 2 else base.copy()
+        if shape == 2 and f:   # (the giants stay, the rest moves)
+            b[5:] = moved(kind, sysb, base[5:], f, amount=0.3)
+        ref = oracle.OracleLayer(kind, min_depth)
+        gpu.clear()
+        gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
+        what = "seed %d kind %d n %d min_depth %d shape %d ids %d+%d*i frame %d" % (seed, kind, n, min_depth, shape, id_base, stride, f)
+        op = int(rng.integers(0, 6)) if f >= 3 else 0
+        if op == 1:
+            check_tree(gpu, ref, what + " unsorted")
+        elif op == 2:
+            twin = gpu.clone()
+            check_tree(twin, ref, what + " clone")
+        elif op == 3:
+            m = 2000
+            eb = moved(kind, sysb, base[:m], 100 + f, amount=0.3)
+            eids = (np.arange(m, dtype=np.uint64) * stride + id_base + n * stride).astype(np.uint32)
+            gpu.extend(sysb, eb, eids); ref.extend(sysb, eb, eids)
+        elif op == 4:
+            raw_ref, _ = ref.scan_raw()
+            check_pairs(gpu.scan_raw(), raw_ref, what + " scan_raw")
+        gpu.par_sort(); ref.sort()
+        check_tree(gpu, ref, what + " par_sort")
+        check_pairs(gpu.par_scan(), ref.scan(), what + " par_scan")
