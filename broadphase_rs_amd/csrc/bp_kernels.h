@@ -122,7 +122,10 @@ hipError_t launch_tree_expand(int kind, uint64_t* words, uint32_t* ids_out, uint
 
 // ---- encode (K1..K3): reference src/layer.rs:94-121, src/geom.rs:121-128,148-163,189-304 ------
 constexpr int ENC_THREADS = 256;
-constexpr int ENC_ROUNDS = 4;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
+#ifndef ENC_ROUNDS_DEF
+#define ENC_ROUNDS_DEF 4
+#endif
+constexpr int ENC_ROUNDS = ENC_ROUNDS_DEF;     // blocks of ENC_THREADS objects per workgroup of encode_count / encode_emit
 constexpr int ENC_STAGE = 2048;   // entries of one round staged in LDS by encode_emit (8 per object)
 constexpr int ENC_CELLS_MAX = 512; // cells encode_emit can histogram (8^3 in 3-D, 4^4 in 2-D)
 constexpr int HIST_COPIES = 32;   // copies of the digit histograms encode_emit spreads its atomics over
