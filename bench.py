@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the configs[1] (1 M objects) sub-record")
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-scene sub-record")
+    ap.add_argument("--no-extra", action="store_true", help="skip the mixed_scale / aabb_filter / one_shot sub-records")
+    ap.add_argument("--mixed-objects", type=int, default=12_500_000, help="objects of the mixed_scale sub-record (configs[4]'s per-GPU share)")
     ap.add_argument("--moving-frames", type=int, default=20)
     ap.add_argument("--sharded", action="store_true", help="run the multi-GPU pipeline even with one rank (rehearsal)")
     ap.add_argument("--pair-order", choices=["global", "local"], default="local",
@@ -174,7 +176,8 @@ def kernel_table(n, M, P_raw, P, cells=False, tree_cells=False, tree_compact=Fal
         "encode": ("encode_count_kernel + encode_emit_kernel (contains + to_local + indices: AABB -> index entries)",
                    28.0 * n + (8.0 if tree_compact else 12.0) * M),
         "tree_sort": (tree_sort, (16.0 if tree_compact else 24.0) * M),
-        "tree_finish": ("tgroup_finishc_kernel (LDS finish of the tree sort: compact records in, index values + context words out)", 8.0 * M + 12.0 * M)
+        "tree_finish": ("tgroup_finishc_kernel (LDS finish of the tree sort: compact records in; index values, {id, context} words and depth / "
+                        "range-length words out)", 8.0 * M + 18.0 * M)
                        if tree_compact else ("tgroup_finish_kernel (LDS finish of the tree sort)", 24.0 * M),
         "scan_emit": ("scan_expand_kernel (overlap scan, single pass)", 12.0 * M + 8.0 * P_raw),
         "pair_sort": (pair_sort, 16.0 * P_raw),
@@ -249,6 +252,7 @@ def run_single(bp, scenes, torch, np, dev, local_rank, n, seed, warmup, steps, a
         layer.profile_enable(False)
         res["detail_steps"], res["prof"] = k, layer.profile()
     res["stats"], res["n_pairs"], res["out"], res["layer"] = layer.stats(), len(out), out, layer
+    res["scene"], res["d_bounds"] = (sysb, d_ids), d_bounds
     return res
 
 
@@ -322,6 +326,119 @@ def run_moving(bp, scenes, torch, np, dev, local_rank, n, seed, frames, check_la
     return rec
 
 
+def run_mixed_scale(bp, scenes, torch, np, dev, local_rank, n, seed, steps, check):
+    """configs[4]'s per-GPU share: n objects with Pareto(alpha = 2.5) sizes (scenes.gen_boxes_powerlaw) -- long ranges, the
+    work-list kernel, a deep stack in the reference.  Steady-state frames like the headline; the pair SET is compared with
+    the CPU restatement's on the same boxes (check) -- fingerprint (count, sum p, sum p^2 mod 2^64)."""
+    sysb, bounds, ids = scenes.gen_boxes_powerlaw(n, seed=seed, alpha=2.5)
+    d_bounds = torch.from_numpy(bounds).to(dev)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    layer = bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank).build(bp.Index64_3D)
+
+    def step():
+        layer.clear(); layer.extend(sysb, d_bounds, d_ids); layer.par_sort()
+        return layer.scan_device()
+
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    st = layer.stats()
+    rec = {"workload": "configs[4]'s per-GPU share: %d Index64_3D AABBs, isotropic Pareto(x_m = 1, alpha = 2.5) sizes capped at L / 4, "
+                       "gen_boxes placement and density; clear+extend+par_sort+par_scan, steady state, %d steps" % (n, steps),
+           "ms_per_step": ms, "entries": st["entries"], "candidates_examined": st.get("raw_candidates", 0), "raw_pairs": st["raw_pairs"],
+           "pairs": len(out), "value": len(out) / (ms * 1e-3), "unit": "pairs/s",
+           "tree_sort_passes": st["tree_sort_passes"], "pair_sort_passes": st["pair_sort_passes"],
+           "set_hash": set_hash_torch(out.as_torch()) if len(out) else [0, 0, 0]}
+    if check:
+        import oracle  # checker only
+        ref = oracle.OracleLayer(oracle.INDEX64_3D, 0)
+        ref.extend(sysb, bounds, ids)
+        threads = usable_cpus(oracle.lib().orc_hw_threads())
+        t0 = time.perf_counter()
+        ref.par_sort(threads)
+        exp = ref.par_scan(threads)
+        rec["cpu_seconds"] = time.perf_counter() - t0
+        rec["parity"] = set_hash_numpy(exp) == rec["set_hash"] and list_hash_numpy(exp) == list_hash_torch(out.as_torch())
+        rec["parity_note"] = "pair list (count, sum p, sum p^2, sum p (2 i + 1) mod 2^64) == the CPU restatement's on the same boxes"
+    else:
+        rec["parity"] = None
+    del layer
+    return rec
+
+
+def run_aabb_filter(bp, torch, np, dev, r, d_bounds, steps):
+    """scan_filtered(|a, b| bounds[a] overlaps bounds[b]) with the predicate inside the fused scan, on the
+    headline scene and the headline's layer.  Parity: the same predicate applied with torch ops to the UNFILTERED device list
+    (itself checked against the CPU list by parity_in_run) must leave the same list."""
+    layer = r["layer"]
+    sysb, d_ids = r["scene"]
+
+    def step():
+        layer.clear(); layer.extend(sysb, d_bounds, d_ids); layer.par_sort()
+        return layer.scan_filtered_aabb_device(d_bounds)
+
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    got = list_hash_torch(out.as_torch()) if len(out) else [0, 0, 0]
+    n_out = len(out)
+    # the reference filter on the unfiltered list (inclusive overlap, geom.rs:112-119), in slices to bound the temporaries
+    layer.clear(); layer.extend(sysb, d_bounds, d_ids); layer.par_sort()
+    full = layer.scan_device().as_torch()
+    keep = torch.empty(full.shape[0], dtype=torch.bool, device=full.device)
+    CH = 1 << 24
+    for a in range(0, full.shape[0], CH):
+        ia = full[a:a + CH, 0].to(torch.int64) & 0xFFFFFFFF
+        ib = full[a:a + CH, 1].to(torch.int64) & 0xFFFFFFFF
+        ba, bb = d_bounds[ia], d_bounds[ib]
+        keep[a:a + CH] = ((ba[:, :3] <= bb[:, 3:]) & (bb[:, :3] <= ba[:, 3:])).all(dim=1)
+        del ia, ib, ba, bb
+    want = list_hash_torch(full[keep])
+    return {"workload": "the headline scene: clear+extend+par_sort+par_scan_filtered with the box-overlap predicate evaluated on the device "
+                        "inside the scan (bp_layer_scan_filtered_aabb_device), steady state, %d steps" % steps,
+            "ms_per_step": ms, "pairs": n_out, "candidate_pairs_unfiltered": int(full.shape[0]),
+            "value": n_out / (ms * 1e-3), "unit": "box-overlapping pairs/s", "list_hash": got,
+            "parity": got == want,
+            "parity_note": "list fingerprint == that of the unfiltered device list (parity_in_run) filtered with the same predicate by torch ops"}
+
+
+def run_one_shot(bp, scenes, torch, np, dev, local_rank, n, seed, pairs_hint, entries_hint, repeats=3):
+    """what a reference test does (tests/test_layer.rs:92-124): a FRESH layer, capacities given to the builder
+    (with_index_capacity / with_collision_capacity), one extend + par_sort + par_scan.  No plan hints, no previous frame."""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=seed)
+    d_bounds = torch.from_numpy(bounds).to(dev)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    times, n_out, st = [], 0, {}
+    for _ in range(repeats):
+        layer = (bp.LayerBuilder.new().with_min_depth(0).with_device(local_rank)
+                 .with_index_capacity(entries_hint).with_collision_capacity(pairs_hint).build(bp.Index64_3D))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        layer.extend(sysb, d_bounds, d_ids)
+        layer.par_sort()
+        out = layer.scan_device()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        n_out, st = len(out), layer.stats()
+        del out, layer
+    return {"workload": "%d objects, a fresh layer per run built with with_index_capacity(%d).with_collision_capacity(%d): "
+                        "extend + par_sort + par_scan once (%d runs)" % (n, entries_hint, pairs_hint, repeats),
+            "ms_per_step": min(times), "ms_runs": [round(t, 4) for t in times], "pairs": n_out,
+            "value": n_out / (min(times) * 1e-3), "unit": "pairs/s",
+            "tree_sort_passes": st.get("tree_sort_passes"), "pair_sort_passes": st.get("pair_sort_passes"),
+            "note": "ms_per_step = the fastest run (the first also pays one-time runtime initialisation of the kernels it is the first to launch)"}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -359,6 +476,17 @@ def main():
                                  "cold_frame_ms": r1["cold_frame_ms"], "host_syncs_per_step": r1["host_syncs_per_step"],
                                  "tree_sort_passes": r1["stats"]["tree_sort_passes"], "pair_sort_passes": r1["stats"]["pair_sort_passes"]}
             del r1
+        if not args.no_extra and not args.aabb_filter:
+            # sub-records the driver's default run verifies: configs[4]'s per-GPU share, the fused narrow phase, a one-shot layer
+            line["aabb_filter"] = run_aabb_filter(bp, torch, np, dev, r, r["d_bounds"], 5)
+            st10 = r["stats"]
+            line["one_shot"] = run_one_shot(bp, scenes, torch, np, dev, local_rank, args.objects, args.seed,
+                                            int(st10["pairs"] * 1.07), int(st10["entries"] * 1.07))
+        r.pop("layer", None); r.pop("scene", None); r.pop("d_bounds", None)
+        torch.cuda.empty_cache()
+        if not args.no_extra and not args.aabb_filter:
+            line["mixed_scale"] = run_mixed_scale(bp, scenes, torch, np, dev, local_rank, args.mixed_objects, args.seed, 5,
+                                                  check=not args.no_cpu_baseline)
         if not args.no_moving and not args.aabb_filter:
             line["moving"] = run_moving(bp, scenes, torch, np, dev, local_rank, args.objects, args.seed, args.moving_frames,
                                         check_last=not args.no_cpu_baseline)
@@ -577,8 +705,9 @@ def single_gpu_line(args, r, np):
         # (compact records: one 8-byte word per entry from the emit pass to the finish instead of a 12-byte (index, id) entry)
         "encode": 28.0 * n + 4.0 * n + 16.0 * n * 2 + (8.0 if compact else 12.0) * M,  # bounds + ids read once, the 16-byte object record written and read, entries written
         "tree_sort": (16.0 if compact else 24.0) * M * pk,
-        "tree_finish": (8.0 if compact else 12.0) * M + (16.0 if compact else 21.0) * M,  # record read; key, {id, ctx} word written (+ id, box byte off the compact route, where they are derived from the words on demand)
-        "scan_emit": 16.0 * M + 8.0 * P_raw,                      # keys + {id, ctx} words read, packed pairs written
+        "tree_finish": (8.0 if compact else 12.0) * M + (18.0 if compact else 21.0) * M,  # record read; key, {id, ctx} word and (compact route, round 5) the 2-byte depth / range-length word written (+ id, box byte off the compact route, where they are derived from the words on demand)
+        # compact route (round 5): {id, ctx} words + depth / range-length words read -- no key; else keys + {id, ctx} words; packed pairs written
+        "scan_emit": (10.0 if compact else 16.0) * M + 8.0 * P_raw,
         "pair_sort": 16.0 * P_raw * pp,
         "dedup": 8.0 * P_raw + 8.0 * P,
     }

@@ -341,7 +341,7 @@ hipError_t launch_scan_fused(int kind, ScanParams p, uint64_t* pairs_out, size_t
 // more blocks when extent exceeds the capacity.  big_list: scratch for big_cap work items of TWO u64 each;
 // KERR_BIGLIST_OVERFLOW in sc->err means the result is incomplete (use scan_fused).
 #ifndef SX_BLOCK_DEF
-#define SX_BLOCK_DEF 256
+#define SX_BLOCK_DEF 128
 #endif
 constexpr uint32_t SX_BLOCK = SX_BLOCK_DEF;
 constexpr int SX_SHARDS = 64;
@@ -361,7 +361,12 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan = nullptr, unsigned long long* hist = nullptr,
-                              const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0, int mixed_scale = 0);
+                              const uint32_t* owner_bounds = nullptr, int owner_n = -1, int gen = 0, int mixed_scale = 0,
+                              const uint16_t* dcnt = nullptr, uint32_t hist_rows = 0xFFFFFFFFu);
+// hist_rows: bit q = count row q of hist_plan (a sort that reads one of the digits only: the others stay zero)
+constexpr size_t SCAN_PAD_ENTRIES = 128;  // with dcnt: idctx and dcnt must be READABLE this many entries beyond m (the scan's loads are not clamped)
+// dcnt (round 5; null: the kernel searches the range ends itself): per entry, depth | range length << 5 -- the number of entries
+// behind it that lie in its cell (0x7FF: unknown, searched) -- as launch_tgroup_finish_compact leaves it; not used by gen 1 / 2
 // mixed_scale (speed, never results): > 0: the tree has ranges long enough for the work list (the previous scan listed some): the
 // kernel instance that keeps six waves per SIMD instead of seven; < 0: the previous scan listed none -- the work-list kernel is
 // not launched, a range of up to 4 x 16384 candidates stays with its wave and a longer one sets KERR_BIGLIST_OVERFLOW (the caller
@@ -459,7 +464,8 @@ hipError_t launch_ids_from_ctx(const uint64_t* idctx, uint32_t* ids_out, uint8_t
 bool tgroup_compact_applies(int comp_gshift);  // the composite's group shift leaves room for the finish kernel's bin digit
 hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_groups, int comp_gshift, const TreeCompact& fmt, uint64_t* keys_out,
                                         uint32_t* ids_out, uint8_t* box_out, DevScalars* sc, hipStream_t stream, int ctx_kind, uint64_t* idctx_out,
-                                        const uint32_t* stats, uint32_t abort_over, const struct CellRoute& cells);
+                                        uint16_t* dcnt_out, const uint32_t* stats, uint32_t abort_over, const struct CellRoute& cells);
+// dcnt_out (round 5): per entry, depth | range length << 5 -- what launch_scan_expand's dcnt takes
 // distinct_id_bits > 0 (with payload_packed): the caller vouches that the ids are DISTINCT and below 2^distinct_id_bits; where
 // the rest of the key and the id fit one 64-bit word the composite-key kernel runs (a group above the capacity then sets
 // KERR_SEGMENT_TOO_LONG instead of taking the multi-round path)

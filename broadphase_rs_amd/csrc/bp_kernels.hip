@@ -2147,24 +2147,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 // Ranges of SX_BIG or more candidates (large objects) are cut into slices on a work list and
 // spread over the whole grid by scan_expand_big_kernel.
 // =================================================================================================
-// Per-entry word: id << 32 | ctx.  ctx packs what the candidate test needs, laid out so that the test is a dozen
-// full-rate VALU instructions on whole words (no per-axis field extraction):
-//   byte a = 0, 1, 2 (one per axis):  bits 0..4  g_a = depth - (trailing count): the box's other cell on axis a leaves
-//                                                the ancestor cell of depth dd  <=>  dd >= g_a   (0 when the axis has one cell)
-//                                     bit  5     always 0 (the borrow guard of the byte-wise subtraction below;
-//                                                byte 0's bit 5 is CTX_SKIPPED in the repeated-id modes)
+// Per-entry word: id << 32 | ctx.  ctx packs what the candidate test needs, laid out so that the test is THREE
+// full-rate VALU instructions on whole words (a subtraction, a mask, a compare):
+//   byte a = 0, 1, 2 (one per axis):  bits 0..4  G_a: where this entry is the UPPER of its box's two cells on axis a, g_a = depth -
+//                                                (trailing zeros of the cell's coordinate) -- the box's other (lower) cell on that axis
+//                                                leaves the ancestor cell of depth dd  <=>  dd >= g_a, and g_a >= 1; else 0
+//                                     bit  5     always 0 (the guard of the byte-wise subtraction below); byte 0's bit 5 is
+//                                                CTX_SKIPPED: set (with G_0 = 0), the entry takes no part as the deeper side -- the skip
+//                                                rule's mark in the repeated-id modes, and the coarse entries of a shard scan
 //                                     bits 6..7  t_a = this entry's box code on the axis (0 one cell, 1 lower, 2 upper of two)
-//   byte 3:  table'' -- bit k (k = 3-bit set of axes on which the other cell is NOT inside the ancestor's box) set <=> the
-//            pair is emitted by an earlier cell of this object (suppressed).  Axes with one cell are don't-cares of the
-//            table, so the test needs no `two` mask.  0xFF: the entry takes no part as the deeper side (CTX_INACTIVE:
-//            a legitimate table never has bit 7 set -- with every other cell outside nothing can be earlier).
-// The ancestor (owner) side supplies two words: DJ = (dd | 32) in each of the three low bytes and CBJ = its own t fields
-// (= its ctx & CTX_CODE_MASK).
-constexpr u32 CTX_INACTIVE = 0xFF000000u;
-constexpr u32 CTX_G_MASK = 0x001F1F1Fu, CTX_GUARD = 0x00202020u, CTX_CODE_MASK = 0x00C0C0C0u;
-// ids that may repeat (GEN modes below): the context carries no suppression data (table'' = 0), bit 5 marks an entry the
-// reference's skip rule drops entirely (some ancestor carries the same id, src/layer.rs:563-565)
+//   byte 3:  0
+// Which combo emits a pair: the reference emits (a, b) once per containment combo (a cell of `a` inside a cell of `b`), and only the
+// combo of the MINIMAL-KEY cell of `a` inside `b`'s box is kept here.  The cells of `a` inside `b`'s box are a product of per-axis
+// choices, and the Morton order of two cells of one box is decided by the axis whose differing bit is most significant -- on which the
+// upper cell is the larger: so the minimal cell takes the lower cell wherever it is inside, and entry i is that cell  <=>  on every axis
+// where i is the upper of two, the lower cell is NOT inside b's box  <=>  it leaves j's cell (dd >= g_a) and j is not itself the upper of
+// b's two cells there (else b's lower cell covers it).  (Rounds 1 - 4 indexed an 8-bit table per entry by the 3-bit set of axes; the table's
+// subset closure reduces to this conjunction -- tests/test_ctx_rule.py checks the two rules against each other and against brute force.)
+// The ancestor (owner) side supplies ONE word: DJ byte a = 0xE0 | (t_a(j) == 2 ? 0 : dd).  Then t = DJ - ctx has no borrow between bytes
+// (0xE0 >= 0xBF, the largest context byte), the code bits and 0xC0 of DJ cancel out of bit 5, and bit 5 of byte a  <=>  dd' >= G_a:
+// keep  <=>  (t & 0x202020) == 0x202020.  A skipped / inactive entry (byte 0 = 0x20 | code) always fails: 0xE0 + dd' - 0x20 has bit 5 clear.
+constexpr u32 CTX_GUARD = 0x00202020u;
 constexpr u32 CTX_SKIPPED = 1u << 5;
+constexpr u32 CTX_INACTIVE = CTX_SKIPPED;
+// an owner word no context passes (the null record behind a chunk's owners): byte 0 cannot borrow, byte 1 = 0xDF - (64 t + G) has bit 5 clear
+constexpr u32 CTX_DJ_NONE = 0x00E0DFFFu;
+__host__ __device__ constexpr u32 ctx_codebits(u32 c27) {  // c27 = t_x + 3 t_y + 9 t_z
+    return ((c27 % 3u) << 6) | (((c27 % 9u) / 3u) << 14) | ((c27 / 9u) << 22);
+}
+// G bytes from the per-axis trailing-zero counts f_a of the cell's coordinates: (depth - f_a) on the axes whose code is 2
+__device__ __forceinline__ u32 ctx_g_bytes(u32 codebits, u32 d, u32 f0, u32 f1, u32 f2) {
+    const u32 up = ((codebits >> 7) & 0x010101u) * 0x1Fu;            // 0x1F in the bytes of the upper-of-two axes
+    return (d * 0x010101u - (f0 | (f1 << 8) | (f2 << 16))) & up;    // (f_a <= d: no borrow)
+}
 template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 code, u32 inactive_below) {
     BoxCtx<KIND> bx;
     bx.init(key, code);
@@ -2173,51 +2188,19 @@ template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 c
     const u32 cb = code == BOX_UNKNOWN ? 0u : code;
     const u32 codebits = ((cb & 3u) << 6) | (((cb >> 2) & 3u) << 14) | (((cb >> 4) & 3u) << 22);
     if (d < inactive_below) return CTX_INACTIVE | codebits;
-    if (code == BOX_UNKNOWN || bx.table == 0) return codebits;  // nothing is ever suppressed
-    const u32 two = bx.two;
-    const u32 g0 = (two & 1u) ? d - (bx.thr & 0xFFu) : 0u, g1 = (two & 2u) ? d - ((bx.thr >> 8) & 0xFFu) : 0u,
-              g2 = (two & 4u) ? d - ((bx.thr >> 16) & 0xFFu) : 0u;
-    // table''[k] = table[(~k & 7) & two]
-    u32 t2 = 0;
-#pragma unroll
-    for (u32 k = 0; k < 8; ++k) t2 |= ((bx.table >> ((~k & 7u) & two)) & 1u) << k;
-    return g0 | (g1 << 8) | (g2 << 16) | codebits | (t2 << 24);
+    if (code == BOX_UNKNOWN) return 0u;  // nothing is ever suppressed
+    return ctx_g_bytes(codebits, d, bx.thr & 0xFFu, (bx.thr >> 8) & 0xFFu, (bx.thr >> 16) & 0xFFu) | codebits;
 }
-// The same word through a lookup table (the kernels that build context words per entry -- entry_ctx, tgroup_finish2 --
-// are VALU-bound): everything BoxCtx derives besides the per-axis g fields depends only on the box code (27 ternary
-// values) and on the ORDER of the deciding Morton bit positions p_a = DIM * f_a + a of the two-cell axes, i.e. on three
-// comparisons (p_1 > p_0 <=> f_1 >= f_0, p_2 > p_0 <=> f_2 >= f_0, p_2 > p_1 <=> f_2 >= f_1).  CtxLut[code * 8 + cmp] =
-// code fields | table'' << 24, generated at compile time from the same rule as BoxCtx::init.
-struct CtxLut { u32 e[27 * 8]; };
-constexpr u32 ctx_lut_entry(u32 c27, u32 cmp) {
-    const u32 t2 = c27 / 9u, t1 = (c27 % 9u) / 3u, t0 = c27 % 3u;
-    const bool ge10 = cmp & 1u, ge20 = cmp & 2u, ge21 = cmp & 4u;
-    const bool dn0 = t0 == 2u, dn1 = t1 == 2u, dn2 = t2 == 2u;
-    u32 ds = 0;
-    if (t0 && dn0) ds |= 1u << 1;
-    if (t1 && dn1) ds |= 1u << 2;
-    if (t2 && dn2) ds |= 1u << 4;
-    if (t0 && t1 && (ge10 ? dn1 : dn0)) ds |= 1u << 3;
-    if (t0 && t2 && (ge20 ? dn2 : dn0)) ds |= 1u << 5;
-    if (t1 && t2 && (ge21 ? dn2 : dn1)) ds |= 1u << 6;
-    if (t0 && t1 && t2 && ((ge21 && ge20) ? dn2 : (ge10 ? dn1 : dn0))) ds |= 1u << 7;
-    u32 tb = ds;
-    tb |= (tb & 0x55u) << 1;
-    tb |= (tb & 0x33u) << 2;
-    tb |= (tb & 0x0Fu) << 4;
-    const u32 two = (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u);
-    u32 tpp = 0;
-    for (u32 k = 0; k < 8; ++k) tpp |= ((tb >> ((~k & 7u) & two)) & 1u) << k;
-    return (t0 << 6) | (t1 << 14) | (t2 << 22) | (tpp << 24);
-}
+// The same word without BoxCtx (the kernels that build context words per entry -- entry_ctx, the tree finishes -- are VALU-bound):
+// the code fields come from a 27-entry table, the G bytes from the trailing zeros of the three coordinate lanes.
+struct CtxLut { u32 e[32]; };
 constexpr CtxLut make_ctx_lut() {
     CtxLut l{};
-    for (u32 c = 0; c < 27; ++c)
-        for (u32 m = 0; m < 8; ++m) l.e[c * 8 + m] = ctx_lut_entry(c, m);
+    for (u32 c = 0; c < 32; ++c) l.e[c] = c < 27u ? ctx_codebits(c) : 0u;
     return l;
 }
 __constant__ CtxLut g_ctx_lut = make_ctx_lut();
-constexpr int CTX_LUT_WORDS = 27 * 8;
+constexpr int CTX_LUT_WORDS = 32;
 // every thread of the workgroup calls this before the first entry_ctx_lut (ends with a barrier)
 __device__ __forceinline__ void ctx_lut_load(u32* s_lut) {
     for (int k = (int)threadIdx.x; k < CTX_LUT_WORDS; k += (int)blockDim.x) s_lut[k] = g_ctx_lut.e[k];
@@ -2229,53 +2212,31 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_wide(u64 key, u
     constexpr u64 LANE = DIM == 3 ? 0x1249249249249249ull : 0x5555555555555555ull;
     const u32 d = key_depth<KIND>(key);
     if (c27 >= 27u) return d < inactive_below ? CTX_INACTIVE : 0u;  // unknown box: own cell only, never suppressed
-    const u32 t2 = (c27 * 57u) >> 9, r = c27 - 9u * t2, t1 = (r * 11u) >> 5, t0 = r - 3u * t1;
+    const u32 codebits = s_lut[c27];
+    if (d < inactive_below) return CTX_INACTIVE | codebits;
     const u64 md = d == 0 ? 0ull : ((key >> DB) >> (DIM * (AB - d)));  // DIM * depth Morton bits
-    const u64 valid = d == 0 ? 0ull : ((1ull << (DIM * d)) - 1ull);
-    // per axis: trailing ones (this is the lower cell: the other one is a step up) / zeros (a step down) of the coordinate
-    u32 f0, f1, f2 = 0;
-    {
-        const u64 src = t0 == 1u ? ((~md) & LANE & valid) : (md & LANE);
-        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
-        f0 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
-    }
-    {
-        const u64 src = t1 == 1u ? ((~(md >> 1)) & LANE & (valid >> 1)) : ((md >> 1) & LANE);
-        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
-        f1 = DIM == 3 ? (c * 171u) >> 9 : c >> 1;
-    }
-    if (DIM == 3) {
-        const u64 src = t2 == 1u ? ((~(md >> 2)) & LANE & (valid >> 2)) : ((md >> 2) & LANE);
-        const u32 c = src ? (u32)__builtin_ctzll(src) : DIM * d;
-        f2 = (c * 171u) >> 9;
-    }
-    const u32 cmp = (f1 >= f0 ? 1u : 0u) | (f2 >= f0 ? 2u : 0u) | (f2 >= f1 ? 4u : 0u);
-    const u32 e = s_lut[c27 * 8u + cmp];
-    if (d < inactive_below) return CTX_INACTIVE | (e & CTX_CODE_MASK);
-    return e | (t0 ? d - f0 : 0u) | ((t1 ? d - f1 : 0u) << 8) | ((t2 ? d - f2 : 0u) << 16);
+    // per axis: trailing zeros of the coordinate (this is the upper cell: the other one is a step down); an empty lane: the whole coordinate
+    const u64 s0 = md & LANE, s1 = (md >> 1) & LANE, s2 = DIM == 3 ? (md >> 2) & LANE : 0ull;
+    const u32 c0 = s0 ? (u32)__builtin_ctzll(s0) : DIM * d, c1 = s1 ? (u32)__builtin_ctzll(s1) : DIM * d, c2 = s2 ? (u32)__builtin_ctzll(s2) : DIM * d;
+    const u32 f0 = DIM == 3 ? (c0 * 171u) >> 9 : c0 >> 1, f1 = DIM == 3 ? (c1 * 171u) >> 9 : c1 >> 1, f2 = DIM == 3 ? (c2 * 171u) >> 9 : 0u;
+    return ctx_g_bytes(codebits, d, f0, f1, f2) | codebits;
 }
 // The same word where the entry's DIM * depth Morton bits fit 32 (depth <= 10 in 3-D, <= 16 in 2-D): the three axes' trailing
-// runs come out of ONE 32-bit word -- the lanes of the axes whose run is of ones are flipped, then per axis a mask, a find-first-
-// bit and a minimum with DIM * depth (an empty lane: the run is the whole coordinate).  A third of the wide version's
-// instructions, in kernels that are bound by instruction issue (the finish of the tree sort spends most of its instructions here).
+// runs come out of ONE 32-bit word -- per axis a mask, a find-first-bit and a minimum with DIM * depth (an empty lane).
 template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_narrow(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
     constexpr u32 DIM = KT<KIND>::DIM, AB = KT<KIND>::AB, DB = KT<KIND>::DB;
     constexpr u32 L0 = DIM == 3 ? 0x49249249u : 0x55555555u, L1 = L0 << 1, L2 = DIM == 3 ? L0 << 2 : 0u;
     const u32 d = key_depth<KIND>(key);
     if (c27 >= 27u) return d < inactive_below ? CTX_INACTIVE : 0u;
-    const u32 t2 = (c27 * 57u) >> 9, r = c27 - 9u * t2, t1 = (r * 11u) >> 5, t0 = r - 3u * t1;
+    const u32 codebits = s_lut[c27];
+    if (d < inactive_below) return CTX_INACTIVE | codebits;
     const u32 nb = DIM * d;                                      // <= 32 (the caller checks)
-    const u32 md = (u32)(key >> (DB + DIM * (AB - d)));         // (depth 0: everything shifts out)
-    const u32 valid = nb >= 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
-    const u32 flip = (t0 == 1u ? L0 : 0u) | (t1 == 1u ? L1 : 0u) | (t2 == 1u ? L2 : 0u);
-    const u32 w = (md ^ flip) & valid;
-    const u32 s0 = w & L0, s1 = w & L1, s2 = w & L2;
-    const u32 p0 = s0 ? (u32)__builtin_ctz(s0) : nb, p1 = s1 ? (u32)__builtin_ctz(s1) : nb, p2 = (DIM == 3 && s2) ? (u32)__builtin_ctz(s2) : nb;
+    const u32 md = (u32)(key >> (DB + DIM * (AB - d)));         // (depth 0: everything shifts out; nothing above bit nb - 1)
+    const u32 s0 = md & L0, s1 = md & L1, s2 = md & L2;
+    const u32 p0 = s0 ? (u32)__builtin_ctz(s0) : nb, p1 = s1 ? (u32)__builtin_ctz(s1) : nb,
+              p2 = DIM == 3 ? s2 ? (u32)__builtin_ctz(s2) : nb : nb;
     const u32 f0 = DIM == 3 ? (p0 * 171u) >> 9 : p0 >> 1, f1 = DIM == 3 ? (p1 * 171u) >> 9 : p1 >> 1, f2 = DIM == 3 ? (p2 * 171u) >> 9 : 0u;
-    const u32 cmp = (f1 >= f0 ? 1u : 0u) | (f2 >= f0 ? 2u : 0u) | (f2 >= f1 ? 4u : 0u);
-    const u32 e = s_lut[c27 * 8u + cmp];
-    if (d < inactive_below) return CTX_INACTIVE | (e & CTX_CODE_MASK);
-    return e | (t0 ? d - f0 : 0u) | ((t1 ? d - f1 : 0u) << 8) | ((t2 ? d - f2 : 0u) << 16);
+    return ctx_g_bytes(codebits, d, f0, f1, f2) | codebits;
 }
 template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
     constexpr u32 DIM = KT<KIND>::DIM;
@@ -2283,19 +2244,14 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c2
     if (ballot64(DIM * key_depth<KIND>(key) > 32u) == 0ull) return entry_ctx_lut_narrow<KIND>(key, c27, inactive_below, s_lut);
     return entry_ctx_lut_wide<KIND>(key, c27, inactive_below, s_lut);
 }
-// owner-side words of an ancestor entry of depth dd whose own context word is ctx_j
-__device__ __forceinline__ u32 ctx_owner_dj(u32 dd) { return (dd | 32u) * 0x010101u; }
-__device__ __forceinline__ u32 ctx_owner_cbj(u32 ctx_j) { return ctx_j & CTX_CODE_MASK; }
-// is candidate (entry i with context ctx_i, ancestor j described by dj / cbj) the emitting combo?
-__device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 dj, u32 cbj) {
-    const u32 t = dj - (ctx_i & CTX_G_MASK);      // per byte dd + 32 - g_a >= 1: no borrow; bit 5 <=> dd >= g_a (crossing)
-    const u32 x = ctx_i ^ cbj;                    // bits 6..7 of each byte: zero <=> the ancestor's box covers the other cell
-    const u32 y = (x >> 1) | (x >> 2);            // bit 5 of each byte: code mismatch
-    const u32 v = t & y & CTX_GUARD;              // bit 5 of byte a: the other cell on axis a is NOT inside the ancestor's box
-    // gather bits 5, 13, 21 into a 3-bit index: 24-bit multiply (full rate), products land on bits 21, 22, 23 with no carries
-    const u32 idx = (__umul24(v, (1u << 16) | (1u << 9) | (1u << 2)) >> 21) & 7u;
-    return ((ctx_i >> (24u + idx)) & 1u) == 0u;
+// owner-side word of an ancestor entry of depth dd whose own context word is ctx_j: 0xE0 | dd per byte, dd = 0 on the axes where j is
+// the upper of its box's two cells (its lower cell covers a candidate's lower neighbour there: nothing passes, g_a >= 1)
+__device__ __forceinline__ u32 ctx_owner_dj(u32 dd, u32 ctx_j) {
+    const u32 up = ((ctx_j >> 7) & 0x010101u) * 0x1Fu;
+    return (0x00E0E0E0u | (dd * 0x010101u)) & ~up;
 }
+// is candidate (entry i with context ctx_i, ancestor j described by dj) the emitting combo?
+__device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 dj) { return ((dj - ctx_i) & CTX_GUARD) == CTX_GUARD; }
 
 // active_lo / active_hi: entries of depth < inactive_below whose id lies in this range stay active all the same (shard
 // scans: coarse-coarse pairs are emitted by the rank that owns the deeper entry's id); lo > hi: no such range
@@ -2331,16 +2287,21 @@ __device__ unsigned long long g_sx_wave[8192][4];  // per wave of the last launc
 #endif
 constexpr int SX_THREADS = 256;
 constexpr int SX_WAVES = SX_THREADS / 64;
-constexpr u32 SX_STAGE = SX_BLOCK + 128;  // per-wave LDS stage: one output block and the most one push can add to it
+#ifndef SX_STAGE_DEF
+#define SX_STAGE_DEF 512
+#endif
+constexpr u32 SX_STAGE = SX_STAGE_DEF;  // per-wave LDS stage: what is left of the previous chunk (< one block) + a chunk's pairs (a chunk that needs more drains in the middle)
 #ifndef SX_BIG_DEF
 #define SX_BIG_DEF 16384
 #endif
 constexpr u32 SX_BIG = SX_BIG_DEF;      // ranges at least this long go to the work list, in slices of this size
 static_assert(SX_BLOCK == HOLE_BLOCK, "the first sort pass reads the scan's block structure");
+constexpr u32 SX_CNT_UNKNOWN = 0x7FFu;  // range length field of a depth / count word: the producer could not bound the range
 
 struct ExpandParams {
     const u64* keys;
     const u64* idctx;
+    const unsigned short* dcnt;  // per entry: depth | range length << 5 (SX_CNT_UNKNOWN: not counted), or null (the range ends are searched)
     size_t m;
     u64* out;          // block-structured: block g = slots [g * SX_BLOCK, (g + 1) * SX_BLOCK)
     u64 out_blocks;    // capacity in blocks
@@ -2358,6 +2319,7 @@ struct ExpandParams {
     // digit (pair >> hist_shift[q]) & 255
     u64* hist;
     int hist_passes;
+    u32 hist_rows;     // bit q: row q is counted (a consumer that reads one digit only says so: every row costs LDS atomics per pair)
     int hist_shift[SX_HIST_MAX];
     // multi-GPU: instead, count the pairs per OWNER of the first id (owner_n >= 0: bounds[i] = first id of rank
     // i + 1, as PairOwnerDigit) into row 0 of hist -- the bucketing pass that follows then needs no histogram read
@@ -2472,49 +2434,95 @@ template <int KIND> __device__ __forceinline__ u64 cell_upper(u64 key) {
 #ifndef SX_STATS_IN_VGPR
 #define SX_STATS_IN_VGPR 1
 #endif
-struct WaveStage {
+#ifndef SX_EXP
+#define SX_EXP 0  // timing experiments (results WRONG): 1 no pair stores, 2 no digit counts, 4 no stage writes, 8 no candidate steps
+#endif
+// Round 5: WHEN a block leaves.  vmcnt counts loads and stores alike and retires in order, so a wait for the next chunk's prefetched
+// words also waits for every store issued behind those loads -- and a block written in the middle of a chunk left the chunk's
+// back edge waiting for its stores' round trip (s_memtime stamps: 30 % of a wave's time at the back edge, more behind the
+// returning atomic of a reservation).  Now the scanning wave only APPENDS while it works on a chunk; the full blocks leave at the
+// top of the next chunk -- after the wait for that chunk's words, before the loads of the one after are issued -- so the stores
+// a wait can see are a whole chunk old.  The reservation's atomic goes out when the last reserved block is taken and is read at
+// the next drain.  (A chunk that would overflow the stage drains in the middle, with the old waits: rare by the stage's size.)
+// LDS_STATS: the two statistics (pairs written, candidates examined) live in two LDS words per wave (stat), not in registers --
+// the scanning kernel is short of both kinds
+template <bool LDS_STATS = false>
+struct WaveStageT {
     u64* buf;      // LDS, SX_STAGE slots
-    u32 wp;        // pairs staged and not yet written: < SX_BLOCK between pushes (wave-uniform)
+    u32 wp;        // pairs staged and not yet written (wave-uniform)
     u32 shard;
     u64 next_k;    // blocks reserved from the shard's cursor and not yet used: [next_k, next_k + k_left)
     u32 k_left;
     u32* hist;     // LDS, workgroup-wide: SX_HIST_MAX x 256 digit counters
     u64 examined;  // candidates this wave tested (wave-uniform)
     u64 total = 0; // pairs written so far
+    u32 pend = 0;  // lane 0: what the reservation in flight returns (k_pend)
+    u32 k_pend = 0;
+    u64* stat = nullptr;  // LDS_STATS: [0] pairs written, [1] candidates examined
+    __device__ __forceinline__ void add_total(u32 n) {
+        if (LDS_STATS) { if (lane_id() == 0) stat[0] += n; }
+        else { total += n; if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(total)); }
+    }
+    __device__ __forceinline__ void add_examined(u64 n) {
+        if (LDS_STATS) { if (lane_id() == 0) stat[1] += n; }
+        else { examined += n; if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(examined)); }
+    }
+    __device__ __forceinline__ void reserve(const ExpandParams& p) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
+        // (the address goes through a register the compiler cannot see through: with a provably uniform address LLVM's atomic
+        // optimizer rewrites the add into mbcnt + atomic + readfirstlane -- and the readfirstlane WAITS for the atomic right here.
+        // A shard's cursor counts blocks: the add is on its low dword -- below 2^32 blocks per shard, no carry -- and one register returns)
+        u32 z = 0;
+        asm volatile("" : "+v"(z));
+        u32 k = 0;
+        if (lane_id() == 0) k = atomicAdd(reinterpret_cast<u32*>(&p.shards[shard]) + z, (u32)SX_RESERVE);
+        pend = k;
+        k_pend = 1u;
+    }
     // OWNER (multi-GPU): the pairs per owner of the first id are counted here, once per block -- a ballot per owner and
     // quarter block, one LDS add per owner (an LDS atomic per pushed pair on <= 16 counters serialised the wave's lanes
     // on a few addresses: the shard scan took 0.83 ms instead of 0.43)
-    template <bool OWNER = false>
-    __device__ __forceinline__ void write_block(const ExpandParams& p, u32 fill) {
+    // from: the block's first slot in the stage.  AHEAD: the next reservation's atomic goes out when the last but one reserved block
+    // is taken, and is read two blocks later -- by then it has long returned
+    template <bool OWNER = false, bool AHEAD = false>
+    __device__ __forceinline__ void write_block(const ExpandParams& p, u32 fill, u32 from = 0u) {
         __builtin_amdgcn_wave_barrier();
-        if (k_left == 0) {  // one returning atomic (~2 us round trip) buys SX_RESERVE blocks
-            u64 k = 0;
-            if (lane_id() == 0) k = atomicAdd(&p.shards[shard], (u64)SX_RESERVE);
-            next_k = uniform_u64(k);
+        if (k_left == 0) {
+            if (!k_pend) reserve(p);
+            next_k = (u64)(u32)__builtin_amdgcn_readfirstlane((int)pend);
             k_left = SX_RESERVE;
+            k_pend = 0u;
         }
         const u64 g = next_k * SX_SHARDS + shard;
         ++next_k;
         --k_left;
         const bool fits = g < p.out_blocks;  // capacity is checked by the host afterwards (from the cursors)
+        const u64* const src = buf + from;
         u64 pr[SX_BLOCK / 64];
 #pragma unroll
-        for (u32 q = 0; q < SX_BLOCK / 64; ++q) pr[q] = buf[q * 64u + (u32)lane_id()];
+        for (u32 q = 0; q < SX_BLOCK / 64; ++q) pr[q] = src[q * 64u + (u32)lane_id()];
 #pragma unroll
         for (u32 q = 0; q < SX_BLOCK / 64; ++q)
-            if (q * 64u + (u32)lane_id() < fill && fits) p.out[g * SX_BLOCK + q * 64u + (u32)lane_id()] = pr[q];
+            if (!(SX_EXP & 1) && q * 64u + (u32)lane_id() < fill && fits) p.out[g * SX_BLOCK + q * 64u + (u32)lane_id()] = pr[q];
+        if (AHEAD && k_left == 1 && !k_pend) reserve(p);  // (a block ahead of its use)
         if (!OWNER) {
             // the digit counters for the sort that follows are fed here, 64 pairs per instruction (counted where a pair is
             // pushed, the same LDS adds ran on the ~45 % of the lanes whose candidate was kept, and cost twice the issue slots)
 #pragma unroll
             for (int h = 0; h < SX_HIST_MAX; ++h) {
-                if (h < p.hist_passes) {  // a counted digit never straddles the two dwords (scan_can_count)
-                    const bool hi = p.hist_shift[h] >= 32;
+                if (!(SX_EXP & 2) && h < p.hist_passes && ((p.hist_rows >> h) & 1u)) {  // a counted digit never straddles the two dwords (scan_can_count)
                     const u32 sh = (u32)p.hist_shift[h] & 31u;
+                    if (p.hist_shift[h] >= 32) {  // (a scalar branch: a select per pair otherwise)
 #pragma unroll
-                    for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
-                        const u32 dg = ((hi ? (u32)(pr[q] >> 32) : (u32)pr[q]) >> sh) & 255u;
-                        if (q * 64u + (u32)lane_id() < fill) __hip_atomic_fetch_add(&hist[h * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                            const u32 dg = ((u32)(pr[q] >> 32) >> sh) & 255u;
+                            if (q * 64u + (u32)lane_id() < fill) __hip_atomic_fetch_add(&hist[h * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else {
+#pragma unroll
+                        for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                            const u32 dg = ((u32)pr[q] >> sh) & 255u;
+                            if (q * 64u + (u32)lane_id() < fill) __hip_atomic_fetch_add(&hist[h * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
             }
@@ -2534,56 +2542,75 @@ struct WaveStage {
         if (fits && lane_id() == 0) p.blockfill[g] = fill;
         __builtin_amdgcn_wave_barrier();
     }
-    // a full block leaves; the (fewer than 128) pairs behind it move to the front
-    template <bool OWNER>
-    __device__ __forceinline__ void flush_full(const ExpandParams& p) {
-        write_block<OWNER>(p, SX_BLOCK);
-        const u32 over = wp - SX_BLOCK;  // wave-uniform
-        total += SX_BLOCK;
-        if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(total));
+    // every full block leaves; the (fewer than SX_BLOCK) pairs behind them move to the front
+    template <bool OWNER, bool AHEAD = false>
+    __device__ __forceinline__ void drain(const ExpandParams& p) {
+        u32 from = 0;
+        while (wp - from >= SX_BLOCK) {  // wave-uniform
+            write_block<OWNER, AHEAD>(p, SX_BLOCK, from);
+            from += SX_BLOCK;
+        }
+        if (from == 0) return;
+        add_total(from);
+        const u32 over = wp - from;  // < SX_BLOCK
         wp = over;
         if (over) {
             const u32 l = (u32)lane_id();
-            const u64 a = buf[SX_BLOCK + l], b = buf[SX_BLOCK + 64u + l];  // (source and destination never overlap)
+            u64 a[SX_BLOCK / 64];
+#pragma unroll
+            for (u32 q = 0; q < SX_BLOCK / 64; ++q) a[q] = buf[from + q * 64u + l];  // (source and destination never overlap: from >= SX_BLOCK)
             __builtin_amdgcn_wave_barrier();
-            if (l < over) buf[l] = a;
-            if (64u + l < over) buf[64u + l] = b;
+#pragma unroll
+            for (u32 q = 0; q < SX_BLOCK / 64; ++q)
+                if (q * 64u + l < over) buf[q * 64u + l] = a[q];
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // one candidate per lane, written out as soon as a block is full (the work-list kernel, the region queries)
     template <bool OWNER = false>
     __device__ __forceinline__ void push(bool keep, u64 pair, const ExpandParams& p) {
+        static_assert(SX_STAGE >= SX_BLOCK + 64, "stage too small for one candidate per lane");
         const u64 mask = ballot64(keep);
         const u32 n = (u32)__popcll(mask);
         if (n == 0) return;
         if (keep) buf[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, wp))] = pair;
         wp += n;
-        if (wp >= SX_BLOCK) flush_full<OWNER>(p);
+        if (wp >= SX_BLOCK) drain<OWNER>(p);
     }
-    // two candidates per lane (<= 128 pairs per call)
+    // two candidates per lane (<= 128 pairs per call), APPENDED: the caller drains at the top of its next chunk; only a stage
+    // without room for another call drains here.  m0 / m1: the votes on keep0 / keep1; a pair is (first id = the candidate's,
+    // second = its ancestor's), handed over as its two dwords: the stage's write position is folded into the (scalar) base, the
+    // slot is v_mbcnt alone
     template <bool OWNER = false>
-    __device__ __forceinline__ void push2(bool keep0, u64 pair0, bool keep1, u64 pair1, const ExpandParams& p) {
-        push2<OWNER>(ballot64(keep0), keep0, pair0, ballot64(keep1), keep1, pair1, p);
-    }
-    // m0 / m1: the votes on keep0 / keep1, for a caller that has them as lane masks already
-    template <bool OWNER = false>
-    __device__ __forceinline__ void push2(u64 m0, bool keep0, u64 pair0, u64 m1, bool keep1, u64 pair1, const ExpandParams& p) {
-        static_assert(SX_BLOCK >= 128 && SX_STAGE >= SX_BLOCK + 128, "stage too small for two candidates per lane");
+    __device__ __forceinline__ void push2(u64 m0, bool keep0, u32 lo0, u32 hi0, u64 m1, bool keep1, u32 lo1, u32 hi1, const ExpandParams& p) {
+        static_assert(SX_STAGE >= SX_BLOCK + 128 && SX_STAGE >= 256, "stage too small for two candidates per lane");
         const u32 n0 = (u32)__popcll(m0), n = n0 + (u32)__popcll(m1);
         if (n == 0) return;
-        if (keep0) buf[__builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, wp))] = pair0;
-        if (keep1) buf[__builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, wp + n0))] = pair1;
+        u32* const d0 = reinterpret_cast<u32*>(buf + wp);
+        u32* const d1 = reinterpret_cast<u32*>(buf + wp + n0);
+        if (!(SX_EXP & 4) && keep0) {
+            const u32 s = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u));
+            d0[2u * s] = lo0; d0[2u * s + 1u] = hi0;
+        }
+        if (!(SX_EXP & 4) && keep1) {
+            const u32 s = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
+            d1[2u * s] = lo1; d1[2u * s + 1u] = hi1;
+        }
         wp += n;
-        if (wp >= SX_BLOCK) flush_full<OWNER>(p);
+        if (wp > SX_STAGE - 128u) drain<OWNER, true>(p);
     }
     template <bool OWNER = false>
     __device__ __forceinline__ void finish(const ExpandParams& p) {
+        drain<OWNER>(p);
         if (wp) write_block<OWNER>(p, wp);
-        total += wp;
-        if (total && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], (u64)total);
-        if (examined && lane_id() == 0) atomicAdd(&p.shards[2 * SX_SHARDS + shard], examined);
+        add_total(wp);
+        __builtin_amdgcn_wave_barrier();
+        const u64 t = LDS_STATS ? uniform_u64(stat[0]) : total, x = LDS_STATS ? uniform_u64(stat[1]) : examined;
+        if (t && lane_id() == 0) atomicAdd(&p.shards[SX_SHARDS + shard], t);
+        if (x && lane_id() == 0) atomicAdd(&p.shards[2 * SX_SHARDS + shard], x);
     }
 };
+using WaveStage = WaveStageT<false>;
 
 __host__ __device__ __forceinline__ int sx_hist_rows(const ExpandParams& p) { return p.owner_n >= 0 ? 1 : p.hist_passes; }
 static size_t sx_hist_bytes(const ExpandParams& p) { return (size_t)sx_hist_rows(p) * 256 * sizeof(u32); }
@@ -2603,7 +2630,7 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 }
 
 #ifndef SX_WAVES_PER_EU
-#define SX_WAVES_PER_EU 7  // measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.390 (69 VGPRs, nothing spilled; round 3's 0.44 for 7 was with the stage cut by half a block)
+#define SX_WAVES_PER_EU 6  // (round 5: the 512-pair stage leaves LDS for six workgroups per CU) round 4 measured at 10 M objects: 5 per SIMD 0.414 ms, 6 0.400, 7 0.390 (69 VGPRs, nothing spilled; round 3's 0.44 for 7 was with the stage cut by half a block)
 #endif
 #if SX_WAVES_PER_EU
 // (the filtering variants need more registers than seven waves leave: they keep the range 5 .. 6.  OCC6: the same for the default
@@ -2615,17 +2642,20 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 #endif
 constexpr u32 SX_WIN = 128;  // entries of a chunk's LDS windows: the wave's 64 and the 64 that follow
 constexpr u32 SX_INLINE_MAX = 4u * SX_BIG;  // longest range a wave walks itself when no work-list kernel follows (ExpandParams::big_inline)
+static_assert(SX_WIN == SCAN_PAD_ENTRIES, "the padding the layer allocates behind the context / count words");
+constexpr u32 SX_REC = 66;   // owner records per wave: 64 owners, the null record behind them, 16 bytes of padding
 // GEN = 0: ids distinct, duplicates suppressed at the source (the default).
 // GEN = 1: ids may repeat, MARK pass: every candidate whose id equals its ancestor's gets CTX_SKIPPED (nothing is emitted).
 // GEN = 2: ids may repeat, EMIT pass: every combo of two unskipped entries (the reference's raw stream as a set).
+// PRECNT: the tree finish left every entry's depth and the LENGTH of its range in p.dcnt (round 5): no key is loaded, nothing is
+//         searched -- a chunk is two loads of {id, context} words and one of the 16-bit depth / count words.  Without it the range
+//         ends are bisected in an LDS window of the chunk's keys (rounds 1 - 4; still what the other tree finishes' output takes).
 //
-// The kernel is bound by the latency chains of a chunk, not by issue slots or bytes (profiles/r01: VALU ~1/3 busy at 6
-// waves per SIMD, 18 k cycles per 64-entry chunk), so everything a chunk waits for is either fetched one chunk ahead or
-// served from LDS: (1) the chunk's four global loads -- 128 keys and 128 {id, context} words -- are issued a whole
-// chunk before they are used (register prefetch across the persistent loop); (2) both 128-entry windows go to LDS:
-// the range ends are bisected in the key window, and a candidate's {id, context} word comes from the word window
-// (nearly every range ends within the 64 entries after its owner) -- only a candidate beyond the window is a global load.
-template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false>
+// Everything a chunk waits for is either fetched one chunk ahead or served from LDS: (1) the chunk's global loads are issued a whole
+// chunk before they are used (register prefetch across the persistent loop); (2) a candidate's {id, context} word comes from a
+// 128-entry LDS window (nearly every range ends within the 64 entries after its owner) -- only a candidate beyond the window is a
+// global load, and only chunks that have such a range run the loop that looks for them.
+template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false, bool PRECNT = false>
 __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(ExpandParams p) {
     constexpr int FDIM = (int)KT<KIND>::DIM;
 #ifndef SX_SUPER_WORDS
@@ -2633,14 +2663,17 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
 #endif
     constexpr u32 SUPER = 64 * SX_SUPER_WORDS;  // candidates covered by one fill of the boundary masks
     __shared__ u64 s_ends[SX_WAVES][SX_SUPER_WORDS];   // bit q of word b: some owner's range ends before candidate 64 b + q
-    // owners with a non-empty range, compacted: {first candidate, id, DJ, CBJ | lane << 24}; the same storage holds
-    // the wave's key window while the range ends are searched (a union, so the compiler knows the two views alias)
-    union RecWin { uint4 rec[64]; u64 win[SX_WIN]; };
+    // owners with a non-empty range, compacted: {lane + 1 - first candidate (a candidate's entry offset is k + x), id, DJ, -}, and behind
+    // them ONE null record {-total, -, CTX_DJ_NONE, -}: the lanes beyond a chunk's last candidate find it by the same count of ended
+    // ranges as any other lane, land inside the window and fail the test -- no lane of a step needs an "is there a candidate" mask.
+    // Without PRECNT the same storage holds the wave's key window while the range ends are searched (a union, so the compiler knows
+    // the two views alias)
+    union RecWin { uint4 rec[SX_REC]; u64 win[SX_WIN]; };
     __shared__ RecWin s_recwin[SX_WAVES];
     __shared__ u64 s_cwin[SX_WAVES][SX_WIN];  // {id, context} words of the entries [base, base + SX_WIN)
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     // the digit counters: as many rows as this launch counts (dynamic LDS, sx_hist_bytes) -- with the two rows of the usual
-    // pair sort a workgroup needs 22.5 KB and six of them share a CU
+    // pair sort a workgroup needs 22.6 KB and seven of them share a CU
     extern __shared__ u32 s_hist[];
     sx_hist_clear(s_hist, p);
     // the wave's index and everything derived from it (chunk base, loop bounds, the stage's counters) are wave-uniform: said
@@ -2651,13 +2684,27 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     u64* const cwin = s_cwin[w];
     const u32 m = (u32)p.m;
     const u32 gw = blockIdx.x * SX_WAVES + (u32)w;  // persistent wave: chunks gw, gw + n_waves, ...
-    WaveStage st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
+    __shared__ u64 s_stat[SX_WAVES][2];
+    WaveStageT<true> st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
+    st.stat = s_stat[w];
+    if (lane < 2) s_stat[w][lane] = 0ull;
     // a chunk's global loads (clamped addresses: every load is unconditional, validity is decided at use)
-    struct Pre { u64 k0, k1, w0, w1; };
+    struct Pre { u64 k0, k1, w0, w1; u32 dc; };
     // (m < 2^32 - 1, checked by the host: the chunk loop's state is 32-bit -- scalar registers are what this kernel runs out of)
     auto prefetch = [&](u32 base) -> Pre {
-        Pre r;
-        if (m - base >= SX_WIN) {  // wave-uniform: every chunk but the last one or two -- no clamping, scalar base + lane offset
+        Pre r{};
+        if constexpr (PRECNT) {
+            // ONE shape of loads, whatever the chunk: both arrays are readable SX_WIN entries beyond the tree (the layer allocates them
+            // so), and what lies there is replaced at use.  An unsigned 32-bit lane index on a uniform base: the loads take their base
+            // from scalar registers -- no clamped indices, no 64-bit address pairs held in VGPRs
+            // (the lane index goes through an opaque register: hoisted out of the loop, "array + lane" becomes a 64-bit address pair per
+            // array that lives in VGPRs for the whole kernel -- and one of them was spilled to scratch, with its reload's wait in here)
+            u32 ul = (u32)lane;
+            asm volatile("" : "+v"(ul));
+            const u64* __restrict__ c = p.idctx + base;
+            r.w0 = c[ul]; r.w1 = c[64u + ul];
+            r.dc = (p.dcnt + base)[ul];
+        } else if (m - base >= SX_WIN) {  // wave-uniform: every chunk but the last one or two -- no clamping, scalar base + lane offset
             const u64* __restrict__ k = p.keys + base;
             const u64* __restrict__ c = p.idctx + base;
             r.k0 = k[lane]; r.k1 = k[64 + lane]; r.w0 = c[lane]; r.w1 = c[64 + lane];
@@ -2683,54 +2730,86 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         SX_T(t0);
         const Pre pre = cur_pre;
         more = m - base > chunk_step;  // (base < m)
+        if (GEN != 1) {
+            // the blocks the LAST chunk filled leave here: behind the wait for this chunk's words, before the next chunk's loads are
+            // issued (the compiler must not move either across: the loads are of read-only data and would otherwise be free to go up)
+            if constexpr (PRECNT) {
+                u32 a0 = (u32)pre.w0, a1 = (u32)pre.w1, a2 = pre.dc;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2) : : "memory");
+            } else {
+                u32 a0 = (u32)pre.w0, a1 = (u32)pre.w1, a3 = (u32)pre.k0, a4 = (u32)pre.k1;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a3), "+v"(a4) : : "memory");
+            }
+            st.template drain<OWNER, true>(p);
+            asm volatile("" ::: "memory");
+        }
         if (more) cur_pre = prefetch(base + chunk_step);  // the NEXT chunk's loads fly while this chunk is processed
         const u32 j = base + (u32)lane;
-        const bool in0 = j < m, in1 = in0 && m - j > 64u;
-        const u64 key = in0 ? pre.k0 : ~0ull;
-        win[lane] = key;
-        win[64 + lane] = in1 ? pre.k1 : ~0ull;
-        cwin[lane] = pre.w0;
-        cwin[64 + lane] = pre.w1;
-        __builtin_amdgcn_wave_barrier();
+        const bool in0 = j < m;
+        if (PRECNT && m - base < SX_WIN) {  // (wave-uniform, the tree's last chunks) what was loaded from behind the tree: an inert word
+            cwin[lane] = in0 ? pre.w0 : (u64)CTX_SKIPPED;
+            cwin[64 + lane] = (in0 && m - j > 64u) ? pre.w1 : (u64)CTX_SKIPPED;
+        } else {
+            cwin[lane] = pre.w0;
+            cwin[64 + lane] = pre.w1;
+        }
+        u32 c = 0, dd = 0;
+        u32 end = 0;
         SX_T(t1);
         SX_ACC(0, t1 - t0);
         SX_ACC(5, 1);
-        u32 c = 0, idj = 0, dj = 0, cbj = 0;
-        u32 end = 0;  // in the window: base + its slot there; SX_WIN + base: not in the window
-        if (in0) {
-            const u64 wj = pre.w0;
-            idj = (u32)(wj >> 32);
-            dj = ctx_owner_dj(key_depth<KIND>(key));
-            cbj = ctx_owner_cbj((u32)wj);
-            const u64 upper = cell_upper<KIND>(key);
-            u32 lo = (u32)lane, hi = SX_WIN;  // win[lo] < upper <= win[hi] (hi == SX_WIN: not in the window)
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const u32 mid = (lo + hi) >> 1;  // <= 127: the read is unconditional (no branch per step)
-                const u64 v = win[mid];
-                const bool ge = (mid > lo) & (v >= upper);
-                hi = ge ? mid : hi;
-                lo = ge ? lo : mid;  // mid == lo leaves lo unchanged as well
+        if constexpr (PRECNT) {
+            dd = pre.dc & 31u;
+            const u32 cc = pre.dc >> 5;
+            // (<= m when the finish ran; clamped all the same: a tree sort whose deferred check fails leaves unwritten words behind, and the
+            // scan that read them must stay inside the arrays -- its output is void, the host repairs the tree and scans again)
+            end = min(j + 1u + cc, m);
+            // a range the finish could not bound (an entry coarser than its group: never on the compact route): searched in HBM
+            if (ballot64(in0 && cc == SX_CNT_UNKNOWN) != 0ull) {
+                if (in0 && cc == SX_CNT_UNKNOWN) {
+                    const u64 key = p.keys[j];
+                    end = range_end(p.keys, m, j, cell_upper<KIND>(key));
+                }
             }
-            end = (u32)base + hi;
-        }
-        // Ranges that leave the window (rare on a uniform scene, one in most chunks of a mixed-scale one): their end is somewhere
-        // in HBM.  Up to four are searched by the whole wave, one after the other (~5 memory round trips each; the owner's key is
-        // still in the key window); more: every lane for itself (~40 dependent loads each, but all lanes at once).
-        if (m - base <= SX_WIN) {  // (wave-uniform) the window reaches the end of the tree
-            if (in0 && end == (u32)base + SX_WIN) end = m;
         } else {
-            u64 fm = ballot64(in0 && end == (u32)base + SX_WIN);
-            if (fm != 0) {
-                if (__popcll(fm) <= 4) {
-                    while (fm) {
-                        const int l = __builtin_ctzll(fm);
-                        fm &= fm - 1;
-                        const u32 e = range_end_wave(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(win[l]));
-                        if (lane == l) end = e;
+            const bool in1 = in0 && m - j > 64u;
+            const u64 key = in0 ? pre.k0 : ~0ull;
+            win[lane] = key;
+            win[64 + lane] = in1 ? pre.k1 : ~0ull;
+            __builtin_amdgcn_wave_barrier();
+            // in the window: base + its slot there; SX_WIN + base: not in the window
+            if (in0) {
+                dd = key_depth<KIND>(key);
+                const u64 upper = cell_upper<KIND>(key);
+                u32 lo = (u32)lane, hi = SX_WIN;  // win[lo] < upper <= win[hi] (hi == SX_WIN: not in the window)
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {
+                    const u32 mid = (lo + hi) >> 1;  // <= 127: the read is unconditional (no branch per step)
+                    const u64 v = win[mid];
+                    const bool ge = (mid > lo) & (v >= upper);
+                    hi = ge ? mid : hi;
+                    lo = ge ? lo : mid;  // mid == lo leaves lo unchanged as well
+                }
+                end = (u32)base + hi;
+            }
+            // Ranges that leave the window (rare on a uniform scene, one in most chunks of a mixed-scale one): their end is somewhere
+            // in HBM.  Up to four are searched by the whole wave, one after the other (~5 memory round trips each; the owner's key is
+            // still in the key window); more: every lane for itself (~40 dependent loads each, but all lanes at once).
+            if (m - base <= SX_WIN) {  // (wave-uniform) the window reaches the end of the tree
+                if (in0 && end == (u32)base + SX_WIN) end = m;
+            } else {
+                u64 fm = ballot64(in0 && end == (u32)base + SX_WIN);
+                if (fm != 0) {
+                    if (__popcll(fm) <= 4) {
+                        while (fm) {
+                            const int l = __builtin_ctzll(fm);
+                            fm &= fm - 1;
+                            const u32 e = range_end_wave(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(win[l]));
+                            if (lane == l) end = e;
+                        }
+                    } else if (in0 && end == (u32)base + SX_WIN) {
+                        end = range_end(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(key));
                     }
-                } else if (in0 && end == (u32)base + SX_WIN) {
-                    end = range_end(p.keys, m, (u32)base + SX_WIN - 1u, cell_upper<KIND>(key));
                 }
             }
         }
@@ -2764,16 +2843,20 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
         if (nz == 0) continue;  // wave-uniform
         const u32 incl = wave_incl_scan_u32(c);
         const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        // The candidates of the 64 ranges, concatenated, are dealt to the lanes 64 per step.  Which
-        // owner a candidate belongs to = how many ranges end at or before it: every owner sets ONE
-        // bit (at its range end) in a row of 64-bit masks, and a step needs one mask word, one
-        // popcount and one 16-byte LDS read per lane -- no per-candidate search.
-        st.examined += total;
-        if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(st.examined));  // (a statistic: not worth two of the scalar registers this kernel spills)
-        // record: {first candidate - lane - 1 (so that a candidate's entry offset is k - x), id, DJ, CBJ}
-        if (c > 0)
-            s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
-                make_uint4(incl - c - (u32)lane - 1u, idj, dj, cbj);
+        // The candidates of the 64 ranges, concatenated, are dealt to the lanes 128 per step.  Which
+        // owner a candidate belongs to = how many ranges end before it: every owner sets ONE
+        // bit (at its range end) in a row of 64-bit masks, and a step needs its two mask words, two
+        // v_mbcnt pairs and one 16-byte LDS read per candidate -- no per-candidate search.
+        st.add_examined(total);  // (a statistic: in LDS -- not worth two registers of either kind in this kernel)
+        // a range leaves the word window: its last candidate is entry base + lane + c (wave-uniform: which stepping loop runs)
+        const bool any_far = ballot64(c > 0 && (u32)lane + c >= SX_WIN) != 0ull;
+        {
+            const u32 n_own = (u32)__popcll(nz);
+            if (c > 0)
+                s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
+                    make_uint4((u32)lane + 1u + c - incl, (u32)(pre.w0 >> 32), ctx_owner_dj(dd, (u32)pre.w0), 0u);
+            if (lane == 0) s_rec_w[n_own] = make_uint4(0u - total, 0u, CTX_DJ_NONE, 0u);
+        }
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         SX_T(t3);
         SX_ACC(2, t3 - t2);
@@ -2789,81 +2872,87 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             const u32 ends_lo = (u32)my_ends, ends_hi = (u32)(my_ends >> 32);
             const u32 left = total - ss;
             const u32 n_steps = left >= SUPER ? SUPER / 128u : (left + 127u) >> 7;
+            u32 kl = ss + (u32)lane;  // slot 0's candidate of the current step (slot 1: + 64)
             // One step = 128 candidates, two per lane (slot 0: candidate 128 b + lane, slot 1: + 64): the two lookup chains
             // (owner record -> {id, context} word -> test) are independent, so their LDS latencies overlap, and the
             // per-step bookkeeping is paid once per 128 candidates.
-            for (u32 b = 0; b < n_steps; ++b) {
-                const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
-                               (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
-                const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
-                               (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b + 1u));
-                const u32 k0 = ss + b * 128u + (u32)lane, k1 = k0 + 64u;
-                const bool act0 = k0 < total, act1 = k1 < total;
-                // owner of a candidate = how many ranges ended strictly before it: the bits below the lane, counted by
-                // v_mbcnt on top of the running total (no AND / popcount per lane).  A lane beyond the last candidate
-                // reads a record past the owners' (harmless LDS garbage): everything it derives is masked by act.
-                const u32 done0 = owners_done + (u32)__popcll(e0);
-                const u32 ord0 = __builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, owners_done));
-                const u32 ord1 = __builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, done0));
-                owners_done = done0 + (u32)__popcll(e1);
-                const uint4 r0 = s_rec_w[ord0], r1 = s_rec_w[ord1];   // ord <= 64: at worst the 16 bytes after the records (still this workgroup's LDS)
-                const u32 off0 = k0 - r0.x, off1 = k1 - r1.x;   // candidate = entry base + off
-                // the common case must stay a ds_read: left to itself the compiler merges the LDS and the global load
-                // into ONE flat load of a selected address, whose wait (vmcnt(0)) also waits for the next chunk's prefetch
-                u32 w0lo, w0hi, w1lo, w1hi;
-                {
-                    const u64 t0 = cwin[off0 < SX_WIN ? off0 : SX_WIN - 1u], t1 = cwin[off1 < SX_WIN ? off1 : SX_WIN - 1u];
-                    w0lo = (u32)t0; w0hi = (u32)(t0 >> 32); w1lo = (u32)t1; w1hi = (u32)(t1 >> 32);
-                    asm volatile("" : "+v"(w0lo), "+v"(w0hi), "+v"(w1lo), "+v"(w1hi));
-                }
-                const bool far0 = act0 && off0 >= SX_WIN, far1 = act1 && off1 >= SX_WIN;
-                if (__any(far0 || far1)) {  // a range that leaves the window (rare): those lanes read HBM
-                    if (far0) {
-                        const u64 t = p.idctx[base + off0];
-                        w0lo = (u32)t; w0hi = (u32)(t >> 32);
-                        asm volatile("" : "+v"(w0lo), "+v"(w0hi));  // consumed HERE: else its wait lands at the join, on every path
+            auto run_steps = [&](auto far_tag) {
+                constexpr bool FAR = decltype(far_tag)::value;
+                for (u32 b = 0; b < n_steps; ++b) {
+                    const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
+                                   (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
+                    const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
+                                   (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b + 1u));
+                    // owner of a candidate = how many ranges ended strictly before it: the bits below the lane (v_mbcnt) on top of
+                    // the running total, which is folded into the (scalar) record pointer
+                    const uint4* const rb0 = s_rec_w + owners_done;
+                    const u32 n0 = (u32)__popcll(e0);
+                    const uint4* const rb1 = rb0 + n0;
+                    owners_done += n0 + (u32)__popcll(e1);
+                    const uint4 r0 = rb0[__builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u))];
+                    const uint4 r1 = rb1[__builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u))];
+                    asm volatile("" : : "v"(r0.w), "v"(r1.w));  // (all four dwords: ds_read_b128 takes 4 LDS cycles, the ds_read_b96 of three takes 8)
+                    const u32 off0 = kl + r0.x, off1 = kl + 64u + r1.x;   // candidate = entry base + off
+                    const bool act0 = GEN == 1 && kl < total, act1 = GEN == 1 && kl + 64u < total;  // (only the marking pass asks)
+                    kl += 128u;
+                    u32 w0lo, w0hi, w1lo, w1hi;
+                    if constexpr (FAR) {
+                        // the common case must stay a ds_read: left to itself the compiler merges the LDS and the global load
+                        // into ONE flat load of a selected address, whose wait (vmcnt(0)) also waits for the next chunk's prefetch
+                        {
+                            const u64 t0 = cwin[off0 < SX_WIN ? off0 : SX_WIN - 1u], t1 = cwin[off1 < SX_WIN ? off1 : SX_WIN - 1u];
+                            w0lo = (u32)t0; w0hi = (u32)(t0 >> 32); w1lo = (u32)t1; w1hi = (u32)(t1 >> 32);
+                            asm volatile("" : "+v"(w0lo), "+v"(w0hi), "+v"(w1lo), "+v"(w1hi));
+                        }
+                        const bool far0 = off0 >= SX_WIN, far1 = off1 >= SX_WIN;  // (a lane behind the last candidate is inside the window)
+                        if (__any(far0 || far1)) {  // those lanes read HBM
+                            if (far0) {
+                                const u64 t = p.idctx[base + off0];
+                                w0lo = (u32)t; w0hi = (u32)(t >> 32);
+                                asm volatile("" : "+v"(w0lo), "+v"(w0hi));  // consumed HERE: else its wait lands at the join, on every path
+                            }
+                            if (far1) {
+                                const u64 t = p.idctx[base + off1];
+                                w1lo = (u32)t; w1hi = (u32)(t >> 32);
+                                asm volatile("" : "+v"(w1lo), "+v"(w1hi));
+                            }
+                        }
+                    } else {
+                        const u64 t0 = cwin[off0], t1 = cwin[off1];
+                        w0lo = (u32)t0; w0hi = (u32)(t0 >> 32); w1lo = (u32)t1; w1hi = (u32)(t1 >> 32);
                     }
-                    if (far1) {
-                        const u64 t = p.idctx[base + off1];
-                        w1lo = (u32)t; w1hi = (u32)(t >> 32);
-                        asm volatile("" : "+v"(w1lo), "+v"(w1hi));
+                    if (GEN == 1) {  // mark: a candidate whose id equals its ancestor's is dropped by the skip rule
+                        if (act0 && w0hi == r0.y && !(w0lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off0, (u64)CTX_SKIPPED);
+                        if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
+                        continue;
                     }
-                }
-                if (GEN == 1) {  // mark: a candidate whose id equals its ancestor's is dropped by the skip rule
-                    if (act0 && w0hi == r0.y && !(w0lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off0, (u64)CTX_SKIPPED);
-                    if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
-                    continue;
-                }
-                // no short circuit: the test runs on every lane (a lane beyond the last candidate tests garbage) and the
-                // ballots come straight out of the compares
-                const bool c0 = ctx_keep(w0lo, r0.z, r0.w), c1 = ctx_keep(w1lo, r1.z, r1.w);
-                bool keep0 = act0 & c0, keep1 = act1 & c1;
-                if (GEN == 0 && !FILT) {
-                    // the vote on (a & b) costs two VALU instructions, the AND of two votes on compares none
-                    // (the lanes with a candidate are the low `rem` ones: their mask is scalar arithmetic)
-                    const u32 rem = total - ss - b * 128u;  // >= 1
-                    const u64 am0 = rem >= 64u ? ~0ull : (1ull << rem) - 1ull;
-                    const u64 am1 = rem >= 128u ? ~0ull : rem > 64u ? (1ull << (rem - 64u)) - 1ull : 0ull;
-                    st.template push2<OWNER>(am0 & ballot64(c0), keep0, ((u64)w0hi << 32) | (u64)r0.y, am1 & ballot64(c1), keep1,
-                                             ((u64)w1hi << 32) | (u64)r1.y, p);
+                    // no short circuit: the test runs on every lane and the ballots come straight out of the compares
+                    const bool c0 = ctx_keep(w0lo, r0.z), c1 = ctx_keep(w1lo, r1.z);
+                    if (GEN == 0 && !FILT) {
+                        st.template push2<OWNER>(ballot64(c0), c0, r0.y, w0hi, ballot64(c1), c1, r1.y, w1hi, p);
+                        SX_ACC(6, 1);
+                        continue;
+                    }
+                    bool keep0 = c0, keep1 = c1;
+                    if (GEN == 2) {  // (implied by the test: a skipped entry's context never passes; kept explicit)
+                        keep0 = keep0 && !(w0lo & CTX_SKIPPED);
+                        keep1 = keep1 && !(w1lo & CTX_SKIPPED);
+                    }
+                    if (FILT) {
+                        const u32 fs = filt_stride<FDIM>(p.filt_shape);
+                        if (keep0) keep0 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w0hi * fs, p.filt_bounds + (size_t)r0.y * fs, p.filt_shape);
+                        if (keep1) keep1 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w1hi * fs, p.filt_bounds + (size_t)r1.y * fs, p.filt_shape);
+                    }
+                    SX_T(tp0);
+                    st.template push2<OWNER>(ballot64(keep0), keep0, r0.y, w0hi, ballot64(keep1), keep1, r1.y, w1hi, p);
+                    SX_T(tp1);
+                    SX_ACC(4, tp1 - tp0);
                     SX_ACC(6, 1);
-                    continue;
                 }
-                if (GEN == 2) {
-                    keep0 = keep0 && !(w0lo & CTX_SKIPPED);
-                    keep1 = keep1 && !(w1lo & CTX_SKIPPED);
-                }
-                if (FILT) {
-                    const u32 fs = filt_stride<FDIM>(p.filt_shape);
-                    if (keep0) keep0 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w0hi * fs, p.filt_bounds + (size_t)r0.y * fs, p.filt_shape);
-                    if (keep1) keep1 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w1hi * fs, p.filt_bounds + (size_t)r1.y * fs, p.filt_shape);
-                }
-                SX_T(tp0);
-                st.template push2<OWNER>(keep0, ((u64)w0hi << 32) | (u64)r0.y, keep1, ((u64)w1hi << 32) | (u64)r1.y, p);
-                SX_T(tp1);
-                SX_ACC(4, tp1 - tp0);
-                SX_ACC(6, 1);
-            }
+            };
+            if (SX_EXP & 8) continue;
+            if (any_far) run_steps(std::true_type{});
+            else run_steps(std::false_type{});
         }
         __builtin_amdgcn_wave_barrier();
         SX_T(t4);
@@ -2909,7 +2998,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
         const u32 end = min((u32)p.big_list[2 * (size_t)it + 1], m);  // (found by the wave that listed the range)
         const u64 key = p.keys[j];
         const u64 wj = p.idctx[j];
-        const u32 idj = (u32)(wj >> 32), dj = ctx_owner_dj(key_depth<KIND>(key)), cbj = ctx_owner_cbj((u32)wj);
+        const u32 idj = (u32)(wj >> 32), dj = ctx_owner_dj(key_depth<KIND>(key), (u32)wj);
         const u64 first = (u64)j + 1u + (u64)slice * SX_BIG;
         const u64 last = min(first + SX_BIG, (u64)end);
         if (w == 0 && last > first) st.examined += last - first;
@@ -2923,7 +3012,7 @@ __global__ __launch_bounds__(SX_THREADS) void scan_expand_big_kernel(ExpandParam
                     if ((u32)(wi >> 32) == idj && !((u32)wi & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + i, (u64)CTX_SKIPPED);
                     continue;
                 }
-                keep = ctx_keep((u32)wi, dj, cbj);
+                keep = ctx_keep((u32)wi, dj);
                 if (GEN == 2) keep = keep && !((u32)wi & CTX_SKIPPED);
                 if (FILT && keep)
                     keep = narrow_keep<FDIM>(p.filt_bounds + (size_t)(u32)(wi >> 32) * filt_stride<FDIM>(p.filt_shape),
@@ -3547,7 +3636,7 @@ __constant__ CompactLut3<2> g_compact_lut3_2d = make_compact_lut3<2>();
 // NSTEP: table reads the tail takes (1: T <= 3, 2: T <= 6 -- compile-time, so that the per-entry code has no branches on the
 // format), 0: any T, by table when lut3 is given, else digit by digit
 template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u64 comp, const TreeCompact& f, u64& key, u32& id, u32& c27,
-                                                                               const unsigned short* lut3 = nullptr) {
+                                                                               const unsigned short* lut3 = nullptr, u32* nlev_out = nullptr) {
     constexpr u32 DIM = KT<KIND>::DIM, BASE = (1u << DIM) + 1u, N3 = BASE * BASE * BASE;
     const u64 kp = comp >> f.low;
     u32 t = (u32)kp & (u32)((1ull << f.tbits) - 1ull);  // (tbits <= 32: tree_compact_format keeps the tail a 32-bit number)
@@ -3577,6 +3666,7 @@ template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u
         }
     }
     const u32 depth = f.dmin + nlev;
+    if (nlev_out) *nlev_out = nlev;
     key = ((kp >> f.tbits) << f.pshift) | (mort << (f.pshift - (int)DIM * f.T)) | (u64)depth;
     id = ((u32)(comp >> 5) & ((1u << f.idbits) - 1u)) + f.id_base;
     c27 = (u32)comp & 31u;
@@ -3597,34 +3687,42 @@ __global__ __launch_bounds__(256) void tree_expand_kernel(u64* __restrict__ word
 // TG2_BIN_BITS as well: the plain unsigned order of the words is the (index, id) order), expansion to index value / id / box byte /
 // context word while writing out.
 #ifndef TGC_WAVES_PER_EU
-#define TGC_WAVES_PER_EU 8
+#define TGC_WAVES_PER_EU 7
 #endif
-constexpr int TGC_CAP = 2044;  // (words per group: with the offsets' 4112 bytes just under the 20480 bytes an eighth of a CU's LDS is)
-static_assert(TGC_CAP <= TGRP_CAP && (size_t)TGC_CAP * 8 + (TG2_BINS + 4) * 4 <= 20480, "tgroup_finishc: eight workgroups per CU");
+constexpr int TGC_CAP = 2044;  // (words per group)
+// LDS: the words (+ two words of padding: the straight-line reads of a bin's first three), the bins' offsets -- alive to the end since round 5:
+// the range lengths are ranks of cell bounds, found through the bins -- and the write-out's tables: 22.1 KB, seven workgroups per CU
+// (round 4 measured seven against eight: 0.228 / 0.230 ms)
+static_assert(TGC_CAP <= TGRP_CAP, "tgroup_finishc: group capacity");
 // WRITE_IDS = false: ids_out / box_out are not written -- the caller derives them from the context words when something asks
 // (launch_ids_from_ctx): two of the write-out's four stores and five of its 21 bytes per entry
+// dcnt_out (round 5): per entry, depth | range length << 5 -- how many entries behind it lie in its cell, i.e. the candidates the scan
+// pairs it with as the ancestor (src/layer.rs:550-573: the entries that find it on the stack).  In composite space an entry of depth
+// dmin + k covers the words [kp, kp + BASE^(T - k)) << low; every entry of the tree is at least as deep as its group's cell (the group
+// shift lies inside the prefix), so the range ends inside the group and its end is the RANK of that bound in the group: the bins'
+// offsets give the bin's start, and the words of one bin (about one) are compared directly -- no search, and the scan loads no key
 template <int CTX_KIND, int NSTEP, bool WRITE_IDS = true>
 __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TGC_WAVES_PER_EU, TGC_WAVES_PER_EU))) void tgroup_finishc_kernel(const u64* __restrict__ words_in, int gshift, TreeCompact fmt,
                                                                       u64* __restrict__ keys_out, u32* __restrict__ ids_out,
                                                                       uint8_t* __restrict__ box_out, u64* __restrict__ idctx_out,
+                                                                      unsigned short* __restrict__ dcnt_out,
                                                                       DevScalars* sc, const u32* __restrict__ stats, u32 abort_over,
                                                                       const uint4* __restrict__ cell_src) {
     static_assert(CTX_KIND >= 0 && CTX_KIND <= 2, "the compact route always writes the context words (CTX_KIND = the index kind)");
     constexpr int XK = CTX_KIND;
-    // LDS is what sets this kernel's occupancy, and occupancy its speed (six workgroups per CU: 0.269 ms, seven: 0.228 at 10 M
-    // objects): every array lives in one of two regions.  s_comp: the bins' arrival counters, then the words grouped by bin, then
-    // the words in final order (the counters' last read is the prefix scan's, two barriers before the first word is placed).
-    // s_off: the bins' offsets (+ the block scan's scratch behind them) while ranking, then -- the offsets are dead once every
-    // rank is known -- the two lookup tables of the write-out.  TGC_CAP words + 4112 bytes = 20464: eight workgroups per CU.
+    // s_comp: the bins' arrival counters, then the words grouped by bin, then the words in final order (the counters' last read is
+    // the prefix scan's, two barriers before the first word is placed).  s_off: the bins' offsets (+ the block scan's scratch behind them)
     constexpr int XDIM = (int)KT<XK>::DIM;
-    __shared__ __attribute__((aligned(16))) u64 s_comp[TGC_CAP];
+    constexpr u32 XBASE = (1u << XDIM) + 1u;
+    __shared__ __attribute__((aligned(16))) u64 s_comp[TGC_CAP + 2];
     u32* const s_cnt = reinterpret_cast<u32*>(s_comp);
     __shared__ __attribute__((aligned(16))) u32 s_off[TG2_BINS + 4];
     u32* const s_ws = s_off + TG2_BINS;   // (four words: the block scan's scratch, then s_off[TG2_BINS] = the group's size)
-    u32* const s_lut = s_off;             // after the ranking
-    unsigned short* const s_lut3 = reinterpret_cast<unsigned short*>(s_off + CTX_LUT_WORDS);
-    static_assert((CTX_LUT_WORDS + CompactLut3<XDIM>::WORDS) <= TG2_BINS, "the write-out's tables fit the offsets' storage");
+    __shared__ u32 s_lut[CTX_LUT_WORDS];
+    __shared__ u32 s_pw[16];              // XBASE^k: the composite span of a cell k levels above the deepest
+    __shared__ __attribute__((aligned(4))) unsigned short s_lut3[CompactLut3<XDIM>::WORDS * 2];
     static_assert((size_t)TGC_CAP * 8 >= (size_t)TG2_BINS * 4, "the counters fit the words' storage");
+    static_assert((size_t)(TGC_CAP + 2) * 8 + (TG2_BINS + 4) * 4 + CTX_LUT_WORDS * 4 + 64 + CompactLut3<XDIM>::WORDS * 4 <= 163840 / 7, "tgroup_finishc: seven workgroups per CU");
     const u32 g = blockIdx.x, tid = threadIdx.x;
     if (stats && stats[1] > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
@@ -3639,6 +3737,17 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
     }
     const int bshift = gshift - TG2_BIN_BITS;  // the host guarantees bshift >= 0
     reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    // the write-out's tables (their own storage; visible after the barriers below)
+    if (tid < (u32)CTX_LUT_WORDS) s_lut[tid] = g_ctx_lut.e[tid];
+    if (tid < 16u) {
+        u32 pw = 1u;
+        for (u32 k = 0; k < tid; ++k) pw *= XBASE;  // (wraps beyond what a 32-bit tail holds: never indexed there)
+        s_pw[tid] = pw;
+    }
+    {
+        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
+        for (u32 q = tid; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
+    }
     u64 c[TGRP_ITEMS];
 #pragma unroll
     for (int i = 0; i < TGRP_ITEMS; ++i) {
@@ -3690,27 +3799,36 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
             slot[i] = start + rank;
         }
     }
-    __syncthreads();  // every rank is known: the buffer now takes the group in final order, the offsets' storage the tables
+    __syncthreads();  // every rank is known: the buffer now takes the group in final order
 #pragma unroll
     for (int i = 0; i < TGRP_ITEMS; ++i) {
         const u32 x = (u32)i * TGRP_THREADS + tid;
         if (x < ng) s_comp[slot[i]] = c[i];
     }
-    for (int q = (int)tid; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];
-    {
-        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
-        for (u32 q = tid; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
-    }
     __syncthreads();
     for (u32 y = tid; y < ng; y += TGRP_THREADS) {
-        u64 ky; u32 id, c27;
-        tree_expand<XK, NSTEP>(s_comp[y], fmt, ky, id, c27, s_lut3);
+        u64 ky; u32 id, c27, nlev;
+        const u64 wy = s_comp[y];
+        tree_expand<XK, NSTEP>(wy, fmt, ky, id, c27, s_lut3, &nlev);
         keys_out[(size_t)lo + y] = ky;
         if constexpr (WRITE_IDS) {
             ids_out[(size_t)lo + y] = id;
             box_out[(size_t)lo + y] = (uint8_t)box_from_packed(c27);
         }
         idctx_out[(size_t)lo + y] = ((u64)id << 32) | (u64)entry_ctx_lut<CTX_KIND>(ky, c27, 0u, s_lut);
+        // the range's end = the rank of the cell's upper bound among the group's words (all of them sorted by now)
+        const u64 ub = ((wy >> fmt.low) + (u64)s_pw[(u32)fmt.T - nlev]) << fmt.low;
+        const u32 b = (u32)(ub >> bshift) & (TG2_BINS - 1u);
+        const u32 start = s_off[b], len = s_off[b + 1] - start;
+        const u64* const q = s_comp + start;
+        const u64 q0 = q[0], q1 = q[1], q2 = q[2];
+        u32 end = start + ((u32)(len > 0u) & (u32)(q0 < ub)) + ((u32)(len > 1u) & (u32)(q1 < ub)) + ((u32)(len > 2u) & (u32)(q2 < ub));
+        if (len > 3u) {
+#pragma unroll 1
+            for (u32 z = 3u; z < len; ++z) end += q[z] < ub ? 1u : 0u;
+        }
+        if (((ub ^ wy) >> gshift) != 0ull) end = ng;  // (the bound lies in the next group: everything behind y is inside)
+        dcnt_out[(size_t)lo + y] = (unsigned short)((fmt.dmin + nlev) | ((end - y - 1u) << 5));
     }
 }
 
@@ -4489,13 +4607,13 @@ hipError_t launch_scan_finalize(const uint64_t* shards, size_t out_blocks, size_
     return hipGetLastError();
 }
 
-template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false>
+template <int KIND, bool FILT, bool OWNER, int GEN = 0, bool OCC6 = false, bool PRECNT = false>
 static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hipStream_t stream) {
     // resident workgroups per dynamic-LDS size (0 .. SX_HIST_MAX rows of counters)
     static unsigned resident[SX_HIST_MAX + 1] = {};
     const int rows = sx_hist_rows(p);
     if (rows < 0 || rows > SX_HIST_MAX) return hipErrorInvalidValue;
-    if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6>, SX_THREADS, sx_hist_bytes(p));
+    if (!resident[rows]) resident[rows] = resident_blocks(scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6, PRECNT>, SX_THREADS, sx_hist_bytes(p));
     constexpr int occ = (FILT || OCC6) ? (SX_WAVES_PER_EU < 6 ? SX_WAVES_PER_EU : 6) : SX_WAVES_PER_EU;
     unsigned res = std::min(resident[rows], resident_cap(occ ? occ * 4 / SX_WAVES : 64));
     // small trees: a wave should have a dozen chunks to amortise its prologue, its last partial block and the counters' flush
@@ -4507,20 +4625,25 @@ static hipError_t launch_scan_expand_variant(ExpandParams p, size_t max_grid, hi
     if (const char* e = getenv("BP_SX_GRID")) res = (unsigned)atoi(e);  // (measurement knob: workgroups of the persistent grid)
     const unsigned grid = (unsigned)std::min<size_t>(max_grid, res);
     p.n_waves = grid * SX_WAVES;
-    scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
+    scan_expand_kernel<KIND, FILT, OWNER, GEN, OCC6, PRECNT><<<grid, SX_THREADS, sx_hist_bytes(p), stream>>>(p);
     if (!p.big_inline) scan_expand_big_kernel<KIND, FILT, OWNER, GEN><<<SXB_BLOCKS, SX_THREADS, 0, stream>>>(p);
     return hipGetLastError();
 }
+template <int KIND, bool PRECNT>
+static hipError_t launch_scan_expand_gen0(ExpandParams p, size_t max_grid, hipStream_t stream, bool occ6) {
+    const bool owner = p.owner_n >= 0;  // the owner-counting variant is a separate instantiation: the default kernel pays nothing
+    if (p.filt_bounds) return owner ? launch_scan_expand_variant<KIND, true, true, 0, false, PRECNT>(p, max_grid, stream)
+                                    : launch_scan_expand_variant<KIND, true, false, 0, false, PRECNT>(p, max_grid, stream);
+    if (owner) return launch_scan_expand_variant<KIND, false, true, 0, false, PRECNT>(p, max_grid, stream);
+    return occ6 ? launch_scan_expand_variant<KIND, false, false, 0, true, PRECNT>(p, max_grid, stream)
+                : launch_scan_expand_variant<KIND, false, false, 0, false, PRECNT>(p, max_grid, stream);
+}
 template <int KIND>
 static hipError_t launch_scan_expand_kind(ExpandParams p, size_t max_grid, hipStream_t stream, int gen, bool occ6) {
-    if (gen == 1) return launch_scan_expand_variant<KIND, false, false, 1>(p, max_grid, stream);
-    if (gen == 2) return launch_scan_expand_variant<KIND, false, false, 2>(p, max_grid, stream);
-    const bool owner = p.owner_n >= 0;  // the owner-counting variant is a separate instantiation: the default kernel pays nothing
-    if (p.filt_bounds) return owner ? launch_scan_expand_variant<KIND, true, true>(p, max_grid, stream)
-                                    : launch_scan_expand_variant<KIND, true, false>(p, max_grid, stream);
-    if (owner) return launch_scan_expand_variant<KIND, false, true>(p, max_grid, stream);
-    return occ6 ? launch_scan_expand_variant<KIND, false, false, 0, true>(p, max_grid, stream)
-                : launch_scan_expand_variant<KIND, false, false>(p, max_grid, stream);
+    // (the passes for ids that may repeat mark and re-read the context words of a tree no finish has counted: ranges searched)
+    if (gen == 1) { p.dcnt = nullptr; return launch_scan_expand_variant<KIND, false, false, 1>(p, max_grid, stream); }
+    if (gen == 2) { p.dcnt = nullptr; return launch_scan_expand_variant<KIND, false, false, 2>(p, max_grid, stream); }
+    return p.dcnt ? launch_scan_expand_gen0<KIND, true>(p, max_grid, stream, occ6) : launch_scan_expand_gen0<KIND, false>(p, max_grid, stream, occ6);
 }
 // digit plans the expanding scan can count while it emits: few enough passes, key digits only, and no digit that
 // straddles the two dwords of a packed pair (the kernel extracts a digit from ONE dword)
@@ -4534,18 +4657,18 @@ hipError_t launch_scan_expand(int kind, const uint64_t* keys, const uint64_t* id
                               uint64_t* pairs_out, size_t out_blocks, uint32_t* blockfill, uint64_t* shards,
                               uint64_t* big_list, uint32_t big_cap, DevScalars* sc, hipStream_t stream,
                               const RadixPlan* hist_plan, unsigned long long* hist, const uint32_t* owner_bounds, int owner_n,
-                              int gen, int mixed_scale) {
+                              int gen, int mixed_scale, const uint16_t* dcnt, uint32_t hist_rows) {
     if (m == 0) return hipSuccess;
     // persistent waves: as many workgroups as are resident at once, never more than the work
     const size_t chunks = (m + 63) / 64;
     const size_t max_grid = (chunks + SX_WAVES - 1) / SX_WAVES;
     ExpandParams p;
-    p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
+    p.keys = (const u64*)keys; p.idctx = (const u64*)idctx; p.dcnt = dcnt; p.m = m; p.out = (u64*)pairs_out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = sc; p.big_list = (u64*)big_list; p.big_cap = big_cap;
     p.n_waves = 0; p.filt_bounds = filt_bounds; p.filt_shape = filt_shape;
     // no work list expected (the last scan listed nothing): the work-list kernel is not launched; gen != 0 (the marking passes) always has it
     p.big_inline = (mixed_scale < 0 && gen == 0) ? 1u : 0u;
-    p.hist = (u64*)hist; p.hist_passes = 0;
+    p.hist = (u64*)hist; p.hist_passes = 0; p.hist_rows = hist_rows;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     if (hist_plan && hist && scan_can_count(*hist_plan)) {
         p.hist_passes = hist_plan->n_passes;
@@ -4999,7 +5122,7 @@ hipError_t launch_region_query(int kind, int ray, const uint64_t* keys, const ui
     ExpandParams p;
     p.keys = (const u64*)keys; p.idctx = nullptr; p.m = m; p.out = (u64*)out; p.out_blocks = out_blocks;
     p.blockfill = blockfill; p.shards = (u64*)shards; p.sc = nullptr; p.big_list = nullptr; p.big_cap = 0; p.big_inline = 0;
-    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.owner_n = -1;
+    p.n_waves = 0; p.filt_bounds = nullptr; p.filt_shape = FILT_AABB; p.hist = nullptr; p.hist_passes = 0; p.hist_rows = 0; p.owner_n = -1;
     for (int q = 0; q < SX_HIST_MAX; ++q) p.hist_shift[q] = 0;
     const unsigned g = (n_queries + SX_THREADS - 1) / SX_THREADS;
     if (ray) {
@@ -5544,8 +5667,9 @@ bool tgroup_composite_applies(int gshift, int distinct_id_bits) { return distinc
 bool tgroup_compact_applies(int comp_gshift) { return comp_gshift >= TG2_BIN_BITS && comp_gshift <= 63; }
 hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_groups, int comp_gshift, const TreeCompact& fmt, uint64_t* keys_out,
                                         uint32_t* ids_out, uint8_t* box_out, DevScalars* sc, hipStream_t stream, int ctx_kind, uint64_t* idctx_out,
-                                        const uint32_t* stats, uint32_t abort_over, const CellRoute& cells) {
+                                        uint16_t* dcnt_out, const uint32_t* stats, uint32_t abort_over, const CellRoute& cells) {
     if (n_groups == 0) return hipSuccess;
+    if (!dcnt_out || fmt.T > 15) return hipErrorInvalidValue;
     // (the kernel takes the index kind from its context-word instantiation: the compact route always writes the context words)
     if (comp_gshift < TG2_BIN_BITS || comp_gshift > 63 || !idctx_out || (ids_out == nullptr) != (box_out == nullptr) || ctx_kind < 0 || ctx_kind > 2 ||
         !cells.src)
@@ -5554,10 +5678,10 @@ hipError_t launch_tgroup_finish_compact(const uint64_t* words_in, uint32_t n_gro
     do {                                                                                                                                            \
         if (ids_out)                                                                                                                                \
             tgroup_finishc_kernel<K, S, true><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, \
-                                                                                     box_out, (u64*)idctx_out, sc, stats, abort_over, cells.src);   \
+                                                                                     box_out, (u64*)idctx_out, dcnt_out, sc, stats, abort_over, cells.src);   \
         else                                                                                                                                        \
             tgroup_finishc_kernel<K, S, false><<<n_groups, TGRP_THREADS, 0, stream>>>((const u64*)words_in, comp_gshift, fmt, (u64*)keys_out, ids_out, \
-                                                                                      box_out, (u64*)idctx_out, sc, stats, abort_over, cells.src);  \
+                                                                                      box_out, (u64*)idctx_out, dcnt_out, sc, stats, abort_over, cells.src);  \
     } while (0)
 #define BP_TGC_STEPS(K)                          \
     do {                                         \

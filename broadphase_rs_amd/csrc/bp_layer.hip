@@ -96,6 +96,8 @@ struct bp_layer {
     size_t n_raw = 0, n_pairs = 0;
     bool raw_is_unique = false;         // the last raw emission already suppressed every duplicate
     DevBuf idctx, big_list;             // expanding scan: per-entry id << 32 | suppression context; long-range work list
+    DevBuf dcnt;                        // per-entry depth | range length << 5, left by the compact tree finish (dcnt_epoch: for which tree)
+    uint64_t dcnt_epoch = 0;
     size_t big_cap = 0;                 // work-list capacity in use
     DevBuf qtab;                        // region queries: slice bounds of the top levels of the sorted tree ...
     uint64_t qtab_epoch = 0;            // ... computed for this epoch (0: never)
@@ -1136,7 +1138,9 @@ int sort_tree(bp_layer* L, bool defer_check) {
                 BP_TRY(ensure_dev(L, L->ids[dst], L->m * sizeof(uint32_t)));
                 BP_TRY(ensure_dev(L, L->box[dst], L->m));
             }
-            BP_TRY(ensure_dev(L, L->idctx, L->m * sizeof(uint64_t)));
+            // (readable a window beyond the tree: the scan's chunk loads are unconditional when it has the range lengths)
+            BP_TRY(ensure_dev(L, L->idctx, (L->m + SCAN_PAD_ENTRIES) * sizeof(uint64_t)));
+            BP_TRY(ensure_dev(L, L->dcnt, (L->m + SCAN_PAD_ENTRIES) * sizeof(uint16_t)));
             uint32_t* ws_epoch = nullptr;
             BP_TRY(radix_ws_tagged(L, radix_workspace_bytes(L->m, 2), &ws_epoch));
             BP_TRY(ensure_dev(L, L->tgrp_bounds, ((size_t)gp.n_groups + 1) * sizeof(uint32_t)));
@@ -1159,7 +1163,8 @@ int sort_tree(bp_layer* L, bool defer_check) {
                                              nullptr, L->stream, &d_ssc->err, (uint32_t)KERR_SEGMENT_TOO_LONG, (uint32_t)L->m));
                 HIP_TRY(L, launch_tgroup_finish_compact((const uint64_t*)L->tcell_keys.p, gp.n_groups, ccp.comp_gshift, L->cfmt, (uint64_t*)L->keys[dst].p,
                                                         lazy_ids ? nullptr : (uint32_t*)L->ids[dst].p, lazy_ids ? nullptr : (uint8_t*)L->box[dst].p, d_ssc,
-                                                        L->stream, L->kind, (uint64_t*)L->idctx.p, group_stats_words(d_ssc), (uint32_t)(L->m / 4), cr));
+                                                        L->stream, L->kind, (uint64_t*)L->idctx.p, (uint16_t*)L->dcnt.p, group_stats_words(d_ssc),
+                                                        (uint32_t)(L->m / 4), cr));
                 ++L->stats.tree_sorts_in_cells;
                 ++L->stats.tree_sorts_compact;
             }
@@ -1170,6 +1175,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
             L->ids_lazy = lazy_ids;
             L->box_valid = true;
             L->ctx_epoch = L->epoch; L->ctx_thr = 0; L->ctx_box = true; L->ctx_lo = 1; L->ctx_hi = 0;
+            L->dcnt_epoch = L->epoch;
             L->ids_packed = false;
             L->sort_pend.on = true; L->sort_pend.src = other; L->sort_pend.ride = true; L->sort_pend.cells = true; L->sort_pend.copied = false;
             L->sort_pend.compact = true;
@@ -1768,6 +1774,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
     p.box = have_box ? (const uint8_t*)L->box[L->cur].p : nullptr;
     L->raw_is_unique = have_box && L->box_all_known;
     static const bool no_expand = getenv("BP_NO_EXPAND_SCAN") != nullptr;  // A/B switch for measurements
+    static const bool no_range_counts = getenv("BP_NO_RANGE_COUNTS") != nullptr;  // A/B switch: the scan bisects the range ends in its key window
     bool expand = !no_expand;
     if (expand) {
         // per-entry {id, suppression context} words; recomputed only when the tree or the mode changed
@@ -1817,6 +1824,26 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                            d_shards, 3 * SX_SHARDS,
                                            (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
                                            count_digits ? (uint32_t)PAIR_HIST_WORDS : (uint32_t)(SX_HIST_MAX * RS_BINS), L->stream));
+            // the sort that goes out behind this scan (below): decided HERE, because the scan counts only the digits that sort will
+            // read -- on the cell route the high digit alone (the second pass is laid out from the previous frame's group sizes)
+            const bool ahead_now = L->ahead_try && attempt == 0 && count_digits;
+            const bp_layer::AheadHint h = L->ahead;
+            size_t n_bound = 0, extent_bound = 0;
+            bool cells_apply = false, cell_route = false;
+            if (ahead_now) {
+                n_bound = std::min<size_t>(h.n_raw + h.n_raw / 8 + 4096, out_blocks * SX_BLOCK);
+                extent_bound = std::min<size_t>(std::max(h.extent + h.extent / 8 + (size_t)SX_SHARDS * SX_BLOCK, n_bound), out_blocks * SX_BLOCK);
+                // The cell route (CellRoute, bp_kernels.h): two claiming passes -- high digit, then every high bin over its cells
+                // (= the finish's groups), laid out from the group sizes the LAST frame's finish left in grp_bounds -- instead of
+                // a claiming and a stable pass + the search for the group bounds.  A cell that outgrows its range is a miss.
+                static const bool no_cells = getenv("BP_NO_CELL_SORT") != nullptr;  // A/B switch for measurements
+                if (L->cell_off) --L->cell_off;
+                cells_apply = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
+                              h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 && radix_claim_applies(extent_bound);
+                cell_route = cells_apply && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
+            }
+            static const bool all_rows = getenv("BP_SCAN_ALL_DIGITS") != nullptr;  // A/B switch: both digit rows whatever the route
+            const uint32_t hist_rows = (cell_route && !all_rows) ? 2u : 0xFFFFFFFFu;  // (row 1 = the plan's second digit, shift 48)
             {
                 ProfScope ps(L, BP_K_SCAN_EMIT);
                 HIP_TRY(L, launch_scan_expand(L->kind, cur_keys(L), (const uint64_t*)L->idctx.p, L->m, filt_bounds, L->filt_shape,
@@ -1825,14 +1852,13 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                                               (uint32_t)std::min<size_t>(L->big_cap, 0xFFFFFFFFu),
                                               (DevScalars*)L->d_sc.p, L->stream, count_digits ? hist_plan : nullptr,
                                               (count_digits || count_owners) ? (unsigned long long*)L->pair_hist.p : nullptr,
-                                              count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1, 0, L->scan_listed));
+                                              count_owners ? owner_bounds : nullptr, count_owners ? owner_n : -1, 0, L->scan_listed,
+                                              // the range lengths the tree finish left for THIS tree (else the kernel searches the range ends)
+                                              (!no_range_counts && L->dcnt_epoch == L->epoch) ? (const uint16_t*)L->dcnt.p : nullptr, hist_rows));
             }
-            if (L->ahead_try && attempt == 0 && count_digits) {
+            if (ahead_now) {
                 // ---- the pair sort and its finish go out behind the scan, sized by the last frame's numbers; ONE round trip ----
                 L->ahead_try = false;
-                const bp_layer::AheadHint h = L->ahead;
-                const size_t n_bound = std::min<size_t>(h.n_raw + h.n_raw / 8 + 4096, out_blocks * SX_BLOCK);
-                const size_t extent_bound = std::min<size_t>(std::max(h.extent + h.extent / 8 + (size_t)SX_SHARDS * SX_BLOCK, n_bound), out_blocks * SX_BLOCK);
                 uint32_t* const d_sizes = sc_sizes_dev(L);
                 // (the sort's first kernel derives the sizes from the shard words: launch_scan_finalize's job without the launch)
                 const ScanFinalize fin{d_shards, out_blocks, n_bound, extent_bound, (const DevScalars*)L->d_sc.p, d_sizes};
@@ -1840,14 +1866,6 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 BP_TRY(ensure_dev(L, L->pairs[1], n_bound * sizeof(uint64_t)));
                 bufs[1] = (uint64_t*)L->pairs[1].p;
                 BP_TRY(ensure_dev(L, L->grp_bounds, ((size_t)h.n_groups + 1) * sizeof(uint32_t)));
-                // The cell route (CellRoute, bp_kernels.h): two claiming passes -- high digit, then every high bin over its cells
-                // (= the finish's groups), laid out from the group sizes the LAST frame's finish left in grp_bounds -- instead of
-                // a claiming and a stable pass + the search for the group bounds.  A cell that outgrows its range is a miss.
-                static const bool no_cells = getenv("BP_NO_CELL_SORT") != nullptr;  // A/B switch for measurements
-                if (L->cell_off) --L->cell_off;
-                const bool cells_apply = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
-                                         h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 && radix_claim_applies(extent_bound);
-                const bool cell_route = cells_apply && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
                 // the gapped layout needs n + n / 4 + 80 slots per cell: more than the raw stream's buffer holds when the scene is small
                 // (5.2 M slots for the 65536 cells alone).  The NEXT frame's buffer is sized for it (one reallocation, 42 MB at most
                 // beyond what the pairs need) -- before, a small scene took this route or not depending on how its buffer had grown
@@ -2260,7 +2278,7 @@ int bp_layer_destroy(bp_layer_t* L) {
     for (int i = 0; i < 2; ++i) { free_dev(L->keys[i]); free_dev(L->ids[i]); free_dev(L->pairs[i]); free_dev(L->box[i]); }
     free_dev(L->in_bounds); free_dev(L->in_ids); free_dev(L->counts); free_dev(L->block_sums); free_dev(L->aux);
     free_dev(L->skip); free_dev(L->out_pairs); free_dev(L->radix_ws); free_dev(L->d_sc);
-    free_dev(L->idctx); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
+    free_dev(L->idctx); free_dev(L->dcnt); free_dev(L->big_list); free_dev(L->blockfill); free_dev(L->shards); free_dev(L->tree_hist);
     free_dev(L->pair_hist); free_dev(L->cell_ws); free_dev(L->tcell_keys); free_dev(L->tcell_ids); free_dev(L->tcell_ws); free_dev(L->qtab); free_dev(L->cell_hist_dev); free_dev(L->grp_bounds); free_dev(L->d_sort_sc); free_dev(L->tgrp_bounds); free_dev(L->cell_sum);
     free_host(L->h_sc); free_host(L->h_pairs); free_host(L->h_keys); free_host(L->h_ids); free_host(L->h_raw); free_host(L->h_cells);
     free_host(L->h_shards); free_host(L->h_sort_sc); free_host(L->h_part_err); free_dev(L->d_part_err);

@@ -185,7 +185,7 @@ class TorchComm:
         return "cpu" if self.host_staged else backend.device
 
     # The RCCL build bundled with PyTorch-ROCm 2.10 silently moves only HALF of any single
-    # send/recv larger than 1 GiB (measured on MI355X: tools/dbg_a2a.py), so every exchange is cut
+    # send/recv larger than 1 GiB (measured on MI355X: tools/attic/dbg_a2a.py), so every exchange is cut
     # into per-peer pieces of at most CHUNK_BYTES.
     CHUNK_BYTES = 256 << 20
 

@@ -4,7 +4,11 @@ utils/src/gen_test_data.rs:98-155) WITHOUT the Rust toolchain: rand_core 0.5 `se
 rand_chacha 0.2 `ChaChaRng` (ChaCha20, 64-bit counter, stream 0, words consumed in order) and rand 0.7
 `gen_range` for f32 (`UniformFloat::sample_single`: 23 random mantissa bits -> [1, 2) - 1, then * scale + low)
 restated from their published algorithms.  The output is authenticated by the sha256 of the reference's
-Git-LFS pointers (tests/data/inputs/*.br_scene), which is all this container has of those files."""
+Git-LFS pointers (tests/data/inputs/*.br_scene), which is all this container has of those files.
+
+The generator a user calls is broadphase_rs_amd.scenes.gen_boxes_reference (behind tools/gen_validation_data.py --gen-inputs);
+this file keeps the SCALAR, draw-by-draw restatement as an independent check of it (tests/test_reference_goldens.py compares both
+with the oids) and the script that found the per-size cbrt correction."""
 import hashlib
 import struct
 import sys

@@ -47,6 +47,10 @@ def test_all_seven_reference_input_scenes_regenerate_to_their_lfs_hash(count):
     sysb, bounds, ids = ref_scene_gen.gen_boxes_fast(count, cbrt_ulps=meta["cbrt_ulps"])
     blob = ref_scene_gen.scene_v1_0_bytes(sysb, bounds, ids)
     assert len(blob) == meta["size"] and sha(blob) == meta["sha256"]
+    # the package's generator (what tools/gen_validation_data.py --gen-inputs calls) with its own cbrt table: the same bytes
+    from broadphase_rs_amd import scenes
+    s2, b2, i2 = scenes.gen_boxes_reference(count)
+    assert scene_io.Scene(system_bounds=s2, bounds=b2, ids=i2).assemble((1, 0)) == blob
 
 
 @pytest.mark.parametrize("count", [1000, 10000])

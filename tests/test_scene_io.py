@@ -51,11 +51,18 @@ def test_v1_2_round_trip_and_exact_bytes():
         Scene.parse(blob[:8] + b"\x01\x00\x03\x00" + blob[12:])
 
 
-def test_gen_inputs_tool(tmp_path):
+def test_gen_inputs_tool_reproduces_the_reference_input_scenes(tmp_path):
+    """tools/gen_validation_data.py --gen-inputs = tests/gen_test_scenes.py of the reference: the seven files it writes hash to the
+    Git-LFS oids of the reference's tests/data/inputs (SURVEY 8(f) #2: a gen_boxes-compatible generator)"""
+    import hashlib
+    import json
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_validation_data.py"), "--gen-inputs", str(tmp_path)])
-    for n, size in REFERENCE_INPUT_SIZES.items():
-        p = tmp_path / ("boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % n)
-        assert p.stat().st_size == size
+    oids = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_lfs_oids.json")))["inputs"]
+    assert len(oids) == len(REFERENCE_INPUT_SIZES)
+    for name, meta in oids.items():
+        blob = (tmp_path / name).read_bytes()
+        assert len(blob) == meta["size"] == REFERENCE_INPUT_SIZES[meta["count"]]
+        assert hashlib.sha256(blob).hexdigest() == meta["sha256"], name
 
 
 @pytest.mark.gpu

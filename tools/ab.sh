@@ -8,7 +8,7 @@ case "$1" in
   build) make -C broadphase_rs_amd/csrc -s OUT=../lib_ab/$2 EXTRA="$3" all ;;
   run) shift; for v in "$@"; do
          lib=broadphase_rs_amd/lib_ab/$v/libbroadphase_amd.so; [ "$v" = base ] && lib=broadphase_rs_amd/lib/libbroadphase_amd.so
-         BP_LIBRARY=$PWD/$lib python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-1m --no-moving ${AB_ARGS} > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || echo "variant $v failed"
+         BP_LIBRARY=$PWD/$lib python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-1m --no-moving --no-extra ${AB_ARGS} > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || echo "variant $v failed"
          python tools/ab_show.py $v
        done ;;
 esac

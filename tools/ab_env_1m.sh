@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}
   ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done
-    python bench.py --objects 1000000 --steps 60 --warmup 10 --no-cpu-baseline --no-1m --no-moving > gpurun_out/m1_$name.json 2>/dev/null )
+    python bench.py --objects 1000000 --steps 60 --warmup 10 --no-cpu-baseline --no-1m --no-moving --no-extra > gpurun_out/m1_$name.json 2>/dev/null )
   python - <<EOF2
 import json
 d=json.loads(open("gpurun_out/m1_$name.json").read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 N=${1:-1000000}
 R=$(pwd); OUT=$R/gpurun_out/tl_$N; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -- python3 $R/bench.py --objects $N --steps 20 --warmup 5 --no-cpu-baseline --no-1m --no-moving > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -- python3 $R/bench.py --objects $N --steps 20 --warmup 5 --no-cpu-baseline --no-1m --no-moving --no-extra > $OUT/log.txt 2>&1
 rc=$?
 cd $R
 python3 - <<EOF2

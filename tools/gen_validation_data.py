@@ -4,7 +4,9 @@ input scene, `extend` -> save 0_layer_unsorted, `sort` -> save 1_layer_sorted, `
 2_layer_collisions, all in the crate's BR_SCENE (1, 2) layout.
 
   python tools/gen_validation_data.py <input.br_scene> <out_dir>          (needs a GPU)
-  python tools/gen_validation_data.py --gen-inputs <out_dir>              (gen_test_scenes.py analogue, no GPU)
+  python tools/gen_validation_data.py --gen-inputs <out_dir>              (gen_test_scenes.py analogue, no GPU: the reference's
+                                                                           seven input scenes, byte for byte -- their SHA-256 are the
+                                                                           Git-LFS oids of tests/data/inputs)
 """
 import os
 import sys
@@ -18,7 +20,8 @@ from broadphase_rs_amd.scene_io import Scene  # noqa: E402
 def gen_inputs(out_dir):
     os.makedirs(out_dir, exist_ok=True)
     for count in (100, 300, 1000, 3000, 10000, 30000, 100000):   # tests/gen_test_scenes.py:12-33
-        sysb, bounds, ids = scenes.gen_boxes(count, seed=0, density=0.001, size_range=(1.0, 10.0))
+        # the reference's own generator (ChaCha20 stream, rand 0.7 sampling), restated bit for bit in scenes.gen_boxes_reference
+        sysb, bounds, ids = scenes.gen_boxes_reference(count, seed=0, density=0.001, size_range=(1.0, 10.0))
         s = Scene(system_bounds=sysb, bounds=bounds, ids=ids)
         s.save(os.path.join(out_dir, "boxes-seed_0-d_1_1000-s_1_10-n_%06d.br_scene" % count), version=(1, 0))
 

@@ -4,7 +4,7 @@ TAG=$1; shift
 R=$(pwd); OUT=$R/gpurun_out/kt_$TAG; mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-1m --no-moving > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-1m --no-moving --no-extra > $OUT/log.txt 2>&1
 rc=$?
 cd $R
 KS=$(find $OUT -name '*kernel_stats.csv' | head -1)

@@ -4,7 +4,7 @@ TAG=$1; shift
 CTRS=${@:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES}
 R=$(pwd); OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-1m --no-moving > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-1m --no-moving --no-extra > $OUT/log.txt 2>&1
 rc=$?
 cd $R
 python3 - <<PY
