@@ -2167,6 +2167,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 // The ancestor (owner) side supplies ONE word: DJ byte a = 0xE0 | (t_a(j) == 2 ? 0 : dd).  Then t = DJ - ctx has no borrow between bytes
 // (0xE0 >= 0xBF, the largest context byte), the code bits and 0xC0 of DJ cancel out of bit 5, and bit 5 of byte a  <=>  dd' >= G_a:
 // keep  <=>  (t & 0x202020) == 0x202020.  A skipped / inactive entry (byte 0 = 0x20 | code) always fails: 0xE0 + dd' - 0x20 has bit 5 clear.
+// a * b for operands below 2^24 as ONE full-rate instruction.  (__umul24 is not enough: where LLVM can prove the operands small it
+// rewrites the intrinsic into a plain multiply, and where it then loses that proof -- behind a select, a loop -- instruction
+// selection emits v_mul_lo_u32, a quarter-rate instruction: four issue slots in kernels that are bound by them)
+template <u32 K> __device__ __forceinline__ u32 mul24k(u32 a) {  // a * K, K a compile-time constant below 2^24 (an immediate, no register)
+    static_assert(K < (1u << 24), "24-bit constant");
+    u32 r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "i"(K), "v"(a));
+    return r;
+}
 constexpr u32 CTX_GUARD = 0x00202020u;
 constexpr u32 CTX_SKIPPED = 1u << 5;
 constexpr u32 CTX_INACTIVE = CTX_SKIPPED;
@@ -2177,8 +2186,9 @@ __host__ __device__ constexpr u32 ctx_codebits(u32 c27) {  // c27 = t_x + 3 t_y 
 }
 // G bytes from the per-axis trailing-zero counts f_a of the cell's coordinates: (depth - f_a) on the axes whose code is 2
 __device__ __forceinline__ u32 ctx_g_bytes(u32 codebits, u32 d, u32 f0, u32 f1, u32 f2) {
-    const u32 up = ((codebits >> 7) & 0x010101u) * 0x1Fu;            // 0x1F in the bytes of the upper-of-two axes
-    return (d * 0x010101u - (f0 | (f1 << 8) | (f2 << 16))) & up;    // (f_a <= d: no borrow)
+    // (24-bit multiplies, said explicitly: a 32-bit v_mul_lo_u32 is a quarter-rate instruction -- four issue slots -- on this part)
+    const u32 up = mul24k<0x1Fu>((codebits >> 7) & 0x010101u);            // 0x1F in the bytes of the upper-of-two axes
+    return (mul24k<0x010101u>(d) - (f0 | (f1 << 8) | (f2 << 16))) & up;    // (f_a <= d < 32: no borrow)
 }
 template <int KIND> __device__ __forceinline__ u32 make_entry_ctx(u64 key, u32 code, u32 inactive_below) {
     BoxCtx<KIND> bx;
@@ -2218,7 +2228,7 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_wide(u64 key, u
     // per axis: trailing zeros of the coordinate (this is the upper cell: the other one is a step down); an empty lane: the whole coordinate
     const u64 s0 = md & LANE, s1 = (md >> 1) & LANE, s2 = DIM == 3 ? (md >> 2) & LANE : 0ull;
     const u32 c0 = s0 ? (u32)__builtin_ctzll(s0) : DIM * d, c1 = s1 ? (u32)__builtin_ctzll(s1) : DIM * d, c2 = s2 ? (u32)__builtin_ctzll(s2) : DIM * d;
-    const u32 f0 = DIM == 3 ? (c0 * 171u) >> 9 : c0 >> 1, f1 = DIM == 3 ? (c1 * 171u) >> 9 : c1 >> 1, f2 = DIM == 3 ? (c2 * 171u) >> 9 : 0u;
+    const u32 f0 = DIM == 3 ? mul24k<171u>(c0) >> 9 : c0 >> 1, f1 = DIM == 3 ? mul24k<171u>(c1) >> 9 : c1 >> 1, f2 = DIM == 3 ? mul24k<171u>(c2) >> 9 : 0u;
     return ctx_g_bytes(codebits, d, f0, f1, f2) | codebits;
 }
 // The same word where the entry's DIM * depth Morton bits fit 32 (depth <= 10 in 3-D, <= 16 in 2-D): the three axes' trailing
@@ -2235,7 +2245,7 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut_narrow(u64 key,
     const u32 s0 = md & L0, s1 = md & L1, s2 = md & L2;
     const u32 p0 = s0 ? (u32)__builtin_ctz(s0) : nb, p1 = s1 ? (u32)__builtin_ctz(s1) : nb,
               p2 = DIM == 3 ? s2 ? (u32)__builtin_ctz(s2) : nb : nb;
-    const u32 f0 = DIM == 3 ? (p0 * 171u) >> 9 : p0 >> 1, f1 = DIM == 3 ? (p1 * 171u) >> 9 : p1 >> 1, f2 = DIM == 3 ? (p2 * 171u) >> 9 : 0u;
+    const u32 f0 = DIM == 3 ? mul24k<171u>(p0) >> 9 : p0 >> 1, f1 = DIM == 3 ? mul24k<171u>(p1) >> 9 : p1 >> 1, f2 = DIM == 3 ? mul24k<171u>(p2) >> 9 : 0u;
     return ctx_g_bytes(codebits, d, f0, f1, f2) | codebits;
 }
 template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c27, u32 inactive_below, const u32* s_lut) {
@@ -2247,8 +2257,8 @@ template <int KIND> __device__ __forceinline__ u32 entry_ctx_lut(u64 key, u32 c2
 // owner-side word of an ancestor entry of depth dd whose own context word is ctx_j: 0xE0 | dd per byte, dd = 0 on the axes where j is
 // the upper of its box's two cells (its lower cell covers a candidate's lower neighbour there: nothing passes, g_a >= 1)
 __device__ __forceinline__ u32 ctx_owner_dj(u32 dd, u32 ctx_j) {
-    const u32 up = ((ctx_j >> 7) & 0x010101u) * 0x1Fu;
-    return (0x00E0E0E0u | (dd * 0x010101u)) & ~up;
+    const u32 up = mul24k<0x1Fu>((ctx_j >> 7) & 0x010101u);
+    return (0x00E0E0E0u | mul24k<0x010101u>(dd)) & ~up;
 }
 // is candidate (entry i with context ctx_i, ancestor j described by dj) the emitting combo?
 __device__ __forceinline__ bool ctx_keep(u32 ctx_i, u32 dj) { return ((dj - ctx_i) & CTX_GUARD) == CTX_GUARD; }
@@ -3647,8 +3657,11 @@ template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u
         mort = e0 & 0xFFFu;
         nlev = e0 >> 12;
     } else if constexpr (NSTEP == 2) {
-        const u32 q = t / N3;
-        const u32 e0 = lut3[t - q * N3], e1 = lut3[q];
+        // t < BASE^6 (531441 in 3-D, 15625 in 2-D): the quotient by BASE^3 from ONE full-rate 24-bit multiply -- ceil(2^32 / 729) has 23
+        // bits and errs by less than 1 / 729 below 2^20; ceil(2^24 / 125) by less than 1 / 125 below 2^14 (a 32-bit division by a
+        // constant is a quarter-rate v_mul_hi_u32 plus fix-ups)
+        const u32 q = DIM == 3 ? (u32)(((u64)(t & 0xFFFFFu) * 5891589ull) >> 32) : (mul24k<134218u>(t & 0x3FFFu) >> 24);
+        const u32 e0 = lut3[t - mul24k<N3>(q)], e1 = lut3[q];
         mort = (e0 & 0xFFFu) | ((e1 & 0xFFFu) << (3 * DIM));
         nlev = (e0 >> 12) + (e1 >> 12);
     } else if (lut3) {
@@ -5292,8 +5305,15 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         }
         return;
     }
+    // (sub_scale below 2^24 says that the second ids are too: the 24-bit multiply is a full-rate instruction, the 32-bit
+    // v_mul_hi_u32 takes four issue slots -- eight of them per thread were 6 % of this kernel's instruction issue)
+    const bool sub24 = (sub_scale >> 31) != 0u;  // (the launcher's flag, in the top bit of the scale's word: see there)
+    const u32 sub_mul = sub_scale & 0x7FFFFFFFu;
     auto bin_of = [&](u64 v) {
-        const u32 sub = min(__umulhi((u32)v, sub_scale), GRP_SUB - 1u);  // (monotone in the second id)
+        u32 h;
+        if (sub24) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(h) : "v"((u32)v), "v"(sub_mul));
+        else h = __umulhi((u32)v, sub_mul) << 1;  // (the scale was halved to make room for the flag)
+        const u32 sub = min(h, GRP_SUB - 1u);  // (monotone in the second id)
         return (((u32)(v >> 32) & bmask) * GRP_SUB) | sub;
     };
     reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
@@ -5389,7 +5409,12 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)
     // second ids at most second_max: GRP_SUB equal ranges of them split every id's pairs (second * scale >> 32; larger values are clamped)
     const unsigned long long scale64 = ((unsigned long long)GRP_SUB << 32) / ((unsigned long long)second_max + 1ull);
-    const u32 sub_scale = scale64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)scale64;
+    u32 sub_scale = scale64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)scale64;
+    // second ids below 2^24 (and enough of them for the scale to fit 24 bits): the kernel multiplies 24-bit operands.  Any monotone
+    // map of the second id onto the sub-bins keeps the order; with few ids a clamped scale only leaves the upper sub-bins empty
+    const bool sub24 = second_max < (1u << 24);
+    if (sub24 && sub_scale >= (1u << 24)) sub_scale = (1u << 24) - 1u;
+    sub_scale = sub24 ? (0x80000000u | sub_scale) : (sub_scale >> 1);  // (bit 31: the kernel's switch; else the scale halved, the product doubled)
     if (cells)
         group_finish_kernel<true><<<n_groups, GRP_THREADS, 0, stream>>>((const u64*)in, bounds, g0, gbits, sub_scale, (uint2*)pairs_out, sc, stats,
                                                                         (u32)(n / 4), dev_sizes, *cells);
