@@ -544,9 +544,14 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_emit_compact_kernel(SysBou
                 t0 = s0 + 3u * s1 + 9u * s2;  // the first cell's code (ternary); a step on an axis adds 1 / 3 / 9
             }
             // The digits counted lie in the part of the word that is the index value shifted (the groups' bits: key_shift_delta
-            // takes a digit's shift back to the index value), and an object's cells lie between its first and its far-corner
-            // cell in index order: where those two agree on a digit all of them do -- one LDS add of the cell count for the object
-            // instead of one per entry (five objects in six on the uniform scene; the adds were a third of the LDS pipe's time)
+            // takes a digit's shift back to the index value).  Every cell of the object is key0 XOR a subset of {dx, dy, dz}, and
+            // the three deltas occupy DISJOINT Morton lanes (x, y, z bits never share a position): so the XOR of the selected deltas
+            // has a zero digit exactly when each selected delta does, and where the first and the far-corner cell (= all deltas
+            // selected) agree on a digit every cell of the object does -- one LDS add of the cell count for the object instead of one
+            // per entry (five objects in six on the uniform scene; the adds were a third of the LDS pipe's time).  (NOT because the
+            // cells lie between the two in index order -- agreement of two ends on one 8-bit digit would not imply agreement in
+            // between; a change that lets the deltas share a lane, e.g. counting the format's tail digits, breaks this silently:
+            // tests/test_compact_format.py::test_digit_shortcut_of_the_emit_pass cross-checks per-object against per-entry counts)
             u32 per_entry = 0;  // bit q: pass q's digit differs inside the object -- its entries count themselves
             {
                 const u64 kmax = key0 ^ ((sbits & 1u) ? dx : 0ull) ^ ((sbits & 2u) ? dy : 0ull) ^ ((sbits & 4u) ? dz : 0ull);

@@ -45,9 +45,15 @@ RcclApi* rccl_api() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+        // BP_RCCL_LIBRARY: another library with RCCL's entry points (tests/cpp/fake_rccl.cpp: ranks as PROCESSES on one GPU, bytes
+        // through shared memory -- the engine's multi-rank code over a real process boundary where the pool has one GPU per box)
+        if (const char* over = getenv("BP_RCCL_LIBRARY")) {
+            api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (api.lib) break;
+            }
         }
         if (!api.lib) { api.why = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found"); return; }
         auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p) api.why = std::string("librccl lacks ") + n; return p; };
@@ -168,7 +174,12 @@ int grp_wait(bp_group* g) {
 // test switch: the part of an exchange that stays on the rank also goes through ncclSend / ncclRecv (a one-rank group
 // then exercises the whole RCCL binding)
 bool self_through_rccl() { return getenv("BP_SHARDED_SELF_SEND") != nullptr; }  // read per call: tests flip it
-constexpr size_t CHUNK_BYTES = 256u << 20;  // per-peer message size cap (RCCL of PyTorch-ROCm 2.10 halves messages > 1 GiB)
+// per-peer message size cap (RCCL of PyTorch-ROCm 2.10 halves messages > 1 GiB); BP_SHARDED_CHUNK_BYTES: test hook (the multi-round cut on small scenes)
+static size_t chunk_bytes() {
+    static const size_t v = getenv("BP_SHARDED_CHUNK_BYTES") ? std::max<size_t>(64, (size_t)strtoull(getenv("BP_SHARDED_CHUNK_BYTES"), nullptr, 0)) : (size_t)(256u << 20);
+    return v;
+}
+#define CHUNK_BYTES (chunk_bytes())
 
 #define RCCL_TRY(g, call)                                                                                   \
     do {                                                                                                    \

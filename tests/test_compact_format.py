@@ -79,3 +79,36 @@ def test_the_headline_scene_fits_64_bits_only_with_the_digit_tail():
     33 + 3 + 24 + 5 = 65 bits; prefix to level 6 or 7 + base-9 digits take 63"""
     assert fmt(2, 7, 11, 24)["total"] == 63 and fmt(2, 6, 11, 24)["total"] == 63
     assert 3 * 11 + 3 + 24 + 5 == 65
+
+
+def test_digit_shortcut_of_the_emit_pass():
+    """encode_emit_compact_kernel counts a radix digit ONCE per object where the object's first and far-corner cell agree on it
+    (csrc/bp_kernels.hip): correct because the per-axis key deltas live in disjoint Morton lanes -- every cell is the first cell XOR a
+    subset of the deltas, so a digit the far corner shares is shared by all.  Cross-check on random 2 x 2 x 2 boxes that straddle digit
+    boundaries: per-object counts (cell count added to the first cell's digit when the two ends agree, else per entry) == per-entry counts."""
+    rng = np.random.default_rng(7)
+    dim, db, ab = KIND[2]
+    for trial in range(300):
+        depth = int(rng.integers(2, 12))
+        # first cell coordinates chosen near power-of-two boundaries so that +1 carries across many bits (and digits)
+        c = []
+        for a in range(3):
+            hi_bit = int(rng.integers(1, depth))
+            base = (int(rng.integers(0, 1 << (depth - hi_bit))) << hi_bit) | ((1 << hi_bit) - 1)
+            c.append(min(base, (1 << depth) - 2))
+        two = [int(rng.integers(0, 2)) for _ in range(3)]
+        def key_of(x, y, z):
+            m = 0
+            for k in range(depth):
+                m |= (((x >> k) & 1) << (3 * k)) | (((y >> k) & 1) << (3 * k + 1)) | (((z >> k) & 1) << (3 * k + 2))
+            return ((m << (3 * (ab - depth))) << db) | depth
+        cells = [key_of(c[0] + dx, c[1] + dy, c[2] + dz) for dz in range(two[2] + 1) for dy in range(two[1] + 1) for dx in range(two[0] + 1)]
+        first, far = cells[0], cells[-1]
+        for shift in (8, 16, 24, 32, 40, 48, 56):
+            per_entry = np.bincount([(k >> shift) & 255 for k in cells], minlength=256)
+            per_object = np.zeros(256, dtype=np.int64)
+            if ((first ^ far) >> shift) & 255 == 0:
+                per_object[(first >> shift) & 255] += len(cells)
+            else:
+                per_object += per_entry
+            assert np.array_equal(per_entry, per_object), (trial, shift, [hex(k) for k in cells])

@@ -295,3 +295,41 @@ def test_compact_route_on_random_layers(seed, monkeypatch):
         gpu.par_sort(); ref.sort()
         check_tree(gpu, ref, what + " par_sort")
         check_pairs(gpu.par_scan(), ref.scan(), what + " par_scan")
+
+
+def test_a_compact_sort_that_fails_its_deferred_check_is_repaired(monkeypatch):
+    """the repair branch of a failed COMPACT sort (settle_sort with sort_pend.compact: the first pass's composite words are
+    expanded in place, the full-width sort runs on plain entries) had no test.  Uniform frames choose the compact format; then a third
+    of the objects moves into one corner between two frames, cells laid out from the previous sort's group sizes overflow there
+    (KERR_SEGMENT_TOO_LONG in the sort's scalars), and the scan that ran behind the unfinished sort -- on depth / range-length words
+    the finish never wrote for the groups it gave up -- is void: the deferred check repairs the tree and scans again.  Tree and pairs
+    equal the oracle's in every frame."""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    n = 300000
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=91)
+    size = bounds[:, 3:] - bounds[:, :3]
+    side = np.float32(sysb[1][0])
+    rng = np.random.default_rng(92)
+    gpu = bp.Layer(bp.Index64_3D, 0)
+    before = None
+    for frame in range(7):
+        mn = bounds[:, :3].copy()
+        if frame in (3, 4):   # a third of the objects into the lower corner (an eighth of the volume): groups there grow ~ 3.5 x
+            pick = rng.random(n) < 0.33
+            mn[pick] *= np.float32(0.5)
+        mn = np.minimum(np.maximum(mn + (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)), np.float32(0)), side - size).astype(np.float32)
+        cur = np.ascontiguousarray(np.concatenate([mn, mn + size], axis=1).astype(np.float32))
+        if frame == 3:
+            before = gpu.stats()
+        ref = oracle.OracleLayer(2, 0)
+        gpu.clear()
+        gpu.extend(sysb, cur, ids); ref.extend(sysb, cur, ids)
+        gpu.par_sort(); ref.par_sort()
+        # (the scan first: it is the consumer that ran behind the sort whose check is still pending)
+        check_pairs(gpu.scan_device().to_numpy(), ref.par_scan(), "bunching scene, frame %d, par_scan" % frame)
+        check_tree(gpu, ref, "bunching scene, frame %d, par_sort" % frame)
+    st = gpu.stats()
+    keys = ("tree_sorts_compact", "tree_sorts_in_cells", "sort_repairs", "tree_expands", "extend_reruns")
+    assert before["tree_sorts_compact"] >= 1 and before["sort_repairs"] == 0, {k: before[k] for k in keys}
+    # the bunched frame's sort was a compact one (the extend before it wrote composite words) and its check failed
+    assert st["sort_repairs"] >= before["sort_repairs"] + 1 and st["tree_expands"] >= before["tree_expands"] + 1, ({k: before[k] for k in keys}, {k: st[k] for k in keys})
