@@ -2474,6 +2474,20 @@ struct WaveStageT {
     u32 pend = 0;  // lane 0: what the reservation in flight returns (k_pend)
     u32 k_pend = 0;
     u64* stat = nullptr;  // LDS_STATS: [0] pairs written, [1] candidates examined
+    // the lean block write of the scanning kernel (write_full): the output's capacity in blocks as 32 bits, and -- when exactly ONE
+    // digit row is counted and it lies in the pairs' high dword (the cell route's) -- that row's shift and LDS offset
+    u32 cap_blocks = 0;
+    u32 fast_sh = 0, fast_row = 0, fast_on = 0;
+    __device__ __forceinline__ void setup_lean(const ExpandParams& p) {
+        cap_blocks = p.out_blocks > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)p.out_blocks;
+        u32 n = 0, sh = 0, row = 0, hi = 0;
+        for (int h = 0; h < SX_HIST_MAX; ++h)
+            if (h < p.hist_passes && ((p.hist_rows >> h) & 1u)) { ++n; sh = (u32)p.hist_shift[h] & 31u; row = (u32)h; hi = p.hist_shift[h] >= 32 ? 1u : 0u; }
+        // (wave-uniform, said explicitly: they live in scalar registers and the per-block branch on fast_on is a scalar branch)
+        fast_on = (u32)__builtin_amdgcn_readfirstlane((int)((p.owner_n < 0 && n == 1u && hi == 1u) ? 1u : 0u));
+        fast_sh = (u32)__builtin_amdgcn_readfirstlane((int)sh);
+        fast_row = (u32)__builtin_amdgcn_readfirstlane((int)(row * 256u));
+    }
     __device__ __forceinline__ void add_total(u32 n) {
         if (LDS_STATS) { if (lane_id() == 0) stat[0] += n; }
         else { total += n; if (SX_STATS_IN_VGPR) asm volatile("" : "+v"(total)); }
@@ -2557,12 +2571,62 @@ struct WaveStageT {
         if (fits && lane_id() == 0) p.blockfill[g] = fill;
         __builtin_amdgcn_wave_barrier();
     }
+    // a FULL block, with as few instructions as it takes (the scanning kernel is bound by its instruction count, scalar and vector
+    // alike; the general write_block spends ~60 scalar instructions and branches per block on fill masks, 64-bit block numbers and
+    // four digit rows that are mostly off): no lane masks, 32-bit block numbers, the one counted digit row straight-line
+    template <bool AHEAD>
+    __device__ __forceinline__ void write_full(const ExpandParams& p, u32 from) {
+        __builtin_amdgcn_wave_barrier();
+        if (k_left == 0) {
+            if (!k_pend) reserve(p);
+            next_k = (u64)(u32)__builtin_amdgcn_readfirstlane((int)pend);
+            k_left = SX_RESERVE;
+            k_pend = 0u;
+        }
+        const u32 g = (u32)next_k * (u32)SX_SHARDS + shard;
+        ++next_k;
+        --k_left;
+        const u64* const src = buf + from;
+        u64 pr[SX_BLOCK / 64];
+#pragma unroll
+        for (u32 q = 0; q < SX_BLOCK / 64; ++q) pr[q] = src[q * 64u + (u32)lane_id()];
+        if (g < cap_blocks) {  // capacity is checked by the host afterwards (from the cursors)
+            u64* const dst = p.out + (size_t)g * SX_BLOCK;
+#pragma unroll
+            for (u32 q = 0; q < SX_BLOCK / 64; ++q)
+                if (!(SX_EXP & 1)) dst[q * 64u + (u32)lane_id()] = pr[q];
+            if (lane_id() == 0) p.blockfill[g] = SX_BLOCK;
+        }
+        if (AHEAD && k_left == 1 && !k_pend) reserve(p);  // (a block ahead of its use)
+        if (fast_on) {
+            if (!(SX_EXP & 2)) {
+#pragma unroll
+                for (u32 q = 0; q < SX_BLOCK / 64; ++q)
+                    __hip_atomic_fetch_add(&hist[fast_row + (((u32)(pr[q] >> 32) >> fast_sh) & 255u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < SX_HIST_MAX; ++h) {
+                if (!(SX_EXP & 2) && h < p.hist_passes && ((p.hist_rows >> h) & 1u)) {  // a counted digit never straddles the two dwords (scan_can_count)
+                    const u32 sh = (u32)p.hist_shift[h] & 31u;
+                    const bool hi = p.hist_shift[h] >= 32;
+#pragma unroll
+                    for (u32 q = 0; q < SX_BLOCK / 64; ++q) {
+                        const u32 dg = ((hi ? (u32)(pr[q] >> 32) : (u32)pr[q]) >> sh) & 255u;
+                        __hip_atomic_fetch_add(&hist[h * 256 + dg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     // every full block leaves; the (fewer than SX_BLOCK) pairs behind them move to the front
     template <bool OWNER, bool AHEAD = false>
     __device__ __forceinline__ void drain(const ExpandParams& p) {
         u32 from = 0;
         while (wp - from >= SX_BLOCK) {  // wave-uniform
-            write_block<OWNER, AHEAD>(p, SX_BLOCK, from);
+            if constexpr (!OWNER && LDS_STATS) write_full<AHEAD>(p, from);   // (LDS_STATS: the scanning kernel, which called setup_lean)
+            else write_block<OWNER, AHEAD>(p, SX_BLOCK, from);
             from += SX_BLOCK;
         }
         if (from == 0) return;
@@ -2702,6 +2766,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     __shared__ u64 s_stat[SX_WAVES][2];
     WaveStageT<true> st{s_stage[w], 0u, gw % SX_SHARDS, 0ull, 0u, s_hist, 0ull};
     st.stat = s_stat[w];
+    st.setup_lean(p);
     if (lane < 2) s_stat[w][lane] = 0ull;
     // a chunk's global loads (clamped addresses: every load is unconditional, validity is decided at use)
     struct Pre { u64 k0, k1, w0, w1; u32 dc; };
