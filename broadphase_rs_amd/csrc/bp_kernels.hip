@@ -5473,7 +5473,8 @@ hipError_t launch_group_finish(const uint64_t* in, size_t n, uint32_t n_groups, 
     // stats (two words of the freshly reset scalars): [0] = largest group, [1] = pairs in groups above the capacity; a
     // quarter of all pairs there: the finish bails out
     // (cells: the bounds and the statistics come from launch_cell_count -- the input is gapped, nothing to search)
-    hipError_t e = cells ? launch_cell_count(*cells, g0, n_groups, bounds, (u32)GRP_CAP, stats, dev_sizes, stream)
+    // (cells are numbered by bits 8 .. 23 of the first id: the group's cell is g0's low 16 bits + its index; the kernel keeps the full g0 for the ids it writes)
+    hipError_t e = cells ? launch_cell_count(*cells, gbits == 8 ? (g0 & 0xFFFFu) : g0, n_groups, bounds, (u32)GRP_CAP, stats, dev_sizes, stream)
                          : launch_group_bounds_stats((const u64*)in, (u32)n, n_groups, (u64)g0, 32 + gbits, bounds, (u32)GRP_CAP, stats, stream, dev_sizes);
     if (e != hipSuccess) return e;
     // second ids below 2^bits: their top two bits split every id's pairs into GRP_SUB ranges (larger values are clamped)

@@ -525,6 +525,9 @@ int ensure_unpacked(bp_layer* L) {
 }
 
 bool tree_partial_plan(size_t m, unsigned long long varying, RadixPlan* plan, int* seg_shift_out);
+// will the next tree sort take the grouped plan where it applies?  Yes when the last sort's group sizes allowed it -- and, nothing
+// being known yet, on a layer's first sort (sort_tree: optimistic; BP_NO_OPTIMISTIC_FIRST_SORT switches that off)
+static bool tgrp_expected(const bp_layer* L);
 struct TreeGroupPlan { RadixPlan plan; int gshift; uint32_t n_groups; unsigned long long g0; };
 bool tree_group_plan(size_t m, unsigned long long key_and, unsigned long long key_or, TreeGroupPlan* out);
 // ---- compact route of the per-frame tree sort (TreeCompact, bp_kernels.h) ------------------------------------------------------
@@ -799,7 +802,7 @@ int extend_device(bp_layer* L, const float* sys_min, const float* sys_max, const
                         hist_plan.n_passes <= SX_HIST_MAX;
     {   // the coming sort takes the grouped plan when the previous sort's group sizes allowed it: count THOSE digits
         TreeGroupPlan gp;
-        if (L->m == 0 && L->tgrp_ok && tree_group_plan(add, sc.key_and, sc.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
+        if (L->m == 0 && tgrp_expected(L) && tree_group_plan(add, sc.key_and, sc.key_or, &gp) && gp.plan.n_passes <= SX_HIST_MAX) {
             hist_plan = gp.plan;
             count_digits = true;
         }
@@ -966,6 +969,10 @@ bool same_plan(const RadixPlan& a, const RadixPlan& b) {
     return true;
 }
 
+static bool tgrp_expected(const bp_layer* L) {
+    static const bool no_optimistic = getenv("BP_NO_OPTIMISTIC_FIRST_SORT") != nullptr;  // A/B switch
+    return L->tgrp_ok || (!L->tgrp_known && !no_optimistic);
+}
 int sort_tree(bp_layer* L, bool defer_check = false);
 int sort_tree_full(bp_layer* L, bool payload_already_packed);
 // tree = [head | sorted tail run]: sort the head alone, then one merge pass.  Returns 1 when it did the job.
@@ -1032,6 +1039,7 @@ int settle_sort(bp_layer* L, bool already_synced, bool* redone) {
     const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
     if (sc.err & KERR_LOOKBACK_TIMEOUT) return fail(L, BP_ERR_KERNEL, "radix look-back timed out");
     const bool tgrp_before = L->tgrp_ok;
+    L->tgrp_known = true;
     L->tgrp_ok = sc.grp_max <= (uint32_t)tgroup_capacity();  // for the next sort (stays on up to the capacity)
     if ((sc.err & KERR_SEGMENT_TOO_LONG) || L->tgrp_ok != tgrp_before) ++L->stats.tree_plan_flips;
     if (sc.err & KERR_SEGMENT_TOO_LONG) {
@@ -1125,6 +1133,12 @@ int sort_tree(bp_layer* L, bool defer_check) {
         bool done = false;
         TreeGroupPlan gp;
         const bool group_able = tree_group_plan(L->m, L->key_and, L->key_or, &gp);
+        // A layer's FIRST sort (nothing known about its group sizes yet) takes the grouped plan optimistically: the plan sizes its
+        // groups for an average of 60 % of the finish's capacity, which a scene without heavy clustering fits -- one pass fewer and
+        // the context words from the finish instead of three passes + segment finish + entry_ctx (a fresh layer's frame: 2.9 -> 2.6 ms
+        // at 10 M objects).  A scene that does not fit pays ONE repair (the deferred check's full-width sort, bp_stats.sort_repairs)
+        // and the layer remembers (tgrp_known); BP_NO_OPTIMISTIC_FIRST_SORT: the probing first sort of rounds 1 - 4
+        const bool tgrp_go = group_able && tgrp_expected(L);
         if (group_able && L->tgrp_ok && compact_go) {
             // the cell route on compact records: key-only claiming passes over composite words (16 bytes per record and pass instead
             // of 24), the finish expands them into index values, ids, box bytes and context words
@@ -1187,7 +1201,7 @@ int sort_tree(bp_layer* L, bool defer_check) {
             }
             BP_TRY(settle_sort(L));
             done = true;
-        } else if (group_able && L->tgrp_ok) {  // one pass fewer; the groups of equal prefix are ordered in LDS
+        } else if (group_able && tgrp_go) {  // one pass fewer; the groups of equal prefix are ordered in LDS
             L->stats.tree_sort_passes = (uint32_t)gp.plan.n_passes;
             const int other = L->cur ^ 1;
             BP_TRY(ensure_dev(L, L->keys[other], L->m * sizeof(uint64_t)));
@@ -1524,7 +1538,7 @@ int sort_distinct_pairs_in(bp_layer* L, uint64_t* buf0, size_t n, unsigned long 
         L->ahead.varying = varying; L->ahead.plan = plan;
         // (should the sort that goes out ahead take the cell route, the scan's buffer must hold the gapped layout: scan_fused_device)
         const size_t nb = n + n / 8 + 4096;
-        if (plan.n_passes == 2 && !plan.from_val[0] && !plan.from_val[1] && plan.shift[0] == 40 && plan.shift[1] == 48 && (first_range[1] >> 24) == 0 &&
+        if (plan.n_passes == 2 && !plan.from_val[0] && !plan.from_val[1] && plan.shift[0] == 40 && plan.shift[1] == 48 && (first_range[1] >> 24) == (first_range[0] >> 24) &&
             radix_claim_applies(std::max(L->raw_extent + L->raw_extent / 8, nb)))
             L->pairs_want_slots = std::max(L->pairs_want_slots, cell_layout_capacity(nb) + cell_layout_capacity(nb) / 16);
     }
@@ -1839,7 +1853,10 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                 static const bool no_cells = getenv("BP_NO_CELL_SORT") != nullptr;  // A/B switch for measurements
                 if (L->cell_off) --L->cell_off;
                 cells_apply = !no_cells && !L->cell_off && h.plan.n_passes == 2 && !h.plan.from_val[0] && !h.plan.from_val[1] &&
-                              h.plan.shift[0] == 40 && h.plan.shift[1] == 48 && (h.first_hi >> 24) == 0 && radix_claim_applies(extent_bound);
+                              h.plan.shift[0] == 40 && h.plan.shift[1] == 48 &&
+                              // (a pair's cell is bits 8 .. 23 of its first id: unique per 256-id group as long as the ids' top byte does not vary --
+                              // ids of any magnitude, round 5; rounds 3 - 4 asked for first ids below 2^24)
+                              (h.first_hi >> 24) == (h.first_lo >> 24) && radix_claim_applies(extent_bound);
                 cell_route = cells_apply && cell_layout_capacity(n_bound) <= out_blocks * SX_BLOCK;
             }
             static const bool all_rows = getenv("BP_SCAN_ALL_DIGITS") != nullptr;  // A/B switch: both digit rows whatever the route
@@ -1891,7 +1908,7 @@ int scan_fused_device(bp_layer* L, uint32_t coarse_depth, int emit_coarse, bool 
                     cr.cell_base = cw + 4 * (size_t)CELL_COUNT; cr.line_cur = cw + 5 * (size_t)CELL_COUNT + 16; cr.frag_cur = cw + 6 * (size_t)CELL_COUNT + 16;
                     cr.miss = d_sizes + SIZES_CELL_MISS;
                     // (the layout runs inside the sort's first kernel)
-                    cr.layout_prev_bounds = (const uint32_t*)L->grp_bounds.p; cr.layout_g0 = h.first_lo >> 8; cr.layout_groups = h.n_groups;
+                    cr.layout_prev_bounds = (const uint32_t*)L->grp_bounds.p; cr.layout_g0 = (h.first_lo >> 8) & 0xFFFFu; cr.layout_groups = h.n_groups;
                     cr.layout_limit = out_blocks * SX_BLOCK;
                 }
                 int res = 0;
@@ -2260,6 +2277,30 @@ int bp_layer_create(bp_layer_t** out, int index_kind, uint32_t min_depth, size_t
         if (rc == BP_OK) rc = ensure_dev(L, L->ids[0], index_capacity * sizeof(uint32_t));
     }
     if (rc == BP_OK && collision_capacity) rc = ensure_dev(L, L->out_pairs, collision_capacity * 2 * sizeof(uint32_t));
+    // Both capacities given (LayerBuilder::with_index_capacity + with_collision_capacity, src/layer.rs:652-668: "pre-size the
+    // vectors"): everything a frame of that size allocates on the way is allocated here, so that a layer's FIRST frame -- what a
+    // reference test or a one-shot caller runs -- pays no hipMalloc (0.05 - 0.1 ms each, ~0.4 ms per 10 M-object frame).  Sizes
+    // mirror the requests of extend / sort_tree / the scan; a request that turns out larger simply grows its buffer as before.
+    if (rc == BP_OK && index_capacity && collision_capacity) {
+        const size_t m = index_capacity, pc = collision_capacity;
+        const size_t raw_slots = std::max<size_t>(6 * m, pc + pc / 4 + 4096);   // the scan's block-structured output (scan_fused_device)
+        auto want = [&](DevBuf& b, size_t bytes) { if (rc == BP_OK) rc = ensure_dev(L, b, bytes); };
+        want(L->keys[1], m * sizeof(uint64_t));
+        want(L->ids[1], m * sizeof(uint32_t));
+        want(L->box[0], m); want(L->box[1], m);
+        want(L->idctx, (m + SCAN_PAD_ENTRIES) * sizeof(uint64_t));
+        want(L->dcnt, (m + SCAN_PAD_ENTRIES) * sizeof(uint16_t));
+        want(L->big_list, std::max<size_t>(65536, m / 16) * 2 * sizeof(uint64_t));
+        want(L->pairs[0], raw_slots * sizeof(uint64_t));
+        want(L->pairs[1], (pc + pc / 8 + 4096) * sizeof(uint64_t));
+        want(L->blockfill, (raw_slots / SX_BLOCK + 1) * sizeof(uint32_t));
+        want(L->pair_hist, PAIR_HIST_WORDS * sizeof(unsigned long long));
+        want(L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long));
+        if (rc == BP_OK) {   // (the radix passes' status words carry launch tags: zero-filled once per allocation -- here, not in the first frame)
+            uint32_t* unused = nullptr;
+            rc = radix_ws_tagged(L, std::max(radix_workspace_bytes(m, 3), radix_workspace_bytes(raw_slots, 2)), &unused);
+        }
+    }
     if (rc != BP_OK) {
         g_last_global_error = L->err;
         bp_layer_destroy(L);

@@ -215,6 +215,8 @@ def test_ids_above_2_27_keep_the_duplicate_suppression_on_the_compact_route(monk
     st = gpu.stats()
     assert st["tree_sorts_compact"] >= 3, {k: st[k] for k in ("tree_sorts_compact", "tree_sorts_in_cells", "extend_reruns", "tree_expands")}
     assert raw[0][0] > raw[0][1] and raw[-1][0] == raw[-1][1], raw   # first frame: every combo; on the route: each pair once
+    # round 5: the pair sort's cell route numbers its cells by bits 8 .. 23 of the first id -- ids of any magnitude whose top byte is constant
+    assert st["sorts_in_cells"] >= 1, {k: st[k] for k in ("sorts_in_cells", "sorts_ahead", "sorts_ahead_missed")}
 
 
 def test_compact_switch_off_gives_the_same_lists():

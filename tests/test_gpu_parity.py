@@ -325,7 +325,7 @@ def test_ten_million_steady_state_frames_match_the_oracle():
         out = gpu.scan_device()
         st = gpu.stats()
         passes.append((st["tree_sort_passes"], st["pair_sort_passes"]))
-    assert passes[0][0] == 3, passes                       # cold plan: 3 passes + tree_segment_finish
+    assert passes[0][0] == 2, passes                       # a layer's first sort takes the grouped plan optimistically (round 5; before: 3 passes + tree_segment_finish)
     assert passes[-1] == (2, 2), passes                    # the plan BENCH reports
     ref = oracle.OracleLayer(2, 0)
     ref.extend(sysb, bounds, ids)
@@ -674,8 +674,8 @@ def test_grouped_tree_sort_over_frames(kind):
         passes.append(gpu.stats()["tree_sort_passes"])
         if f in (2, 5, 9):
             assert_pairs_equal(np.array(gpu.par_scan()), ref.scan(), "scan after grouped tree sort, frame %d" % f)
-    if kind == 2:      # the uniform cube qualifies: frame 0 probes, frames 1-2 run one pass fewer (the 2-D scene leaves
-        assert passes[1] < passes[0] and passes[2] == passes[1], passes     # part of its square empty: groups too uneven)
+    if kind == 2:      # the uniform cube qualifies: the grouped plan from the layer's first sort on (round 5: optimistic; rounds
+        assert passes[1] <= passes[0] and passes[2] == passes[1], passes    # 1 - 4 probed in frame 0) -- the 2-D scene leaves part of its square empty: groups too uneven
 
 
 @pytest.mark.parametrize("kind", [2, 1, 0])
