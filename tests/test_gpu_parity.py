@@ -1162,3 +1162,22 @@ def test_scan_without_its_work_list_kernel_when_long_ranges_appear():
         gpu.clear()
         gpu.extend(sysb, b, ids); ref.extend(sysb, b, ids)
         assert_pairs_equal(gpu.par_scan(), ref.scan(), "frame %d" % f)
+
+
+@pytest.mark.parametrize("kind,n", [(2, 120000), (0, 150000)])
+def test_a_layer_built_with_both_capacities_runs_its_first_frame_in_presized_buffers(kind, n):
+    """LayerBuilder::with_index_capacity / with_collision_capacity (src/layer.rs:652-668) pre-size the reference's vectors; here a
+    builder given BOTH allocates every buffer a frame of that size needs at build() (round 5: the one-shot frame of a reference test
+    pays no hipMalloc).  Capacities that are too small only mean growth on the way; either way the first frame -- which also takes
+    the grouped plan optimistically -- equals the oracle's tree and list."""
+    sysb, bounds, ids = scenes.gen_boxes(n, seed=77) if kind == 2 else scenes.gen_circles_2d(n, seed=77)
+    ref = oracle.OracleLayer(kind, 0)
+    ref.extend(sysb, bounds, ids)
+    ref.sort()
+    exp = ref.scan()
+    for idx_cap, pair_cap in ((int(len(ref) * 1.1), int(len(exp) * 1.1)), (1000, 1000)):
+        gpu = bp.LayerBuilder.new().with_min_depth(0).with_index_capacity(idx_cap).with_collision_capacity(pair_cap).build(KINDS[kind])
+        gpu.extend(sysb, bounds, ids)
+        gpu.par_sort()
+        assert_pairs_equal(np.array(gpu.par_scan()), exp, "first frame of a pre-sized layer (%d, %d)" % (idx_cap, pair_cap))
+        assert_tree_equal(gpu, ref, "first frame of a pre-sized layer (%d, %d)" % (idx_cap, pair_cap))
