@@ -2715,7 +2715,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 // (the filtering variants need more registers than seven waves leave: they keep the range 5 .. 6.  OCC6: the same for the default
 // variant, chosen at launch for mixed-scale scenes -- with ranges that leave the LDS windows, the seventh wave per SIMD costs the
 // scan 2.5 % (12.5 M power-law objects: 1.15 against 1.12 ms), on the uniform scene it gains as much)
-#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu((FILT || OCC6) ? 5 : SX_WAVES_PER_EU, (FILT || OCC6) ? 6 : SX_WAVES_PER_EU)))
+#ifndef SX_FILT_WAVES
+#define SX_FILT_WAVES 4  // FILT: two register sets of narrow-phase rows in flight (the exact test runs one step behind its loads)
+#endif
+#define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FILT ? SX_FILT_WAVES : OCC6 ? 5 : SX_WAVES_PER_EU, FILT ? SX_FILT_WAVES + 1 : OCC6 ? 6 : SX_WAVES_PER_EU)))
 #else
 #define SX_OCC_ATTR
 #endif
@@ -2750,6 +2753,8 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     union RecWin { uint4 rec[SX_REC]; u64 win[SX_WIN]; };
     __shared__ RecWin s_recwin[SX_WAVES];
     __shared__ u64 s_cwin[SX_WAVES][SX_WIN];  // {id, context} words of the entries [base, base + SX_WIN)
+    // FILT: the owners' narrow-phase rows beside their records (an owner's row is read once per chunk from HBM, not once per candidate)
+    __shared__ float s_orow[FILT ? SX_WAVES : 1][FILT ? SX_REC : 1][2 * FDIM];
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     // the digit counters: as many rows as this launch counts (dynamic LDS, sx_hist_bytes) -- with the two rows of the usual
     // pair sort a workgroup needs 22.6 KB and seven of them share a CU
@@ -2936,6 +2941,15 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                 s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
                     make_uint4((u32)lane + 1u + c - incl, (u32)(pre.w0 >> 32), ctx_owner_dj(dd, (u32)pre.w0), 0u);
             if (lane == 0) s_rec_w[n_own] = make_uint4(0u - total, 0u, CTX_DJ_NONE, 0u);
+            if constexpr (FILT) {
+                if (c > 0) {
+                    const u32 fs = filt_stride<FDIM>(p.filt_shape);
+                    const float* const row = p.filt_bounds + (size_t)(u32)(pre.w0 >> 32) * fs;
+                    float* const dst = s_orow[w][__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))];
+#pragma unroll
+                    for (int k = 0; k < 2 * FDIM; ++k) dst[k] = (u32)k < fs ? row[k] : 0.f;
+                }
+            }
         }
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         SX_T(t3);
@@ -2956,9 +2970,37 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             // One step = 128 candidates, two per lane (slot 0: candidate 128 b + lane, slot 1: + 64): the two lookup chains
             // (owner record -> {id, context} word -> test) are independent, so their LDS latencies overlap, and the
             // per-step bookkeeping is paid once per 128 candidates.
-            auto run_steps = [&](auto far_tag) {
+            // FILT: a step only ISSUES the row loads of its surviving candidates; the exact test and the push happen one step later,
+            // while the next step's loads are in flight (two register sets, the loop unrolled by two: a copy between sets would be
+            // a use and wait for the load).  What stays pending: the candidates' rows, their ids and their owners' record numbers.
+            auto run_steps = [&](auto far_tag, auto nf_tag) {
                 constexpr bool FAR = decltype(far_tag)::value;
-                for (u32 b = 0; b < n_steps; ++b) {
+                constexpr int NF = decltype(nf_tag)::value;  // floats per narrow-phase row (0: not FILT)
+                struct Pend { float a0[NF ? NF : 1], a1[NF ? NF : 1]; u32 c0, c1, o0, o1; bool k0, k1; };
+                Pend X{}, Y{};
+                auto retire = [&](Pend& R) {
+                    if constexpr (NF != 0) {
+#pragma unroll
+                        for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(R.a0[k]), "+v"(R.a1[k]));
+                        const float* const ow = &s_orow[FILT ? w : 0][0][0];
+                        float b0[NF], b1[NF];
+#pragma unroll
+                        for (int k = 0; k < NF; ++k) { b0[k] = ow[R.o0 * (2 * FDIM) + k]; b1[k] = ow[R.o1 * (2 * FDIM) + k]; }
+                        const u32 id0 = s_rec_w[R.o0].y, id1 = s_rec_w[R.o1].y;
+                        bool k0 = R.k0, k1 = R.k1;
+                        if constexpr (NF == FDIM + 1) { k0 = k0 & spheres_touch<FDIM>(R.a0, b0); k1 = k1 & spheres_touch<FDIM>(R.a1, b1); }
+                        else {  // boxes_overlap without its early outs: (NaN compares false, so NaN overlaps -- src/geom.rs:112-119)
+#pragma unroll
+                            for (int ax = 0; ax < FDIM; ++ax) {
+                                k0 = k0 & !(R.a0[ax] > b0[FDIM + ax]) & !(R.a0[FDIM + ax] < b0[ax]);
+                                k1 = k1 & !(R.a1[ax] > b1[FDIM + ax]) & !(R.a1[FDIM + ax] < b1[ax]);
+                            }
+                        }
+                        st.template push2<OWNER>(ballot64(k0), k0, id0, R.c0, ballot64(k1), k1, id1, R.c1, p);
+                        R.k0 = R.k1 = false;
+                    }
+                };
+                auto one = [&](u32 b, Pend& cur, Pend& prev) {
                     const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
                                    (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
                     const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
@@ -2968,9 +3010,12 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     const uint4* const rb0 = s_rec_w + owners_done;
                     const u32 n0 = (u32)__popcll(e0);
                     const uint4* const rb1 = rb0 + n0;
+                    [[maybe_unused]] const u32 owners_before = owners_done;
                     owners_done += n0 + (u32)__popcll(e1);
-                    const uint4 r0 = rb0[__builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u))];
-                    const uint4 r1 = rb1[__builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u))];
+                    const u32 oi0 = __builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u));
+                    const u32 oi1 = __builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u));
+                    const uint4 r0 = rb0[oi0];
+                    const uint4 r1 = rb1[oi1];
                     asm volatile("" : : "v"(r0.w), "v"(r1.w));  // (all four dwords: ds_read_b128 takes 4 LDS cycles, the ds_read_b96 of three takes 8)
                     const u32 off0 = kl + r0.x, off1 = kl + 64u + r1.x;   // candidate = entry base + off
                     const bool act0 = GEN == 1 && kl < total, act1 = GEN == 1 && kl + 64u < total;  // (only the marking pass asks)
@@ -3004,35 +3049,63 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     if (GEN == 1) {  // mark: a candidate whose id equals its ancestor's is dropped by the skip rule
                         if (act0 && w0hi == r0.y && !(w0lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off0, (u64)CTX_SKIPPED);
                         if (act1 && w1hi == r1.y && !(w1lo & CTX_SKIPPED)) atomicOr(const_cast<u64*>(p.idctx) + base + off1, (u64)CTX_SKIPPED);
-                        continue;
+                        return;
                     }
                     // no short circuit: the test runs on every lane and the ballots come straight out of the compares
                     const bool c0 = ctx_keep(w0lo, r0.z), c1 = ctx_keep(w1lo, r1.z);
                     if (GEN == 0 && !FILT) {
                         st.template push2<OWNER>(ballot64(c0), c0, r0.y, w0hi, ballot64(c1), c1, r1.y, w1hi, p);
                         SX_ACC(6, 1);
-                        continue;
+                        return;
                     }
                     bool keep0 = c0, keep1 = c1;
                     if (GEN == 2) {  // (implied by the test: a skipped entry's context never passes; kept explicit)
                         keep0 = keep0 && !(w0lo & CTX_SKIPPED);
                         keep1 = keep1 && !(w1lo & CTX_SKIPPED);
                     }
-                    if (FILT) {
-                        const u32 fs = filt_stride<FDIM>(p.filt_shape);
-                        if (keep0) keep0 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w0hi * fs, p.filt_bounds + (size_t)r0.y * fs, p.filt_shape);
-                        if (keep1) keep1 = narrow_keep<FDIM>(p.filt_bounds + (size_t)w1hi * fs, p.filt_bounds + (size_t)r1.y * fs, p.filt_shape);
+                    if constexpr (NF != 0) {
+                        cur.k0 = keep0; cur.k1 = keep1; cur.c0 = w0hi; cur.c1 = w1hi;
+                        cur.o0 = owners_before + oi0; cur.o1 = owners_before + n0 + oi1;
+                        // (unconditional, a dropped lane reads row 0: with the loads under a branch the count of loads in flight is
+                        // not a constant, and the wait for the PREVIOUS step's rows becomes a wait for everything)
+                        const float* const a0 = p.filt_bounds + (size_t)(keep0 ? w0hi : 0u) * NF;
+                        const float* const a1 = p.filt_bounds + (size_t)(keep1 ? w1hi : 0u) * NF;
+#pragma unroll
+                        for (int k = 0; k < NF; ++k) { cur.a0[k] = a0[k]; cur.a1[k] = a1[k]; }
+                        retire(prev);
+                        SX_ACC(6, 1);
+                        return;
                     }
                     SX_T(tp0);
                     st.template push2<OWNER>(ballot64(keep0), keep0, r0.y, w0hi, ballot64(keep1), keep1, r1.y, w1hi, p);
                     SX_T(tp1);
                     SX_ACC(4, tp1 - tp0);
                     SX_ACC(6, 1);
+                };
+                if constexpr (NF == 0) {
+                    for (u32 b = 0; b < n_steps; ++b) one(b, X, X);
+                } else {
+                    // (an odd last step LEAVES the loop: with "if (b + 1 < n) second half" inside, the flow graph has a path from the
+                    // first half back to the loop head, on which the first set would still be in flight -- and the compiler waits for it)
+                    for (u32 b = 0; b < n_steps; b += 2) {
+                        one(b, X, Y);
+                        if (b + 1u >= n_steps) break;
+                        one(b + 1u, Y, X);
+                    }
+                    retire(X); retire(Y);  // (one of them is empty; an empty set pushes nothing)
                 }
             };
             if (SX_EXP & 8) continue;
-            if (any_far) run_steps(std::true_type{});
-            else run_steps(std::false_type{});
+            if constexpr (!FILT) {
+                if (any_far) run_steps(std::true_type{}, std::integral_constant<int, 0>{});
+                else run_steps(std::false_type{}, std::integral_constant<int, 0>{});
+            } else if (p.filt_shape == FILT_SPHERE) {
+                if (any_far) run_steps(std::true_type{}, std::integral_constant<int, FDIM + 1>{});
+                else run_steps(std::false_type{}, std::integral_constant<int, FDIM + 1>{});
+            } else {
+                if (any_far) run_steps(std::true_type{}, std::integral_constant<int, 2 * FDIM>{});
+                else run_steps(std::false_type{}, std::integral_constant<int, 2 * FDIM>{});
+            }
         }
         __builtin_amdgcn_wave_barrier();
         SX_T(t4);
