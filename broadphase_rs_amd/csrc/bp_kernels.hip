@@ -2716,7 +2716,10 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 // variant, chosen at launch for mixed-scale scenes -- with ranges that leave the LDS windows, the seventh wave per SIMD costs the
 // scan 2.5 % (12.5 M power-law objects: 1.15 against 1.12 ms), on the uniform scene it gains as much)
 #ifndef SX_FILT_WAVES
-#define SX_FILT_WAVES 4  // FILT: two register sets of narrow-phase rows in flight (the exact test runs one step behind its loads)
+#define SX_FILT_WAVES 4  // FILT: the narrow-phase rows of SX_FILT_DEPTH steps in flight at once
+#endif
+#ifndef SX_FILT_DEPTH
+#define SX_FILT_DEPTH 2  // (2, 3, 4 measured equal at 10 M objects -- 0.640, 0.646, 0.663 ms: past two the gathers' throughput is the bound, not their latency)
 #endif
 #define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FILT ? SX_FILT_WAVES : OCC6 ? 5 : SX_WAVES_PER_EU, FILT ? SX_FILT_WAVES + 1 : OCC6 ? 6 : SX_WAVES_PER_EU)))
 #else
@@ -2970,23 +2973,26 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             // One step = 128 candidates, two per lane (slot 0: candidate 128 b + lane, slot 1: + 64): the two lookup chains
             // (owner record -> {id, context} word -> test) are independent, so their LDS latencies overlap, and the
             // per-step bookkeeping is paid once per 128 candidates.
-            // FILT: a step only ISSUES the row loads of its surviving candidates; the exact test and the push happen one step later,
-            // while the next step's loads are in flight (two register sets, the loop unrolled by two: a copy between sets would be
-            // a use and wait for the load).  What stays pending: the candidates' rows, their ids and their owners' record numbers.
+            // FILT: the steps of a chunk (about three on the uniform scene) are taken SX_FILT_DEPTH at a time -- first every step's
+            // candidates are found and the loads of their narrow-phase rows issued (unconditionally: a dropped lane, and a step beyond
+            // the last, read row 0, so the number of loads in flight is a constant the waits can count), then the steps are finished
+            // in order: exact test against the owner's row (LDS), push.  One exposed memory latency per group instead of per step.
+            // (Tried first: a rolling two-set pipeline across the loop's back edge -- the register allocator copies the loop-carried
+            // rows between sets, a copy is a use, and the wait for it undid the overlap.)
             auto run_steps = [&](auto far_tag, auto nf_tag) {
                 constexpr bool FAR = decltype(far_tag)::value;
                 constexpr int NF = decltype(nf_tag)::value;  // floats per narrow-phase row (0: not FILT)
-                struct Pend { float a0[NF ? NF : 1], a1[NF ? NF : 1]; u32 c0, c1, o0, o1; bool k0, k1; };
-                Pend X{}, Y{};
+                struct Pend { float a0[NF ? NF : 1], a1[NF ? NF : 1]; u32 c0, c1, oo; bool k0, k1; };  // oo: the owners' record numbers, 16 bits each
                 auto retire = [&](Pend& R) {
                     if constexpr (NF != 0) {
 #pragma unroll
                         for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(R.a0[k]), "+v"(R.a1[k]));
                         const float* const ow = &s_orow[FILT ? w : 0][0][0];
+                        const u32 o0 = R.oo & 0xFFFFu, o1 = R.oo >> 16;
                         float b0[NF], b1[NF];
 #pragma unroll
-                        for (int k = 0; k < NF; ++k) { b0[k] = ow[R.o0 * (2 * FDIM) + k]; b1[k] = ow[R.o1 * (2 * FDIM) + k]; }
-                        const u32 id0 = s_rec_w[R.o0].y, id1 = s_rec_w[R.o1].y;
+                        for (int k = 0; k < NF; ++k) { b0[k] = ow[o0 * (2 * FDIM) + k]; b1[k] = ow[o1 * (2 * FDIM) + k]; }
+                        const u32 id0 = s_rec_w[o0].y, id1 = s_rec_w[o1].y;
                         bool k0 = R.k0, k1 = R.k1;
                         if constexpr (NF == FDIM + 1) { k0 = k0 & spheres_touch<FDIM>(R.a0, b0); k1 = k1 & spheres_touch<FDIM>(R.a1, b1); }
                         else {  // boxes_overlap without its early outs: (NaN compares false, so NaN overlaps -- src/geom.rs:112-119)
@@ -2997,10 +3003,9 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                             }
                         }
                         st.template push2<OWNER>(ballot64(k0), k0, id0, R.c0, ballot64(k1), k1, id1, R.c1, p);
-                        R.k0 = R.k1 = false;
                     }
                 };
-                auto one = [&](u32 b, Pend& cur, Pend& prev) {
+                auto one = [&](u32 b, Pend& cur) {
                     const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
                                    (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
                     const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
@@ -3065,14 +3070,7 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     }
                     if constexpr (NF != 0) {
                         cur.k0 = keep0; cur.k1 = keep1; cur.c0 = w0hi; cur.c1 = w1hi;
-                        cur.o0 = owners_before + oi0; cur.o1 = owners_before + n0 + oi1;
-                        // (unconditional, a dropped lane reads row 0: with the loads under a branch the count of loads in flight is
-                        // not a constant, and the wait for the PREVIOUS step's rows becomes a wait for everything)
-                        const float* const a0 = p.filt_bounds + (size_t)(keep0 ? w0hi : 0u) * NF;
-                        const float* const a1 = p.filt_bounds + (size_t)(keep1 ? w1hi : 0u) * NF;
-#pragma unroll
-                        for (int k = 0; k < NF; ++k) { cur.a0[k] = a0[k]; cur.a1[k] = a1[k]; }
-                        retire(prev);
+                        cur.oo = (owners_before + oi0) | ((owners_before + n0 + oi1) << 16);
                         SX_ACC(6, 1);
                         return;
                     }
@@ -3083,16 +3081,25 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     SX_ACC(6, 1);
                 };
                 if constexpr (NF == 0) {
-                    for (u32 b = 0; b < n_steps; ++b) one(b, X, X);
+                    Pend none{};
+                    for (u32 b = 0; b < n_steps; ++b) one(b, none);
                 } else {
-                    // (an odd last step LEAVES the loop: with "if (b + 1 < n) second half" inside, the flow graph has a path from the
-                    // first half back to the loop head, on which the first set would still be in flight -- and the compiler waits for it)
-                    for (u32 b = 0; b < n_steps; b += 2) {
-                        one(b, X, Y);
-                        if (b + 1u >= n_steps) break;
-                        one(b + 1u, Y, X);
+                    for (u32 b = 0; b < n_steps; b += SX_FILT_DEPTH) {
+                        Pend P[SX_FILT_DEPTH];
+#pragma unroll
+                        for (int q = 0; q < SX_FILT_DEPTH; ++q) {
+                            Pend& cur = P[q];
+                            cur.k0 = cur.k1 = false; cur.c0 = cur.c1 = 0u; cur.oo = 0u;
+                            if (b + (u32)q < n_steps) one(b + (u32)q, cur);  // (wave-uniform)
+                            const float* const a0 = p.filt_bounds + (size_t)(cur.k0 ? cur.c0 : 0u) * NF;
+                            const float* const a1 = p.filt_bounds + (size_t)(cur.k1 ? cur.c1 : 0u) * NF;
+#pragma unroll
+                            for (int k = 0; k < NF; ++k) { cur.a0[k] = a0[k]; cur.a1[k] = a1[k]; }
+                        }
+#pragma unroll
+                        for (int q = 0; q < SX_FILT_DEPTH; ++q)
+                            if (b + (u32)q < n_steps) retire(P[q]);
                     }
-                    retire(X); retire(Y);  // (one of them is empty; an empty set pushes nothing)
                 }
             };
             if (SX_EXP & 8) continue;

@@ -1,6 +1,6 @@
 """Per-kernel-class times of the fused narrow phase frame (clear + extend + par_sort + scan_filtered_aabb_device on the headline
 scene), from the layer's own event profile.   python tools/filt_micro.py [n_objects]
-A/B: BP_NO_FILTER_QBOX=1 (exact rows only), BP_LIBRARY=<variant .so>."""
+A/B: BP_LIBRARY=<variant .so>."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import time
@@ -36,5 +36,5 @@ for _ in range(K):
     out = step()
 torch.cuda.synchronize()
 prof = L.profile()
-print("filtered frame %.3f ms wall, %d pairs; qbox %s" % (wall, len(out), "off" if os.environ.get("BP_NO_FILTER_QBOX") else "on"))
+print("filtered frame %.3f ms wall, %d pairs" % (wall, len(out)))
 print("  " + "  ".join("%s %.3f" % (k, ms / K) for k, (ms, cnt) in sorted(prof.items()) if ms / K > 0.004))
