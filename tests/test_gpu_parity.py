@@ -479,6 +479,37 @@ def test_builtin_sphere_predicate_equals_host_filter(kind, n):
         gpu.scan_filtered_sphere(sph[: n // 2])
 
 
+@pytest.mark.parametrize("scene", ["uniform", "powerlaw"])
+def test_fused_narrow_phase_over_frames_with_ranges_that_leave_the_window(scene, monkeypatch):
+    """the filtering scan in the per-frame pattern (third and later frames: range lengths from the tree finish, a chunk's steps taken
+    in groups, owners' rows in LDS) -- on a uniform scene and on one whose large objects give ranges of thousands of candidates (the
+    far-candidate loop, the work list); rows with NaN / infinite components keep what the reference's predicates keep"""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")   # (the claiming passes, and with them the cell routes, start at ~2 M records by default)
+    n = 200000
+    sysb, bounds, ids = (scenes.gen_boxes(n, seed=23) if scene == "uniform" else scenes.gen_boxes_powerlaw(n, seed=23, alpha=1.5))
+    rows = bounds.copy()
+    rows[7, 1] = np.nan; rows[11, 4] = np.inf; rows[13, 0] = -np.inf          # (geom.rs:112-119: negated compares, NaN overlaps)
+    centre = ((bounds[:, :3] + bounds[:, 3:]) * np.float32(0.5)).astype(np.float32)
+    radius = ((bounds[:, 3:] - bounds[:, :3]).max(axis=1) * np.float32(0.5)).astype(np.float32)
+    sph = np.ascontiguousarray(np.concatenate([centre, radius[:, None]], axis=1), dtype=np.float32)
+    sph[5, 0] = np.nan; sph[9, 3] = np.inf
+    gpu, ref = both(2, 0)
+    ref.extend(sysb, bounds, ids)
+    full = ref.scan()
+    exp_box = full[_aabb_overlap(rows, full, 3)]
+    exp_sph = full[_spheres_touch(sph, full, 3)]
+    assert 0 < len(exp_box) < len(full) and 0 < len(exp_sph) < len(full)
+    for frame in range(7):
+        gpu.clear(); gpu.extend(sysb, bounds, ids); gpu.par_sort()
+        if frame % 2 == 0:
+            assert_pairs_equal(gpu.scan_filtered_aabb(rows), exp_box, "%s frame %d: box rows" % (scene, frame))
+        else:
+            assert_pairs_equal(gpu.scan_filtered_sphere(sph), exp_sph, "%s frame %d: sphere rows" % (scene, frame))
+    if scene == "uniform":
+        assert gpu.stats()["tree_sorts_compact"] >= 2     # (the route whose finish leaves the range lengths)
+    assert_pairs_equal(np.array(gpu.par_scan()), full, "%s: the unfiltered scan of the same layer" % scene)
+
+
 @pytest.mark.parametrize("k", [300, 2500])
 def test_grouped_pair_finish_handles_oversize_and_empty_groups(k):
     """the pair sort stops one digit early and finishes groups of 256 first ids in LDS: a group far above the LDS
