@@ -18,9 +18,39 @@ def _tree(gpu, ref, what):
     assert gpu.sorted == ref.sorted, what
 
 
-def _scan(gpu, ref, what, rng):
+def _narrow_rows(ref, pool):
+    """one narrow-phase row per id (ids may be shared by objects: the table is simply a function of the id)"""
+    n_ids = int(ref.ids.max()) + 1 if len(ref) else 1
+    return np.ascontiguousarray(pool[np.arange(n_ids) % len(pool)], dtype=np.float32)
+
+
+def _scan(gpu, ref, what, rng, pool=None):
     exp = ref.scan()
-    mode = rng.integers(0, 4)
+    mode = rng.integers(0, 6 if pool is not None else 4)
+    if mode >= 4:   # the narrow phase on the device, inside the scan (a pure function of the two ids: filtering before or after the dedup is the same)
+        dim = pool.shape[1] // 2
+        rows = _narrow_rows(ref, pool)
+        if mode == 4:
+            a, b = rows[exp[:, 0]], rows[exp[:, 1]]
+            keep = np.ones(len(exp), dtype=bool)
+            for ax in range(dim):
+                keep &= ~((a[:, ax] > b[:, dim + ax]) | (a[:, dim + ax] < b[:, ax]))       # geom.rs:112-119
+            got = np.asarray(gpu.scan_filtered_aabb(rows))
+        else:
+            sph = np.ascontiguousarray(np.concatenate([(rows[:, :dim] + rows[:, dim:]) * np.float32(0.5),
+                                                       ((rows[:, dim:] - rows[:, :dim]).max(axis=1) * np.float32(0.5))[:, None]], axis=1), dtype=np.float32)
+            a, b = sph[exp[:, 0]], sph[exp[:, 1]]
+            d2 = None
+            for ax in range(dim):
+                o = (b[:, ax] - a[:, ax]).astype(np.float32)
+                d2 = o * o if d2 is None else (d2 + o * o).astype(np.float32)
+            keep = ~(np.sqrt(d2, dtype=np.float32) > (a[:, dim] + b[:, dim]).astype(np.float32)) if len(exp) else np.zeros(0, dtype=bool)
+            got = np.asarray(gpu.scan_filtered_sphere(sph))
+        exp = exp[keep]
+        got = got.reshape(-1, 2)
+        assert got.shape == exp.shape and np.array_equal(got, exp), what + " (narrow phase %d)" % mode
+        assert gpu.sorted and ref.sorted
+        return
     if mode == 0:
         got = np.array(gpu.scan())
     elif mode == 1:
@@ -92,7 +122,7 @@ def test_random_operation_sequences(seed):
             _tree(g, r, " | ".join(log[-6:]))
         elif op == 5:
             log.append("scan[%d]" % which)
-            _scan(g, r, " | ".join(log[-6:]), rng)
+            _scan(g, r, " | ".join(log[-6:]), rng, bounds)
         elif op == 6:
             g.clear(); r.clear()
             log.append("clear[%d]" % which)
@@ -132,7 +162,7 @@ def test_random_operation_sequences(seed):
         raise AssertionError("%s after: %s" % (e, " | ".join(log))) from e
     for which in range(2):
         g, r = layers[which]
-        _scan(g, r, "final scan[%d] after %s" % (which, " | ".join(log[-8:])), rng)
+        _scan(g, r, "final scan[%d] after %s" % (which, " | ".join(log[-8:])), rng, bounds)
 
 
 def _frame_scene(rng, n, style):
