@@ -1,6 +1,6 @@
 """One RANK of tests/test_gpu_sharded_procs.py, as its own process: the C sharded engine (include/bp_sharded.h) over its RCCL
 binding, with BP_RCCL_LIBRARY pointing at the shared-memory stand-in (tests/cpp/fake_rccl.cpp).  Every rank uses GPU 0.
-   python tests/sharded_proc_worker.py <rank> <world> <uid hex> <out dir> <scene> <n total> <pair order> <frames> [fail_rank]"""
+   python tests/sharded_proc_worker.py <rank> <world> <uid hex> <out dir> <scene> <n total> <pair order> <frames> [fail_rank [id|die]]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ def main():
     rank, world, uid, out_dir, scene, n_total, order, frames = (int(sys.argv[1]), int(sys.argv[2]), bytes.fromhex(sys.argv[3]), sys.argv[4],
                                                                  sys.argv[5], int(sys.argv[6]), sys.argv[7], int(sys.argv[8]))
     fail_rank = int(sys.argv[9]) if len(sys.argv) > 9 else -1
+    fail_mode = sys.argv[10] if len(sys.argv) > 10 else "id"   # "id": an id beyond id_count; "die": the process leaves before the last frame's first collective
     import broadphase_rs_amd as bp
     from broadphase_rs_amd import scenes, sharded
     group = sharded.Group.rccl(rank, world, uid, 0)
@@ -29,6 +30,9 @@ def main():
                     b[0] = [0, 0, 0, L, L, L]
                     b[1] = [0.1 * L * (rank + 1) / world, 0, 0, 0.1 * L * (rank + 1) / world + 0.4 * L, 0.5 * L, 0.45 * L]
                     b[2] = [0.3 * L, 0.3 * L, 0.3 * L, 0.62 * L, 0.62 * L, 0.62 * L]
+            if rank == fail_rank and frame == frames - 1 and fail_mode == "die":
+                open(os.path.join(out_dir, "status_%d.txt" % rank), "w").write("left")
+                os._exit(0)              # no goodbye: its peers find out from their bounded waits
             if rank == fail_rank and frame == frames - 1:
                 ids = ids.copy()
                 ids[5] = n_total + 7     # an id beyond id_count: refused -- on EVERY rank, through the gathered status words

@@ -24,8 +24,8 @@ def build_fake():
     return FAKE
 
 
-def run_world(tmp_path, world, scene, n_total, order, frames=2, fail_rank=-1, chunk_bytes=None, timeout=300):
-    env = dict(os.environ, BP_RCCL_LIBRARY=build_fake(), FAKE_RCCL_BOX_BYTES=str(24 << 20), BP_SHARDED_TIMEOUT_MS="20000", FAKE_RCCL_TIMEOUT_MS="20000")
+def run_world(tmp_path, world, scene, n_total, order, frames=2, fail_rank=-1, chunk_bytes=None, timeout=300, fail_mode="id", wait_ms=20000):
+    env = dict(os.environ, BP_RCCL_LIBRARY=build_fake(), FAKE_RCCL_BOX_BYTES=str(24 << 20), BP_SHARDED_TIMEOUT_MS=str(wait_ms), FAKE_RCCL_TIMEOUT_MS=str(wait_ms))
     if chunk_bytes:
         env["BP_SHARDED_CHUNK_BYTES"] = str(chunk_bytes)
     # the unique id comes from the stand-in as well (any process may ask: no GPU work in it)
@@ -33,7 +33,7 @@ def run_world(tmp_path, world, scene, n_total, order, frames=2, fail_rank=-1, ch
                                    "import sys; sys.path.insert(0, %r); from broadphase_rs_amd import sharded; print(sharded.Group.unique_id().hex())" % ROOT],
                                   env=env).decode().strip()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_proc_worker.py"), str(r), str(world), uid, str(tmp_path), scene,
-                               str(n_total), order, str(frames)] + ([str(fail_rank)] if fail_rank >= 0 else []), env=env)
+                               str(n_total), order, str(frames)] + ([str(fail_rank), fail_mode] if fail_rank >= 0 else []), env=env)
              for r in range(world)]
     rcs = []
     for p in procs:
@@ -83,3 +83,19 @@ def test_an_id_beyond_id_count_on_one_process_is_refused_by_every_process(tmp_pa
     left waiting in an exchange (the workers exit on their own, well inside the timeout)"""
     status = run_world(tmp_path, 3, "uniform", 45000, "global", frames=2, fail_rank=1, timeout=120)
     assert all(s.startswith("error") for s in status), status
+
+
+def test_a_process_that_leaves_is_noticed_by_its_peers_within_the_bounded_wait(tmp_path):
+    """rank 1 of 3 exits without a word before the second frame's first collective: the others must come back from that frame with an
+    error (BP_ERR_COMM through the transport's error or the engine's own bounded wait) instead of waiting for ever -- and exit cleanly"""
+    import time
+    t0 = time.time()
+    status = run_world(tmp_path, 3, "uniform", 45000, "local", frames=2, fail_rank=1, timeout=120, fail_mode="die", wait_ms=4000)
+    assert status[1] == "left"
+    assert status[0].startswith("error") and status[2].startswith("error"), status
+    assert time.time() - t0 < 90
+    # the first frame, which every rank took part in, is complete and correct
+    exp = oracle_pairs(tmp_path, 3, 0)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "out_0_%d.npy" % r)).reshape(-1, 2) for r in range(3)])
+    got = got[np.lexsort((got[:, 1], got[:, 0]))]
+    assert got.shape == exp.shape and np.array_equal(got, exp)
