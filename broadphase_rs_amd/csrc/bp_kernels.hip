@@ -2716,10 +2716,7 @@ __device__ __forceinline__ void sx_hist_flush(const u32* s_hist, const ExpandPar
 // variant, chosen at launch for mixed-scale scenes -- with ranges that leave the LDS windows, the seventh wave per SIMD costs the
 // scan 2.5 % (12.5 M power-law objects: 1.15 against 1.12 ms), on the uniform scene it gains as much)
 #ifndef SX_FILT_WAVES
-#define SX_FILT_WAVES 4  // FILT: the narrow-phase rows of SX_FILT_DEPTH steps in flight at once
-#endif
-#ifndef SX_FILT_DEPTH
-#define SX_FILT_DEPTH 2  // (2, 3, 4 measured equal at 10 M objects -- 0.640, 0.646, 0.663 ms: past two the gathers' throughput is the bound, not their latency)
+#define SX_FILT_WAVES 3  // FILT: the window's rows (12 KB per workgroup in 3-D) and the queue leave LDS for three workgroups per CU (3, 4, 5 measured equal)
 #endif
 #define SX_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FILT ? SX_FILT_WAVES : OCC6 ? 5 : SX_WAVES_PER_EU, FILT ? SX_FILT_WAVES + 1 : OCC6 ? 6 : SX_WAVES_PER_EU)))
 #else
@@ -2756,8 +2753,16 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
     union RecWin { uint4 rec[SX_REC]; u64 win[SX_WIN]; };
     __shared__ RecWin s_recwin[SX_WAVES];
     __shared__ u64 s_cwin[SX_WAVES][SX_WIN];  // {id, context} words of the entries [base, base + SX_WIN)
-    // FILT: the owners' narrow-phase rows beside their records (an owner's row is read once per chunk from HBM, not once per candidate)
-    __shared__ float s_orow[FILT ? SX_WAVES : 1][FILT ? SX_REC : 1][2 * FDIM];
+    // FILT: the narrow-phase rows of the window's entries -- gathered by id ONCE per chunk (128 gathers, a whole chunk ahead of their
+    // use) instead of once per candidate that passes the cell test (~310 per chunk on the uniform scene, + 64 owners): a
+    // candidate's row and its owner's are then LDS reads, like their {id, context} words
+    __shared__ float s_rows[FILT ? SX_WAVES : 1][FILT ? SX_WIN : 1][2 * FDIM];
+    // FILT: the candidates that passed the cell test wait here -- {window slot of the candidate | the owner's << 8} -- until 64 of them
+    // can take the exact test together: a step's two slots pass it to ~29 % of their lanes, and the rows' LDS reads cost the same
+    // whether one lane asks or all of them (the test inside the step put this kernel on the LDS pipe)
+    constexpr u32 SX_QCAP = 192;  // (at most 63 left over + 128 new per step)
+    __shared__ u32 s_q[FILT ? SX_WAVES : 1][FILT ? SX_QCAP : 1];
+    [[maybe_unused]] u32 qn = 0;  // entries waiting (wave-uniform)
     __shared__ u64 s_stage[SX_WAVES][SX_STAGE];
     // the digit counters: as many rows as this launch counts (dynamic LDS, sx_hist_bytes) -- with the two rows of the usual
     // pair sort a workgroup needs 22.6 KB and seven of them share a CU
@@ -2814,6 +2819,33 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
 #endif
     Pre cur_pre{};
     if (base < m) cur_pre = prefetch(base);
+    // FILT: the rows of a chunk's window entries are gathered a whole chunk ahead, like its words -- which therefore run TWO chunks ahead
+    // (the gathers need the ids): nxt_pre = the words of the next chunk, nrow0 / nrow1 = the rows of this one
+    [[maybe_unused]] Pre nxt_pre{};
+    [[maybe_unused]] float nrow0[FILT ? 2 * FDIM : 1], nrow1[FILT ? 2 * FDIM : 1];
+    auto gather_rows = [&](const Pre& pw, u32 b0, float* r0, float* r1) {
+        if constexpr (FILT) {
+            // (a slot behind the tree reads row 0; the id of a real entry is below the table's length: the host checks)
+            const u32 jj = b0 + (u32)lane;
+            const bool v0 = jj < m, v1 = v0 && m - jj > 64u;
+            const u32 fs = filt_stride<FDIM>(p.filt_shape);
+            const float* const r0p = p.filt_bounds + (size_t)(v0 ? (u32)(pw.w0 >> 32) : 0u) * fs;
+            const float* const r1p = p.filt_bounds + (size_t)(v1 ? (u32)(pw.w1 >> 32) : 0u) * fs;
+            if (p.filt_shape == FILT_SPHERE) {  // (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < 2 * FDIM; ++k) { r0[k] = k <= FDIM ? r0p[k] : 0.f; r1[k] = k <= FDIM ? r1p[k] : 0.f; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2 * FDIM; ++k) { r0[k] = r0p[k]; r1[k] = r1p[k]; }
+            }
+        }
+    };
+    if constexpr (FILT) {
+        if (base < m) {
+            gather_rows(cur_pre, base, nrow0, nrow1);  // (the wave's first chunk: its words are waited for here, once)
+            if (m - base > chunk_step) nxt_pre = prefetch(base + chunk_step);
+        }
+    }
     for (bool more = base < m; more; base += chunk_step) {  // wave-uniform (the last increment may wrap: `more` alone decides)
         SX_T(t0);
         const Pre pre = cur_pre;
@@ -2831,9 +2863,21 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             st.template drain<OWNER, true>(p);
             asm volatile("" ::: "memory");
         }
-        if (more) cur_pre = prefetch(base + chunk_step);  // the NEXT chunk's loads fly while this chunk is processed
         const u32 j = base + (u32)lane;
         const bool in0 = j < m;
+        // FILT: this chunk's rows (gathered a chunk ago) go to the LDS window; then the next chunk's rows and the words of the chunk
+        // behind it are requested
+        if constexpr (FILT) {
+#pragma unroll
+            for (int k = 0; k < 2 * FDIM; ++k) { s_rows[w][lane][k] = nrow0[k]; s_rows[w][64 + lane][k] = nrow1[k]; }
+            if (more) {
+                cur_pre = nxt_pre;
+                gather_rows(cur_pre, base + chunk_step, nrow0, nrow1);
+                if (m - base - chunk_step > chunk_step) nxt_pre = prefetch(base + 2u * chunk_step);
+            }
+        } else {
+            if (more) cur_pre = prefetch(base + chunk_step);  // the NEXT chunk's loads fly while this chunk is processed
+        }
         if (PRECNT && m - base < SX_WIN) {  // (wave-uniform, the tree's last chunks) what was loaded from behind the tree: an inert word
             cwin[lane] = in0 ? pre.w0 : (u64)CTX_SKIPPED;
             cwin[64 + lane] = (in0 && m - j > 64u) ? pre.w1 : (u64)CTX_SKIPPED;
@@ -2942,17 +2986,9 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             const u32 n_own = (u32)__popcll(nz);
             if (c > 0)
                 s_rec_w[__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))] =
-                    make_uint4((u32)lane + 1u + c - incl, (u32)(pre.w0 >> 32), ctx_owner_dj(dd, (u32)pre.w0), 0u);
+                    make_uint4((u32)lane + 1u + c - incl, (u32)(pre.w0 >> 32), ctx_owner_dj(dd, (u32)pre.w0), (u32)lane);  // (.w: the owner's slot in the window -- FILT reads its row there)
             if (lane == 0) s_rec_w[n_own] = make_uint4(0u - total, 0u, CTX_DJ_NONE, 0u);
-            if constexpr (FILT) {
-                if (c > 0) {
-                    const u32 fs = filt_stride<FDIM>(p.filt_shape);
-                    const float* const row = p.filt_bounds + (size_t)(u32)(pre.w0 >> 32) * fs;
-                    float* const dst = s_orow[w][__builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u))];
-#pragma unroll
-                    for (int k = 0; k < 2 * FDIM; ++k) dst[k] = (u32)k < fs ? row[k] : 0.f;
-                }
-            }
+            if constexpr (FILT) __builtin_amdgcn_wave_barrier();  // (the rows written at the chunk's top)
         }
         u32 owners_done = 0;  // owners whose range ends before the current step (wave-uniform)
         SX_T(t3);
@@ -2973,39 +3009,61 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
             // One step = 128 candidates, two per lane (slot 0: candidate 128 b + lane, slot 1: + 64): the two lookup chains
             // (owner record -> {id, context} word -> test) are independent, so their LDS latencies overlap, and the
             // per-step bookkeeping is paid once per 128 candidates.
-            // FILT: the steps of a chunk (about three on the uniform scene) are taken SX_FILT_DEPTH at a time -- first every step's
-            // candidates are found and the loads of their narrow-phase rows issued (unconditionally: a dropped lane, and a step beyond
-            // the last, read row 0, so the number of loads in flight is a constant the waits can count), then the steps are finished
-            // in order: exact test against the owner's row (LDS), push.  One exposed memory latency per group instead of per step.
-            // (Tried first: a rolling two-set pipeline across the loop's back edge -- the register allocator copies the loop-carried
-            // rows between sets, a copy is a use, and the wait for it undid the overlap.)
+            // FILT: a candidate that passes the cell test is QUEUED (its window slot and its owner's); whenever 64 wait they take the exact
+            // test together, rows from the LDS window -- a far candidate (the far loop only) is gathered from HBM and tested there and
+            // then.  (Tried before, DESIGN section 9: rows gathered per candidate with the test a step or a group of steps behind its
+            // loads -- bound by the throughput of 87 M random gathers; the test inside the step on LDS rows -- bound by the LDS pipe.)
             auto run_steps = [&](auto far_tag, auto nf_tag) {
                 constexpr bool FAR = decltype(far_tag)::value;
                 constexpr int NF = decltype(nf_tag)::value;  // floats per narrow-phase row (0: not FILT)
-                struct Pend { float a0[NF ? NF : 1], a1[NF ? NF : 1]; u32 c0, c1, oo; bool k0, k1; };  // oo: the owners' record numbers, 16 bits each
-                auto retire = [&](Pend& R) {
-                    if constexpr (NF != 0) {
+                // a far candidate (the far loop only): its row is gathered from HBM there and then
+                [[maybe_unused]] auto narrow_far = [&](bool k, u32 cand_id, u32 own_slot) -> bool {
+                    if constexpr (NF == 0) return k;
+                    else {
+                        bool r = false;
+                        if (k) {
+                            const float* const ow = &s_rows[FILT ? w : 0][own_slot][0];
+                            const float* const g = p.filt_bounds + (size_t)cand_id * NF;
+                            float a[NF], o[NF];
 #pragma unroll
-                        for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(R.a0[k]), "+v"(R.a1[k]));
-                        const float* const ow = &s_orow[FILT ? w : 0][0][0];
-                        const u32 o0 = R.oo & 0xFFFFu, o1 = R.oo >> 16;
-                        float b0[NF], b1[NF];
-#pragma unroll
-                        for (int k = 0; k < NF; ++k) { b0[k] = ow[o0 * (2 * FDIM) + k]; b1[k] = ow[o1 * (2 * FDIM) + k]; }
-                        const u32 id0 = s_rec_w[o0].y, id1 = s_rec_w[o1].y;
-                        bool k0 = R.k0, k1 = R.k1;
-                        if constexpr (NF == FDIM + 1) { k0 = k0 & spheres_touch<FDIM>(R.a0, b0); k1 = k1 & spheres_touch<FDIM>(R.a1, b1); }
-                        else {  // boxes_overlap without its early outs: (NaN compares false, so NaN overlaps -- src/geom.rs:112-119)
-#pragma unroll
-                            for (int ax = 0; ax < FDIM; ++ax) {
-                                k0 = k0 & !(R.a0[ax] > b0[FDIM + ax]) & !(R.a0[FDIM + ax] < b0[ax]);
-                                k1 = k1 & !(R.a1[ax] > b1[FDIM + ax]) & !(R.a1[FDIM + ax] < b1[ax]);
-                            }
+                            for (int q = 0; q < NF; ++q) { a[q] = g[q]; o[q] = ow[q]; }
+                            if constexpr (NF == FDIM + 1) r = spheres_touch<FDIM>(a, o);
+                            else r = boxes_overlap<FDIM>(a, o);
                         }
-                        st.template push2<OWNER>(ballot64(k0), k0, id0, R.c0, ballot64(k1), k1, id1, R.c1, p);
+                        return r;
                     }
                 };
-                auto one = [&](u32 b, Pend& cur) {
+                // the last `cnt` (<= 64) queue entries take the exact test, one per lane; what passes goes to the stage
+                [[maybe_unused]] auto qpop = [&](u32 cnt) {
+                    if constexpr (NF != 0) {
+                        const u32* const qq = s_q[FILT ? w : 0];
+                        qn -= cnt;
+                        const bool on = (u32)lane < cnt;
+                        const u32 e = on ? qq[qn + (u32)lane] : 0u;
+                        const u32 cs = e & 0xFFu, os = e >> 8;
+                        const float* const cw = &s_rows[FILT ? w : 0][cs][0];
+                        const float* const ow = &s_rows[FILT ? w : 0][os][0];
+                        float a[NF], o[NF];
+#pragma unroll
+                        for (int q = 0; q < NF; ++q) { a[q] = cw[q]; o[q] = ow[q]; }
+                        const u32 cid = (u32)(cwin[cs] >> 32), oid = (u32)(cwin[os] >> 32);
+                        bool r = on;
+                        if constexpr (NF == FDIM + 1) r = r & spheres_touch<FDIM>(a, o);
+                        else {  // boxes_overlap without its early outs (NaN compares false, so NaN overlaps: src/geom.rs:112-119)
+#pragma unroll
+                            for (int ax = 0; ax < FDIM; ++ax) r = r & !(a[ax] > o[FDIM + ax]) & !(a[FDIM + ax] < o[ax]);
+                        }
+                        st.template push2<OWNER>(ballot64(r), r, oid, cid, 0ull, false, 0u, 0u, p);
+                    }
+                };
+                [[maybe_unused]] auto qpush = [&](bool k, u32 val) {
+                    if constexpr (NF != 0) {
+                        const u64 mk = ballot64(k);
+                        if (k) s_q[FILT ? w : 0][qn + __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u))] = val;
+                        qn += (u32)__popcll(mk);
+                    }
+                };
+                auto one = [&](u32 b) {
                     const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b)) << 32) |
                                    (u64)(u32)__builtin_amdgcn_readlane((int)ends_lo, (int)(2u * b));
                     const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ends_hi, (int)(2u * b + 1u)) << 32) |
@@ -3015,12 +3073,9 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     const uint4* const rb0 = s_rec_w + owners_done;
                     const u32 n0 = (u32)__popcll(e0);
                     const uint4* const rb1 = rb0 + n0;
-                    [[maybe_unused]] const u32 owners_before = owners_done;
                     owners_done += n0 + (u32)__popcll(e1);
-                    const u32 oi0 = __builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u));
-                    const u32 oi1 = __builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u));
-                    const uint4 r0 = rb0[oi0];
-                    const uint4 r1 = rb1[oi1];
+                    const uint4 r0 = rb0[__builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u))];
+                    const uint4 r1 = rb1[__builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u))];
                     asm volatile("" : : "v"(r0.w), "v"(r1.w));  // (all four dwords: ds_read_b128 takes 4 LDS cycles, the ds_read_b96 of three takes 8)
                     const u32 off0 = kl + r0.x, off1 = kl + 64u + r1.x;   // candidate = entry base + off
                     const bool act0 = GEN == 1 && kl < total, act1 = GEN == 1 && kl + 64u < total;  // (only the marking pass asks)
@@ -3069,8 +3124,16 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                         keep1 = keep1 && !(w1lo & CTX_SKIPPED);
                     }
                     if constexpr (NF != 0) {
-                        cur.k0 = keep0; cur.k1 = keep1; cur.c0 = w0hi; cur.c1 = w1hi;
-                        cur.oo = (owners_before + oi0) | ((owners_before + n0 + oi1) << 16);
+                        bool far0 = false, far1 = false;
+                        if constexpr (FAR) { far0 = off0 >= SX_WIN; far1 = off1 >= SX_WIN; }
+                        qpush(keep0 & !far0, off0 | (r0.w << 8));
+                        qpush(keep1 & !far1, off1 | (r1.w << 8));
+                        while (qn >= 64u) qpop(64u);  // (wave-uniform)
+                        if constexpr (FAR) {
+                            keep0 = narrow_far(keep0 & far0, w0hi, r0.w);
+                            keep1 = narrow_far(keep1 & far1, w1hi, r1.w);
+                            if (__any(keep0 | keep1)) st.template push2<OWNER>(ballot64(keep0), keep0, r0.y, w0hi, ballot64(keep1), keep1, r1.y, w1hi, p);
+                        }
                         SX_ACC(6, 1);
                         return;
                     }
@@ -3080,26 +3143,9 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                     SX_ACC(4, tp1 - tp0);
                     SX_ACC(6, 1);
                 };
-                if constexpr (NF == 0) {
-                    Pend none{};
-                    for (u32 b = 0; b < n_steps; ++b) one(b, none);
-                } else {
-                    for (u32 b = 0; b < n_steps; b += SX_FILT_DEPTH) {
-                        Pend P[SX_FILT_DEPTH];
-#pragma unroll
-                        for (int q = 0; q < SX_FILT_DEPTH; ++q) {
-                            Pend& cur = P[q];
-                            cur.k0 = cur.k1 = false; cur.c0 = cur.c1 = 0u; cur.oo = 0u;
-                            if (b + (u32)q < n_steps) one(b + (u32)q, cur);  // (wave-uniform)
-                            const float* const a0 = p.filt_bounds + (size_t)(cur.k0 ? cur.c0 : 0u) * NF;
-                            const float* const a1 = p.filt_bounds + (size_t)(cur.k1 ? cur.c1 : 0u) * NF;
-#pragma unroll
-                            for (int k = 0; k < NF; ++k) { cur.a0[k] = a0[k]; cur.a1[k] = a1[k]; }
-                        }
-#pragma unroll
-                        for (int q = 0; q < SX_FILT_DEPTH; ++q)
-                            if (b + (u32)q < n_steps) retire(P[q]);
-                    }
+                for (u32 b = 0; b < n_steps; ++b) one(b);
+                if constexpr (NF != 0) {  // (the window these entries point into is overwritten at the next chunk's top)
+                    if (qn) qpop(qn);
                 }
             };
             if (SX_EXP & 8) continue;
