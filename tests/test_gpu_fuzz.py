@@ -216,3 +216,13 @@ def test_random_frame_sequences_on_one_layer(seed):
         if rng.random() < 0.3:                                          # a second scan of the same tree (cached context words)
             got = np.array(gpu.scan())
             assert got.shape == exp.shape and np.array_equal(got, exp), "rescan, frames " + " ".join(log)
+        if rng.random() < 0.5:                                          # ... and one with the narrow phase on the device (rows per id)
+            n_ids = int(ids.max()) + 1
+            rows = np.zeros((n_ids, 6), dtype=np.float32)
+            rows[ids] = bounds                                          # (repeated ids: the last object's box -- any table is a valid predicate)
+            a, b = rows[exp[:, 0]], rows[exp[:, 1]]
+            keep = np.ones(len(exp), dtype=bool)
+            for ax in range(3):
+                keep &= ~((a[:, ax] > b[:, 3 + ax]) | (a[:, 3 + ax] < b[:, ax]))       # geom.rs:112-119
+            got = np.asarray(gpu.scan_filtered_aabb(rows)).reshape(-1, 2)
+            assert got.shape == exp[keep].shape and np.array_equal(got, exp[keep]), "narrow phase, frames " + " ".join(log)
