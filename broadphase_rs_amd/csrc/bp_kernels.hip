@@ -3723,10 +3723,18 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
     __shared__ u32 s_ws[TGRP_THREADS / 64];
     __shared__ u32 s_lut[CTX_KIND >= 0 ? CTX_LUT_WORDS : 1];
     static_assert(sizeof(Aux) >= TGRP_CAP * sizeof(u32), "payload view must fit");
-    if constexpr (CTX_KIND >= 0)
-        for (int q = (int)threadIdx.x; q < CTX_LUT_WORDS; q += TGRP_THREADS) s_lut[q] = g_ctx_lut.e[q];  // visible after the barriers below
     const u32 g = blockIdx.x, tid = threadIdx.x;
-    if (stats && stats[1] > abort_over) {
+    // (every load of the prologue is requested before the first is used -- the context table, the abort statistic, the group's source
+    // word: a workgroup lives a few microseconds, and each dependent round trip at its start is most of one)
+    constexpr int LUT_ITERS = CTX_KIND >= 0 ? (CTX_LUT_WORDS + TGRP_THREADS - 1) / TGRP_THREADS : 1;
+    u32 lutv[LUT_ITERS];
+#pragma unroll
+    for (int q = 0; q < LUT_ITERS; ++q) lutv[q] = (CTX_KIND >= 0 && (u32)q * TGRP_THREADS + tid < (u32)CTX_LUT_WORDS) ? g_ctx_lut.e[(u32)q * TGRP_THREADS + tid] : 0u;
+    uint4 si = make_uint4(0u, 0u, 0u, 0u);
+    if (GAPPED) si = cell_src[g];
+    const u32 over_stat = stats ? stats[1] : 0u;
+    if (GAPPED) asm volatile("" : "+s"(si.x), "+s"(si.y), "+s"(si.z), "+s"(si.w));
+    if (over_stat > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
@@ -3734,7 +3742,6 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
     // goes in the dense output and how long it is (launch_cell_count; group_finish_kernel reads the same word)
     u32 lo, ng, src_a, src_nf, src_b = 0;
     if (GAPPED) {
-        const uint4 si = cell_src[g];
         src_a = si.x; src_b = si.y; lo = si.z; ng = si.w >> 16; src_nf = si.w & 0xFFFFu;
     } else {
         lo = bounds[g];
@@ -3758,6 +3765,13 @@ __global__ __launch_bounds__(TGRP_THREADS) void tgroup_finish2_kernel(const u64*
         const u32 x = (u32)i * TGRP_THREADS + tid;
         k[i] = x < ng ? keys_in[src(x)] : 0ull;
         p[i] = x < ng ? ids_in[src(x)] : 0u;
+    }
+    if constexpr (CTX_KIND >= 0) {  // the table's LDS copy (visible after the barriers below)
+#pragma unroll
+        for (int q = 0; q < LUT_ITERS; ++q) {
+            asm volatile("" : "+v"(lutv[q]));
+            if ((u32)q * TGRP_THREADS + tid < (u32)CTX_LUT_WORDS) s_lut[(u32)q * TGRP_THREADS + tid] = lutv[q];
+        }
     }
     __syncthreads();
     u32 slot[TGRP_ITEMS];  // arrival ticket inside the bin, then the scatter slot, then the final position
@@ -3933,11 +3947,15 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
     static_assert((size_t)TGC_CAP * 8 >= (size_t)TG2_BINS * 4, "the counters fit the words' storage");
     static_assert((size_t)(TGC_CAP + 2) * 8 + (TG2_BINS + 4) * 4 + CTX_LUT_WORDS * 4 + 64 + CompactLut3<XDIM>::WORDS * 4 <= 163840 / 7, "tgroup_finishc: seven workgroups per CU");
     const u32 g = blockIdx.x, tid = threadIdx.x;
-    if (stats && stats[1] > abort_over) {
+    // (the group's source word and the abort statistic are requested TOGETHER: a workgroup lives ~6 us, and every dependent load at
+    // its start is most of a microsecond in which it holds its LDS and does nothing)
+    uint4 si = cell_src[g];
+    const u32 over_stat = stats ? stats[1] : 0u;
+    asm volatile("" : "+s"(si.x), "+s"(si.y), "+s"(si.z), "+s"(si.w));  // (else the source word's load sinks below the abort test: one more round trip)
+    if (over_stat > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
-    const uint4 si = cell_src[g];
     const u32 src_a = si.x, src_b = si.y, lo = si.z, ng = si.w >> 16, src_nf = si.w & 0xFFFFu;
     if (ng == 0) return;  // workgroup-uniform
     if (ng > (u32)TGC_CAP) {
@@ -3946,22 +3964,38 @@ __global__ __launch_bounds__(TGRP_THREADS) __attribute__((amdgpu_waves_per_eu(TG
     }
     const int bshift = gshift - TG2_BIN_BITS;  // the host guarantees bshift >= 0
     reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    // the write-out's tables (their own storage; visible after the barriers below)
-    if (tid < (u32)CTX_LUT_WORDS) s_lut[tid] = g_ctx_lut.e[tid];
-    if (tid < 16u) {
-        u32 pw = 1u;
-        for (u32 k = 0; k < tid; ++k) pw *= XBASE;  // (wraps beyond what a 32-bit tail holds: never indexed there)
-        s_pw[tid] = pw;
-    }
-    {
-        const u32* src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
-        for (u32 q = tid; q < CompactLut3<XDIM>::WORDS; q += TGRP_THREADS) reinterpret_cast<u32*>(s_lut3)[q] = src3[q];
+    // Every load of the prologue is issued before the first is used -- the write-out's tables (constant memory behind the L2) and the
+    // group's words: left in source order, each table's LDS store waited for its load in front of the next one's issue, and a
+    // workgroup that lives ~6 us spent three more round trips at its start
+    constexpr u32 L3_ITERS = (CompactLut3<XDIM>::WORDS + TGRP_THREADS - 1) / TGRP_THREADS;
+    const u32* const src3 = reinterpret_cast<const u32*>(XDIM == 3 ? (const void*)g_compact_lut3_3d.e : (const void*)g_compact_lut3_2d.e);
+    u32 lutv = 0, l3v[L3_ITERS];
+    if (tid < (u32)CTX_LUT_WORDS) lutv = g_ctx_lut.e[tid];
+#pragma unroll
+    for (u32 k = 0; k < L3_ITERS; ++k) {
+        const u32 q = k * TGRP_THREADS + tid;
+        l3v[k] = q < CompactLut3<XDIM>::WORDS ? src3[q] : 0u;
     }
     u64 c[TGRP_ITEMS];
 #pragma unroll
     for (int i = 0; i < TGRP_ITEMS; ++i) {
         const u32 x = (u32)i * TGRP_THREADS + tid;
         c[i] = x < ng ? words_in[x < src_nf ? (size_t)src_a + x : (size_t)src_b + (x - src_nf)] : 0ull;
+    }
+    asm volatile("" : "+v"(lutv));
+#pragma unroll
+    for (u32 k = 0; k < L3_ITERS; ++k) asm volatile("" : "+v"(l3v[k]));
+    // the tables' LDS copies (their own storage; visible after the barriers below)
+    if (tid < (u32)CTX_LUT_WORDS) s_lut[tid] = lutv;
+    if (tid < 16u) {
+        u32 pw = 1u;
+        for (u32 k = 0; k < tid; ++k) pw *= XBASE;  // (wraps beyond what a 32-bit tail holds: never indexed there)
+        s_pw[tid] = pw;
+    }
+#pragma unroll
+    for (u32 k = 0; k < L3_ITERS; ++k) {
+        const u32 q = k * TGRP_THREADS + tid;
+        if (q < CompactLut3<XDIM>::WORDS) reinterpret_cast<u32*>(s_lut3)[q] = l3v[k];
     }
     __syncthreads();
     u32 slot[TGRP_ITEMS];  // arrival ticket inside the bin, then the scatter slot, then the final position
@@ -5414,7 +5448,7 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
                                                                    int gbits, u32 sub_scale, uint2* __restrict__ out, DevScalars* sc,
                                                                    const u32* __restrict__ stats, u32 abort_over,
                                                                    const u32* __restrict__ dev_sizes, CellRoute cells) {
-    if (dev_sizes) abort_over = dev_sizes[SIZES_N] / 4u;
+    u32 dev_n = dev_sizes ? dev_sizes[SIZES_N] : 0u;  // (requested together with the two loads below: see there)
     // bins of the fast path: id within the group x GRP_SUB equal ranges of the second id (second * sub_scale >> 32, clamped):
     // about one pair per bin -- the rank loops are what this kernel spends its instructions on (their cost is quadratic in the
     // bin length, and a wave runs to the longest bin of its 64 lanes)
@@ -5428,16 +5462,21 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
     const u32 g = blockIdx.x, tid = threadIdx.x;
     // most pairs sit in oversize groups (ids that follow the scene's clusters): rounds over every such group would cost far
     // more than the full-width sort the host runs when it sees this flag
-    if (stats && stats[1] > abort_over) {
+    // where record x of the group is read: `in` dense (the group is in[lo .. hi)), or the gapped result of a cell sort (the
+    // cell's whole lines from its start, then what was claimed downwards from its end: ONE 16-byte word per group, written by
+    // launch_cell_count, instead of the two bounds -- a second, dependent load would add a memory latency to every workgroup;
+    // requested together with the abort statistic for the same reason)
+    uint4 si = make_uint4(0u, 0u, 0u, 0u);
+    if (GAPPED) si = cells.src[g];
+    const u32 over_stat = stats ? stats[1] : 0u;
+    if (GAPPED) asm volatile("" : "+s"(si.x), "+s"(si.y), "+s"(si.z), "+s"(si.w), "+s"(dev_n));  // (else the loads sink below the abort test, one round trip each)
+    if (dev_sizes) abort_over = dev_n / 4u;
+    if (over_stat > abort_over) {
         if (g == 0 && tid == 0) atomicOr(&sc->err, (u32)KERR_SEGMENT_TOO_LONG);
         return;
     }
-    // where record x of the group is read: `in` dense (the group is in[lo .. hi)), or the gapped result of a cell sort (the
-    // cell's whole lines from its start, then what was claimed downwards from its end: ONE 16-byte word per group, written by
-    // launch_cell_count, instead of the two bounds -- a second, dependent load would add a memory latency to every workgroup)
     u32 lo, ng, src_a, src_nf, src_b = 0;
     if (GAPPED) {
-        const uint4 si = cells.src[g];
         src_a = si.x; src_b = si.y; lo = si.z; ng = si.w >> 16; src_nf = si.w & 0xFFFFu;
     } else {
         lo = bounds[g];
