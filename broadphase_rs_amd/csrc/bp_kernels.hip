@@ -4324,22 +4324,25 @@ __device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Val
     __shared__ u32 s_ws[CELL_THREADS / 64];
     __shared__ u64 s_before;
     const u32 t = threadIdx.x, b = blockIdx.x;
+    // (a thread takes FOUR CONSECUTIVE cells: one block scan of the threads' sums instead of one per row of cells -- each is two
+    // barriers in a kernel that is nothing but a chain of latencies)
     uint4 raw[CELL_PER_THREAD];
-    u32 v[CELL_PER_THREAD], ex[CELL_PER_THREAD], row[CELL_PER_THREAD];
+    u32 v[CELL_PER_THREAD], ex[CELL_PER_THREAD];
+    const u32 c0 = b * 1024u + t * (u32)CELL_PER_THREAD;
 #pragma unroll
-    for (int k = 0; k < CELL_PER_THREAD; ++k) raw[k] = load(b * 1024u + (u32)k * CELL_THREADS + t);
+    for (int k = 0; k < CELL_PER_THREAD; ++k) raw[k] = load(c0 + (u32)k);
     __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler pairs every cell's loads with their use: a wait per cell)
+    u32 tsum = 0;
 #pragma unroll
-    for (int k = 0; k < CELL_PER_THREAD; ++k) v[k] = value(b * 1024u + (u32)k * CELL_THREADS + t, raw[k]);
-    u32 wg_total = 0;
-#pragma unroll
-    for (int k = 0; k < CELL_PER_THREAD; ++k) {  // cell order inside the workgroup: row k, then thread
-        u32 tot;
-        ex[k] = block_excl_scan_u32<CELL_THREADS>(v[k], s_ws, tot);
-        row[k] = wg_total;
-        wg_total += tot;
-        __syncthreads();
+    for (int k = 0; k < CELL_PER_THREAD; ++k) {
+        v[k] = value(c0 + (u32)k, raw[k]);
+        ex[k] = tsum;
+        tsum += v[k];
     }
+    u32 wg_total = 0;
+    const u32 tex = block_excl_scan_u32<CELL_THREADS>(tsum, s_ws, wg_total);
+#pragma unroll
+    for (int k = 0; k < CELL_PER_THREAD; ++k) ex[k] += tex;
     if (t == 0u) __hip_atomic_store(&status[b], ((u64)tag << 40) | (u64)wg_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < 64u) {  // wave 0: the sums of the workgroups before this one
         u64 mine = 0;
@@ -4359,7 +4362,7 @@ __device__ __forceinline__ u64 cells_walk(u64* status, u32 tag, Load&& load, Val
     __syncthreads();
     const u64 before = s_before;
 #pragma unroll
-    for (int k = 0; k < CELL_PER_THREAD; ++k) emit(b * 1024u + (u32)k * CELL_THREADS + t, (u32)before + row[k] + ex[k], v[k], raw[k]);
+    for (int k = 0; k < CELL_PER_THREAD; ++k) emit(c0 + (u32)k, (u32)before + ex[k], v[k], raw[k]);
     return before + wg_total;  // (the last workgroup: the grand total)
 }
 __device__ __forceinline__ void cell_layout_body(const u32* __restrict__ prev_bounds, u32 prev_g0, u32 prev_groups,
