@@ -2172,9 +2172,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_fused_kernel(ScanParams p, 
 // The ancestor (owner) side supplies ONE word: DJ byte a = 0xE0 | (t_a(j) == 2 ? 0 : dd).  Then t = DJ - ctx has no borrow between bytes
 // (0xE0 >= 0xBF, the largest context byte), the code bits and 0xC0 of DJ cancel out of bit 5, and bit 5 of byte a  <=>  dd' >= G_a:
 // keep  <=>  (t & 0x202020) == 0x202020.  A skipped / inactive entry (byte 0 = 0x20 | code) always fails: 0xE0 + dd' - 0x20 has bit 5 clear.
-// a * b for operands below 2^24 as ONE full-rate instruction.  (__umul24 is not enough: where LLVM can prove the operands small it
-// rewrites the intrinsic into a plain multiply, and where it then loses that proof -- behind a select, a loop -- instruction
-// selection emits v_mul_lo_u32, a quarter-rate instruction: four issue slots in kernels that are bound by them)
+// a * K for a below 2^24 as ONE instruction with the constant as an immediate.  (What this saves is instructions, not issue slots:
+// tools/micro/alu_rate.hip measures v_mul_lo_u32, v_mul_hi_u32 and the 64-bit shifts at the same 4.2 cycles per wave instruction
+// as a 32-bit shift on gfx950 -- none of them is a reduced-rate instruction on this part, as rounds 4 - 5 first assumed; the
+// gains booked to "24-bit multiplies" came from the shorter sequences: no constant in a register, no fix-ups of a division.)
 template <u32 K> __device__ __forceinline__ u32 mul24k(u32 a) {  // a * K, K a compile-time constant below 2^24 (an immediate, no register)
     static_assert(K < (1u << 24), "24-bit constant");
     u32 r;
@@ -2191,7 +2192,7 @@ __host__ __device__ constexpr u32 ctx_codebits(u32 c27) {  // c27 = t_x + 3 t_y 
 }
 // G bytes from the per-axis trailing-zero counts f_a of the cell's coordinates: (depth - f_a) on the axes whose code is 2
 __device__ __forceinline__ u32 ctx_g_bytes(u32 codebits, u32 d, u32 f0, u32 f1, u32 f2) {
-    // (24-bit multiplies, said explicitly: a 32-bit v_mul_lo_u32 is a quarter-rate instruction -- four issue slots -- on this part)
+    // (24-bit multiplies with immediate constants: one instruction each)
     const u32 up = mul24k<0x1Fu>((codebits >> 7) & 0x010101u);            // 0x1F in the bytes of the upper-of-two axes
     return (mul24k<0x010101u>(d) - (f0 | (f1 << 8) | (f2 << 16))) & up;    // (f_a <= d < 32: no borrow)
 }
@@ -3869,7 +3870,7 @@ template <int KIND, int NSTEP = 0> __device__ __forceinline__ void tree_expand(u
     } else if constexpr (NSTEP == 2) {
         // t < BASE^6 (531441 in 3-D, 15625 in 2-D): the quotient by BASE^3 from ONE full-rate 24-bit multiply -- ceil(2^32 / 729) has 23
         // bits and errs by less than 1 / 729 below 2^20; ceil(2^24 / 125) by less than 1 / 125 below 2^14 (a 32-bit division by a
-        // constant is a quarter-rate v_mul_hi_u32 plus fix-ups)
+        // constant is a v_mul_hi_u32 plus shifts and fix-ups: four to six instructions)
         const u32 q = DIM == 3 ? (u32)(((u64)(t & 0xFFFFFu) * 5891589ull) >> 32) : (mul24k<134218u>(t & 0x3FFFu) >> 24);
         const u32 e0 = lut3[t - mul24k<N3>(q)], e1 = lut3[q];
         mort = (e0 & 0xFFFu) | ((e1 & 0xFFFu) << (3 * DIM));
@@ -5543,8 +5544,8 @@ __global__ __launch_bounds__(GRP_THREADS) void group_finish_kernel(const u64* __
         }
         return;
     }
-    // (sub_scale below 2^24 says that the second ids are too: the 24-bit multiply is a full-rate instruction, the 32-bit
-    // v_mul_hi_u32 takes four issue slots -- eight of them per thread were 6 % of this kernel's instruction issue)
+    // (sub_scale below 2^24 says that the second ids are too: one v_mul_hi_u32_u24 instead of v_mul_hi_u32 + the shift that undoes
+    // the halved scale)
     const bool sub24 = (sub_scale >> 31) != 0u;  // (the launcher's flag, in the top bit of the scale's word: see there)
     const u32 sub_mul = sub_scale & 0x7FFFFFFFu;
     auto bin_of = [&](u64 v) {
