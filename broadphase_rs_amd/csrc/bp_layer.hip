@@ -2366,9 +2366,32 @@ int bp_layer_stream(const bp_layer_t* L, void** stream) {
     return BP_OK;
 }
 
+// A deferred tree sort whose tree is being dropped (clear): its result needs no check and no repair -- but what its scalars say about
+// the NEXT sort's plan (do the groups fit the LDS finish? did the cells hold?) is exactly what a frame loop without a scan between its
+// sorts would otherwise never learn: it stayed on a layer's first, optimistic plan for ever (one host round trip here instead;
+// a loop that scans has settled the sort on the scan's round trip and does not come through here)
+static void learn_from_dropped_sort(bp_layer* L) {
+    if (!L->sort_pend.on) return;
+    DeviceGuard g(L->device);
+    const bool got = sort_sc_fetch(L) == BP_OK && sync_stream(L) == BP_OK && L->sort_pend.copied;
+    L->sort_pend.on = false;
+    if (!got) return;  // (best effort: the hints stay what they were)
+    const DevScalars sc = *(const DevScalars*)L->h_sort_sc.p;
+    const bool tgrp_before = L->tgrp_ok;
+    const bool fits = sc.grp_max <= (uint32_t)tgroup_capacity();
+    L->tgrp_known = true;
+    L->tgrp_ok = fits;
+    if (sc.err & KERR_SEGMENT_TOO_LONG) {
+        if (!(L->sort_pend.cells && fits)) L->tgrp_ok = false;
+        if (L->sort_pend.cells) L->tcell_off = 16;
+        L->tcell.valid = false;
+    }
+    if ((sc.err & KERR_SEGMENT_TOO_LONG) || L->tgrp_ok != tgrp_before) ++L->stats.tree_plan_flips;
+}
+
 int bp_layer_clear(bp_layer_t* L) {
     if (!L) return BP_ERR_INVALID_ARG;
-    L->sort_pend.on = false;  // a sort whose result is dropped needs no check (its kernels stay ordered on the stream)
+    learn_from_dropped_sort(L);  // (its kernels stay ordered on the stream either way)
     L->tree_hist_valid = false; L->cell_hist_valid = false; L->cell_dev_valid = false;
     L->tail_run = false;
     ++L->prof_frame;

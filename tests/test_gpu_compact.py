@@ -335,3 +335,35 @@ def test_a_compact_sort_that_fails_its_deferred_check_is_repaired(monkeypatch):
     assert before["tree_sorts_compact"] >= 1 and before["sort_repairs"] == 0, {k: before[k] for k in keys}
     # the bunched frame's sort was a compact one (the extend before it wrote composite words) and its check failed
     assert st["sort_repairs"] >= before["sort_repairs"] + 1 and st["tree_expands"] >= before["tree_expands"] + 1, ({k: before[k] for k in keys}, {k: st[k] for k in keys})
+
+
+def test_a_frame_loop_without_scans_still_learns_its_sort_plan(monkeypatch):
+    """clear + extend + par_sort, frame after frame, with nothing that reads the tree's order in between: the deferred check of a sort
+    whose tree is dropped is not needed -- but what it says about the next sort's plan is, or the loop stays on a layer's first plan
+    for ever (`clear` fetches the dropped sort's scalars).  The trees must equal the oracle's whichever plan sorted them, and a frame
+    whose groups outgrow the LDS finish (a tight cluster) must switch the grouped plan off again for the frames behind it."""
+    monkeypatch.setenv("BP_RADIX_CLAIM_MIN_TILES", "1")
+    kind, n = 2, 200000
+    sysb, base, ids = base_scene(kind, n, seed=11)
+    gpu = bp.Layer(KINDS[kind], 0)
+    for f in range(5):
+        b = moved(kind, sysb, base, f)
+        gpu.clear(); gpu.extend(sysb, b, ids); gpu.par_sort()
+    st = gpu.stats()
+    assert st["tree_sorts_compact"] >= 2 and st["tree_sorts_in_cells"] >= 2, {k: st[k] for k in ("tree_sorts_compact", "tree_sorts_in_cells", "tree_plan_flips")}
+    ref = oracle.OracleLayer(kind, 0)
+    ref.extend(sysb, moved(kind, sysb, base, 4), ids); ref.sort()
+    check_tree(gpu, ref, "the last frame of a loop without scans")
+    # a frame that does not fit the grouped finish: dropped unseen, learned from all the same
+    L = float(sysb[1][0])
+    tight = base.copy()
+    k = n // 2
+    lo = (np.float32(0.4) * L + np.random.default_rng(5).uniform(0, 0.0008 * L, size=(k, 3))).astype(np.float32)
+    tight[:k] = np.concatenate([lo, lo + (base[:k, 3:] - base[:k, :3]) * np.float32(0.02)], axis=1).astype(np.float32)
+    flips = gpu.stats()["tree_plan_flips"]
+    gpu.clear(); gpu.extend(sysb, tight, ids); gpu.par_sort()
+    gpu.clear(); gpu.extend(sysb, tight, ids); gpu.par_sort()
+    ref2 = oracle.OracleLayer(kind, 0)
+    ref2.extend(sysb, tight, ids); ref2.sort()
+    check_tree(gpu, ref2, "a clustered frame behind one whose failed sort was dropped by clear")
+    assert gpu.stats()["tree_plan_flips"] > flips
