@@ -2293,6 +2293,9 @@ int bp_layer_create(bp_layer_t** out, int index_kind, uint32_t min_depth, size_t
         want(L->big_list, std::max<size_t>(65536, m / 16) * 2 * sizeof(uint64_t));
         want(L->pairs[0], raw_slots * sizeof(uint64_t));
         want(L->pairs[1], (pc + pc / 8 + 4096) * sizeof(uint64_t));
+        want(L->out_pairs, (pc + pc / 8 + 4096) * 2 * sizeof(uint32_t));  // (the finish asks for the margin the NEXT frame's sort ahead will want)
+        want(L->grp_bounds, ((size_t)CELL_COUNT + 2) * sizeof(uint32_t));
+        want(L->tgrp_bounds, ((size_t)CELL_COUNT + 2) * sizeof(uint32_t));
         want(L->blockfill, (raw_slots / SX_BLOCK + 1) * sizeof(uint32_t));
         want(L->pair_hist, PAIR_HIST_WORDS * sizeof(unsigned long long));
         want(L->tree_hist, (size_t)HIST_COPIES * SX_HIST_MAX * RS_BINS * sizeof(unsigned long long));

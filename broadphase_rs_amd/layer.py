@@ -352,7 +352,9 @@ class Layer:
         self._check(self._L.bp_layer_clear(self._h))
 
     def extend(self, system_bounds, bounds, ids):
-        """src/layer.rs:94-121.  bounds: (n, 2*dim) f32 rows [min.., max..]; ids: (n,) u32."""
+        """src/layer.rs:94-121.  bounds: (n, 2*dim) f32 rows [min.., max..]; ids: (n,) u32.
+        CUDA torch tensors are read in place on the layer's stream (ordered behind torch's current stream): do not write to them
+        again before the next call on this layer that returns a result (include/bp_layer.h, STREAM ORDERING)."""
         dim = self.index.dim
         # (the per-frame call: the two corner points go straight into C float arrays; numpy's conversion chain took 5 us)
         fvec = C.c_float * dim

@@ -14,7 +14,12 @@
  *   - STREAM ORDERING: the handle's stream is non-blocking (it does not synchronise with the legacy default
  *     stream).  Results are complete on return, so any stream may read them afterwards.  DEVICE INPUTS,
  *     however, are read on the handle's stream: if kernels that write them may still be in flight on another
- *     stream, call bp_layer_wait_stream(layer, that_stream) first (or synchronise that stream);
+ *     stream, call bp_layer_wait_stream(layer, that_stream) first (or synchronise that stream) -- and they may
+ *     STILL BE BEING READ when bp_layer_extend_device returns (in the per-frame pattern the call returns as soon
+ *     as the frame's entry count is known, with the pass that writes the entries still running behind it): do not
+ *     overwrite or free them before the next call on the handle that returns a result (a scan, bp_layer_tree*,
+ *     a query), or order the writer behind bp_layer_stream().  Host inputs (bp_layer_extend_host, and
+ *     bp_layer_extend with host pointers) are copied before the call returns and are the caller's again at once;
  *   - returned pointers are BORROWED: valid until the next mutating call on the same handle
  *     (the reference returns `&'a Vec<(ID, ID)>` tied to `&'a mut self`, src/layer.rs:449-451);
  *   - ID is u32, by decision.  The reference's `ObjectID` (src/traits.rs:6-16) admits any `Copy + Hash + Ord` type; the only
