@@ -277,6 +277,15 @@ hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const 
                              uint32_t coarse_bucket, void* workspace, size_t workspace_bytes, DevScalars* sc,
                              const unsigned long long** d_hist, hipStream_t stream, const uint8_t* box_in = nullptr,
                              const unsigned long long* ready_hist = nullptr);
+// the same pass when the bucket sizes are known on the host (the caller derived them from the cell histogram): the owner table, the
+// sizes and the scalars' reset travel as kernel arguments of ONE setup launch (no H2D copies, no memset, no D2D copy); n_cells <=
+// PART_SETUP_MAX_CELLS; d_lut: device scratch of n_cells bytes the setup kernel fills
+constexpr uint32_t PART_SETUP_MAX_CELLS = 1024;
+hipError_t partition_entries_known(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
+                                   const unsigned char* host_lut, uint32_t n_cells, unsigned char* d_lut, const unsigned long long* host_hist,
+                                   int cell_shift, uint32_t depth_mask, uint32_t split_depth, uint32_t coarse_bucket, void* workspace,
+                                   size_t workspace_bytes, DevScalars* sc, const DevScalars& sc_init, const unsigned long long** d_hist,
+                                   hipStream_t stream, const uint8_t* box_in = nullptr);
 // ids[i] = packed & BOX_ID_MASK, box[i] = packed >> BOX_ID_BITS (in place on ids)
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream);
 // the inverse: ids[i] |= box_to_packed(box[i]) << BOX_ID_BITS (in place)

@@ -862,6 +862,36 @@ __global__ __launch_bounds__(RS_BINS) void radix_binbase_kernel(const u64* __res
     bin_base[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = base + incl - v;
 }
 
+// Everything in front of the sharded engine's partition pass in ONE launch, its small inputs as kernel arguments: the owner table and
+// the bucket sizes (host data: the splitters were just computed there) used to be two H2D copies, the scalars' reset a third, the
+// workspace a memset, the sizes a D2D copy, the bases a kernel -- six operations of a few microseconds each with the host's launch
+// latency between them, on a path where the GPU has nothing else queued (one rank's step of configs[3]: ~30 us).
+struct PartSetupArgs {
+    unsigned char lut[PART_SETUP_MAX_CELLS];   // cell -> owner
+    unsigned long long hist[RS_BINS];          // bucket sizes
+};
+__global__ __launch_bounds__(RS_BINS) void partition_setup_kernel(PartSetupArgs a, u32 n_cells, unsigned char* __restrict__ d_lut,
+                                                                  u64* __restrict__ ws_words, size_t ws_n_words, u64* __restrict__ hist,
+                                                                  u64* __restrict__ bin_base, DevScalars* sc, DevScalars sc_init) {
+    // every workgroup zero-fills its slice of the workspace (tile tickets and the look-back's status words) ...
+    for (size_t k = (size_t)blockIdx.x * RS_BINS + threadIdx.x; k < ws_n_words; k += (size_t)gridDim.x * RS_BINS)
+        if (k >= 2 * (size_t)RS_BINS) ws_words[k] = 0ull;   // (the first 512 words are hist and bin_base: written below)
+    if (blockIdx.x != 0) return;
+    // ... and the first one the rest
+    for (u32 c = threadIdx.x; c < n_cells; c += RS_BINS) d_lut[c] = a.lut[c];
+    if (threadIdx.x == 0) *sc = sc_init;
+    __shared__ u64 s_wave[RS_BINS / 64];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const u64 v = a.hist[threadIdx.x];
+    hist[threadIdx.x] = v;
+    const u64 incl = wave_incl_scan_u64(v);
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    u64 base = 0;
+    for (int k = 0; k < w; ++k) base += s_wave[k];
+    bin_base[threadIdx.x] = base + incl - v;
+}
+
 // one wave: the sizes of a finished expanding scan from its shard cursors and counts (launch_scan_finalize, or the first
 // kernel of the sort enqueued behind the scan)
 __device__ __forceinline__ void scan_finalize_wave(const u64* __restrict__ shards, u64 out_blocks, u64 n_bound, u64 extent_bound,
@@ -4708,6 +4738,31 @@ static hipError_t partition_pass(const u64* ki, u64* ko, const V* vi, V* vo, siz
     static const bool no_few = getenv("BP_NO_FEW_RANKING") != nullptr;  // A/B switch
     return launch_onesweep<u64, V, DigitFn>(ki, ko, vi, vo, n, fn, bin_base, status, counters, sc, stream, box_in, nullptr, blockfill, n_out,
                                             true, 0, !no_few);
+}
+
+hipError_t partition_entries_known(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,
+                                   const unsigned char* host_lut, uint32_t n_cells, unsigned char* d_lut, const unsigned long long* host_hist,
+                                   int cell_shift, uint32_t depth_mask, uint32_t split_depth, uint32_t coarse_bucket, void* workspace,
+                                   size_t workspace_bytes, DevScalars* sc, const DevScalars& sc_init, const unsigned long long** d_hist,
+                                   hipStream_t stream, const uint8_t* box_in) {
+    if (m == 0 || m >= 0xFFFFFFFFull || n_cells == 0 || n_cells > PART_SETUP_MAX_CELLS) return hipErrorInvalidValue;
+    if (radix_workspace_bytes(m, 1) > workspace_bytes) return hipErrorInvalidValue;
+    unsigned char* ws = (unsigned char*)workspace;
+    u64* hist = (u64*)ws;
+    u64* bin_base = hist + RS_BINS;
+    u32* counters = (u32*)(bin_base + RS_BINS);
+    u64* status = (u64*)((unsigned char*)counters + align_up(sizeof(u32), 256));
+    PartSetupArgs a;
+    for (uint32_t c = 0; c < n_cells; ++c) a.lut[c] = host_lut[c];
+    for (int k = 0; k < RS_BINS; ++k) a.hist[k] = host_hist[k];
+    partition_setup_kernel<<<64, RS_BINS, 0, stream>>>(a, n_cells, d_lut, (u64*)ws, radix_workspace_bytes(m, 1) / sizeof(u64), hist, bin_base, sc, sc_init);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    *d_hist = hist;
+    EntryDestDigit fn{d_lut, cell_shift, depth_mask, split_depth, coarse_bucket};
+    static const bool no_few = getenv("BP_NO_FEW_RANKING") != nullptr;  // A/B switch
+    return launch_onesweep<u64, u32, EntryDestDigit>((const u64*)keys_in, (u64*)keys_out, ids_in, ids_out, m, fn, bin_base, status, counters, sc, stream,
+                                                     box_in, nullptr, nullptr, m, true, 0, !no_few);
 }
 
 hipError_t partition_entries(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* ids_in, uint32_t* ids_out, size_t m,

@@ -3039,11 +3039,44 @@ int bp_layer_partition_entries_packed_device(bp_layer_t* L, uint32_t split_depth
     *d_ids = (const uint32_t*)L->ids[other].p;
     if (L->m == 0) return BP_OK;
     BP_TRY(ensure_dev(L, L->skip, n_cells));  // device copy of the lut
-    HIP_TRY(L, hipMemcpyAsync(L->skip.p, lut, n_cells, hipMemcpyHostToDevice, L->stream));
     BP_TRY(ensure_dev(L, L->radix_ws, radix_workspace_bytes(L->m, 1)));
     BP_TRY(ensure_host(L, L->h_raw, 256 * sizeof(unsigned long long)));
-    BP_TRY(sc_reset(L));
     const int cell_shift = (int)(ki.dim * ki.axis_bits + ki.depth_bits - ki.dim * split_depth);
+    // the bucket sizes follow from the cell histogram the caller just asked for (same tree, same split depth): table, sizes and
+    // the scalars' reset then ride in ONE setup launch (partition_entries_known) instead of three H2D copies, a memset, a D2D copy
+    // and a kernel -- on this path the GPU has nothing queued, and each of them cost the host's launch latency
+    static const bool no_fused_setup = getenv("BP_NO_PARTITION_SETUP") != nullptr;  // A/B switch
+    if (!no_fused_setup && n_cells <= PART_SETUP_MAX_CELLS && L->cell_hist_valid && L->cell_hist_depth == split_depth &&
+        L->cell_hist_cache.size() == n_cells + 1) {
+        unsigned long long h[256];
+        std::memset(h, 0, sizeof h);
+        for (size_t c = 0; c < n_cells; ++c) h[lut[c] < n_dest ? lut[c] : 0] += L->cell_hist_cache[c];
+        h[n_dest] += L->cell_hist_cache[n_cells];  // coarse entries
+        for (uint32_t i = 0; i <= n_dest; ++i) counts[i] = h[i];  // the bucket sizes ARE these sums
+        const unsigned long long* d_hist_k = nullptr;
+        {
+            ProfScope ps(L, BP_K_MISC);
+            HIP_TRY(L, partition_entries_known(cur_keys(L), (uint64_t*)L->keys[other].p, cur_ids(L), (uint32_t*)L->ids[other].p, L->m, lut,
+                                               (uint32_t)n_cells, (unsigned char*)L->skip.p, h, cell_shift, (1u << ki.depth_bits) - 1u, split_depth,
+                                               n_dest, L->radix_ws.p, L->radix_ws.cap, (DevScalars*)L->d_sc.p, neutral_scalars(), &d_hist_k,
+                                               L->stream, (pack_box && !already_packed) ? (const uint8_t*)L->box[L->cur].p : nullptr));
+        }
+        if (flags & BP_PARTITION_ENQUEUE_ONLY) {
+            // nobody waits here, but the pass's error word must not be lost (the next reset of the scalars would overwrite it):
+            // it is copied behind the pass and checked by the layer's next host round trip
+            BP_TRY(ensure_dev(L, L->d_part_err, sizeof(unsigned)));
+            BP_TRY(ensure_host(L, L->h_part_err, sizeof(unsigned)));
+            HIP_TRY(L, hipMemcpyAsync(L->d_part_err.p, &((DevScalars*)L->d_sc.p)->err, sizeof(unsigned), hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(L, hipMemcpyAsync(L->h_part_err.p, L->d_part_err.p, sizeof(unsigned), hipMemcpyDeviceToHost, L->stream));
+            L->part_pend = true;
+            return BP_OK;
+        }
+        DevScalars sck;
+        BP_TRY(sc_fetch(L, &sck));
+        return BP_OK;
+    }
+    HIP_TRY(L, hipMemcpyAsync(L->skip.p, lut, n_cells, hipMemcpyHostToDevice, L->stream));
+    BP_TRY(sc_reset(L));
     // bucket sizes straight from the cell histogram the caller just asked for (same tree, same split depth):
     // the partition pass then needs no histogram read of its own
     const unsigned long long* ready_hist = nullptr;
