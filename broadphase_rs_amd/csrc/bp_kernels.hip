@@ -3127,17 +3127,14 @@ __global__ __launch_bounds__(SX_THREADS) SX_OCC_ATTR void scan_expand_kernel(Exp
                             asm volatile("" : "+v"(w0lo), "+v"(w0hi), "+v"(w1lo), "+v"(w1hi));
                         }
                         const bool far0 = off0 >= SX_WIN, far1 = off1 >= SX_WIN;  // (a lane behind the last candidate is inside the window)
-                        if (__any(far0 || far1)) {  // those lanes read HBM
-                            if (far0) {
-                                const u64 t = p.idctx[base + off0];
-                                w0lo = (u32)t; w0hi = (u32)(t >> 32);
-                                asm volatile("" : "+v"(w0lo), "+v"(w0hi));  // consumed HERE: else its wait lands at the join, on every path
-                            }
-                            if (far1) {
-                                const u64 t = p.idctx[base + off1];
-                                w1lo = (u32)t; w1hi = (u32)(t >> 32);
-                                asm volatile("" : "+v"(w1lo), "+v"(w1hi));
-                            }
+                        if (__any(far0 || far1)) {  // those lanes read HBM: both slots' loads first, ONE wait for the two
+                            u64 t0 = 0, t1 = 0;
+                            if (far0) t0 = p.idctx[base + off0];
+                            if (far1) t1 = p.idctx[base + off1];
+                            u32 a0 = (u32)t0, a1 = (u32)(t0 >> 32), b0 = (u32)t1, b1 = (u32)(t1 >> 32);
+                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));  // consumed HERE: else the wait lands at the join, on every path
+                            if (far0) { w0lo = a0; w0hi = a1; }
+                            if (far1) { w1lo = b0; w1hi = b1; }
                         }
                     } else {
                         const u64 t0 = cwin[off0], t1 = cwin[off1];
