@@ -794,16 +794,32 @@ __global__ __launch_bounds__(HIST_THREADS) void radix_hist_kernel(const u64* __r
     const int np = plan.n_passes;
     for (int j = threadIdx.x; j < np * RS_BINS; j += HIST_THREADS) h[j] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * HIST_THREADS) {
-        if (blockfill) {  // 64 consecutive records per wave: the block is wave-uniform
-            const u32 blk = uniform_u32((u32)(i / HOLE_BLOCK));
-            if ((u32)(i & (HOLE_BLOCK - 1u)) >= blockfill[blk]) continue;  // hole
+    // (four records per thread and step, their loads issued together: with one block per CU -- see HIST_MAX_BLOCKS -- a thread walks
+    // many records, and one dependent load per step left a large input at a third of the rate)
+    constexpr int UNR = 4;
+    const size_t step = (size_t)gridDim.x * HIST_THREADS;
+    for (size_t i0 = (size_t)blockIdx.x * HIST_THREADS + threadIdx.x; i0 < n; i0 += UNR * step) {
+        u64 k[UNR];
+        u32 v[UNR];
+        bool on[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const size_t i = i0 + (size_t)q * step;
+            on[q] = i < n;
+            if (on[q] && blockfill) {  // 64 consecutive records per wave: the block is wave-uniform
+                const u32 blk = uniform_u32((u32)(i / HOLE_BLOCK));
+                on[q] = (u32)(i & (HOLE_BLOCK - 1u)) < blockfill[blk];  // (else a hole)
+            }
+            k[q] = on[q] ? keys[i] : 0ull;
+            v[q] = (on[q] && vals) ? vals[i] : 0u;
         }
-        const u64 k = keys[i];
-        const u32 v = vals ? vals[i] : 0u;
-        for (int p = 0; p < np; ++p) {
-            const u32 dg = plan.from_val[p] ? ((v >> plan.shift[p]) & 0xFFu) : ((u32)(k >> plan.shift[p]) & 0xFFu);
-            atomicAdd(&h[p * RS_BINS + dg], 1u);
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            if (!on[q]) continue;
+            for (int p = 0; p < np; ++p) {
+                const u32 dg = plan.from_val[p] ? ((v[q] >> plan.shift[p]) & 0xFFu) : ((u32)(k[q] >> plan.shift[p]) & 0xFFu);
+                atomicAdd(&h[p * RS_BINS + dg], 1u);
+            }
         }
     }
     __syncthreads();
@@ -4620,7 +4636,8 @@ hipError_t radix_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_
             e = hipMemsetAsync(hist, 0, (size_t)np * RS_BINS * sizeof(u64), stream);
             if (e != hipSuccess) return e;
         }
-        radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
+        static const int hist_blocks_env = getenv("BP_HIST_BLOCKS") ? atoi(getenv("BP_HIST_BLOCKS")) : 0;  // measurement knob
+        radix_hist_kernel<<<grid_for(extent, HIST_THREADS * 4, hist_blocks_env > 0 ? (unsigned)hist_blocks_env : (unsigned)HIST_MAX_BLOCKS), HIST_THREADS, 0, stream>>>(
             (const u64*)keys0, vals0, extent, plan, hist, blockfill);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         radix_prepare_kernel<<<np, RS_BINS, 0, stream>>>(nullptr, 0, hist, bin_base, counters, sc, init, sc_init ? 1 : 0,
