@@ -286,6 +286,8 @@ hipError_t partition_entries_known(const uint64_t* keys_in, uint64_t* keys_out, 
                                    int cell_shift, uint32_t depth_mask, uint32_t split_depth, uint32_t coarse_bucket, void* workspace,
                                    size_t workspace_bytes, DevScalars* sc, const DevScalars& sc_init, const unsigned long long** d_hist,
                                    hipStream_t stream, const uint8_t* box_in = nullptr);
+// device-to-device copy: a kernel for anything above 1 MB (the runtime's copy runs at a third of the memory's rate), hipMemcpyAsync below
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stream);
 // ids[i] = packed & BOX_ID_MASK, box[i] = packed >> BOX_ID_BITS (in place on ids)
 hipError_t launch_split_box(uint32_t* ids, uint8_t* box, size_t m, hipStream_t stream);
 // the inverse: ids[i] |= box_to_packed(box[i]) << BOX_ID_BITS (in place)

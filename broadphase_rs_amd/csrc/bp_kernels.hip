@@ -5484,6 +5484,31 @@ hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8
     return hipGetLastError();
 }
 
+// A large device-to-device copy as a kernel: hipMemcpyAsync moved a sorted layer's 0.27 GB of index values into another layer (merge)
+// at 1.5 TB/s; four independent 16-byte loads per thread and step run at the memory's rate.  T: the widest type both pointers and the
+// size are aligned to.
+template <typename T>
+__global__ __launch_bounds__(256) void copy_kernel(T* __restrict__ dst, const T* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const T a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes < ((size_t)1 << 20)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    const size_t al = (size_t)dst | (size_t)src | bytes;
+    const unsigned grid = 2048;
+    if ((al & 15) == 0) copy_kernel<uint4><<<grid, 256, 0, stream>>>((uint4*)dst, (const uint4*)src, bytes / 16);
+    else if ((al & 7) == 0) copy_kernel<u64><<<grid, 256, 0, stream>>>((u64*)dst, (const u64*)src, bytes / 8);
+    else if ((al & 3) == 0) copy_kernel<u32><<<grid, 256, 0, stream>>>((u32*)dst, (const u32*)src, bytes / 4);
+    else copy_kernel<uint8_t><<<grid, 256, 0, stream>>>((uint8_t*)dst, (const uint8_t*)src, bytes);
+    return hipGetLastError();
+}
+
 hipError_t launch_blockfill_to_u64(const uint32_t* blockfill, size_t n_blocks, unsigned long long* out, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     blockfill_to_u64_kernel<<<(unsigned)((n_blocks + 255) / 256), 256, 0, stream>>>(blockfill, n_blocks, (u64*)out);

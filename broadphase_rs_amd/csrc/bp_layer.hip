@@ -2477,10 +2477,10 @@ int bp_layer_merge(bp_layer_t* L, const bp_layer_t* other) {
         (void)hipStreamSynchronize(other->stream);
         BP_TRY(ensure_tree_capacity(L, L->m + m));
         const int oc = other->cur;
-        HIP_TRY(L, hipMemcpyAsync(cur_keys(L) + L->m, other->keys[oc].p, m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
-        HIP_TRY(L, hipMemcpyAsync(cur_ids(L) + L->m, other->ids[oc].p, m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        HIP_TRY(L, launch_copy_bytes(cur_keys(L) + L->m, other->keys[oc].p, m * sizeof(uint64_t), L->stream));
+        HIP_TRY(L, launch_copy_bytes(cur_ids(L) + L->m, other->ids[oc].p, m * sizeof(uint32_t), L->stream));
         if (other->box_valid && other->box[oc].p) {
-            HIP_TRY(L, hipMemcpyAsync((uint8_t*)L->box[L->cur].p + L->m, other->box[oc].p, m, hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(L, launch_copy_bytes((uint8_t*)L->box[L->cur].p + L->m, other->box[oc].p, m, L->stream));
             L->box_all_known = L->box_all_known && other->box_all_known;
         } else {
             HIP_TRY(L, hipMemsetAsync((uint8_t*)L->box[L->cur].p + L->m, (int)BOX_UNKNOWN, m, L->stream));
@@ -3309,11 +3309,11 @@ int bp_layer_clone(const bp_layer_t* src, bp_layer_t** out) {
     DeviceGuard g(L->device);
     if (src->m) {
         (void)hipStreamSynchronize(src->stream);
-        HIP_TRY(L, hipMemcpyAsync(L->keys[0].p, src->keys[src->cur].p, src->m * sizeof(uint64_t), hipMemcpyDeviceToDevice, L->stream));
-        HIP_TRY(L, hipMemcpyAsync(L->ids[0].p, src->ids[src->cur].p, src->m * sizeof(uint32_t), hipMemcpyDeviceToDevice, L->stream));
+        HIP_TRY(L, launch_copy_bytes(L->keys[0].p, src->keys[src->cur].p, src->m * sizeof(uint64_t), L->stream));
+        HIP_TRY(L, launch_copy_bytes(L->ids[0].p, src->ids[src->cur].p, src->m * sizeof(uint32_t), L->stream));
         BP_TRY(ensure_dev(L, L->box[0], src->m));
         if (src->box_valid && src->box[src->cur].p)
-            HIP_TRY(L, hipMemcpyAsync(L->box[0].p, src->box[src->cur].p, src->m, hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(L, launch_copy_bytes(L->box[0].p, src->box[src->cur].p, src->m, L->stream));
         BP_TRY(sync_stream(L));
     }
     L->box_valid = src->box_valid && (src->m == 0 || src->box[src->cur].p != nullptr);
