@@ -416,7 +416,8 @@ hipError_t launch_pick_ray(int kind, const uint64_t* keys, const uint32_t* ids, 
 // merge of two (key, id)-sorted runs A, B (box bytes ride along when bo != nullptr) into ko / io / bo
 hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8_t* ba, size_t na, const uint64_t* kb,
                              const uint32_t* ib, const uint8_t* bb, size_t nb, uint64_t* ko, uint32_t* io, uint8_t* bo,
-                             hipStream_t stream);
+                             hipStream_t stream, uint32_t* splits = nullptr);  // splits: merge_runs_split_words(na + nb) words of scratch (the tiles' splits in one small launch of their own)
+size_t merge_runs_split_words(size_t n_total);
 // dense copy of a block-structured stream (consumers that cannot read around the holes):
 // block_offs[g] = exclusive prefix sum of blockfill (launch_scan_block_sums on a u64 copy)
 hipError_t launch_compact_blocks(const uint64_t* in, size_t n_blocks, const uint32_t* blockfill,

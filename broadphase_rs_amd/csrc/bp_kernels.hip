@@ -5372,26 +5372,37 @@ __global__ __launch_bounds__(256) void pick_ray_kernel(const u64* __restrict__ k
 constexpr int MG_THREADS = 256;
 constexpr int MG_TILE = 2048;
 __device__ __forceinline__ bool rec_less(u64 ka, u32 ia, u64 kb, u32 ib) { return ka < kb || (ka == kb && ia < ib); }
+// merge-path split of diagonal d: a = #elements of A among the first d outputs
+__device__ __forceinline__ u32 merge_split(const u64* __restrict__ ka, const u32* __restrict__ ia, u32 na, const u64* __restrict__ kb,
+                                           const u32* __restrict__ ib, u32 nb, u32 d) {
+    u32 lo = d > nb ? d - nb : 0u, hi = min(d, na);
+    while (lo < hi) {
+        const u32 a = lo + ((hi - lo) >> 1), b = d - a;  // A[a] vs B[b - 1]: is A[a] among the first d?
+        // A[a] precedes B[b - 1] (ties: A first) -> the split lies further right
+        if (b > 0 && !rec_less(kb[b - 1], ib[b - 1], ka[a], ia[a])) lo = a + 1; else hi = a;
+    }
+    return lo;
+}
+// every tile's split in ONE small launch, one diagonal per thread: inside the merge kernel the bisection was ~20 dependent pairs of HBM
+// loads by two threads at the start of every workgroup -- most of a tile's life (33.7 M + 0.34 M entries: 397 us for 0.88 GB)
+__global__ __launch_bounds__(256) void merge_splits_kernel(const u64* __restrict__ ka, const u32* __restrict__ ia, u32 na, const u64* __restrict__ kb,
+                                                           const u32* __restrict__ ib, u32 nb, u32* __restrict__ splits, u32 n_tiles) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t > n_tiles) return;
+    const u32 total = na + nb;
+    splits[t] = merge_split(ka, ia, na, kb, ib, nb, min(t * (u32)MG_TILE, total));
+}
 __global__ __launch_bounds__(MG_THREADS) void merge_runs_kernel(const u64* __restrict__ ka, const u32* __restrict__ ia,
                                                                const uint8_t* __restrict__ ba, u32 na,
                                                                const u64* __restrict__ kb, const u32* __restrict__ ib,
                                                                const uint8_t* __restrict__ bb, u32 nb, u64* __restrict__ ko,
-                                                               u32* __restrict__ io, uint8_t* __restrict__ bo) {
+                                                               u32* __restrict__ io, uint8_t* __restrict__ bo, const u32* __restrict__ splits) {
     __shared__ u64 s_k[MG_TILE];
     __shared__ u32 s_i[MG_TILE];
     __shared__ u32 s_split[2];
     const u32 total = na + nb;
     const u32 d0 = blockIdx.x * MG_TILE, d1 = min(d0 + (u32)MG_TILE, total);
-    if (threadIdx.x < 2) {  // merge-path split of diagonal d: a = #elements of A among the first d outputs
-        const u32 d = threadIdx.x == 0 ? d0 : d1;
-        u32 lo = d > nb ? d - nb : 0u, hi = min(d, na);
-        while (lo < hi) {
-            const u32 a = lo + ((hi - lo) >> 1), b = d - a;  // A[a] vs B[b - 1]: is A[a] among the first d?
-            // A[a] precedes B[b - 1] (ties: A first) -> the split lies further right
-            if (b > 0 && !rec_less(kb[b - 1], ib[b - 1], ka[a], ia[a])) lo = a + 1; else hi = a;
-        }
-        s_split[threadIdx.x] = lo;
-    }
+    if (threadIdx.x < 2) s_split[threadIdx.x] = splits ? splits[blockIdx.x + threadIdx.x] : merge_split(ka, ia, na, kb, ib, nb, threadIdx.x == 0 ? d0 : d1);
     __syncthreads();
     const u32 a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
     const u32 la = a1 - a0, lb = b1 - b0;  // la + lb = d1 - d0 <= MG_TILE
@@ -5476,13 +5487,15 @@ hipError_t launch_pick_ray(int kind, const uint64_t* keys, const uint32_t* ids, 
 
 hipError_t launch_merge_runs(const uint64_t* ka, const uint32_t* ia, const uint8_t* ba, size_t na, const uint64_t* kb,
                              const uint32_t* ib, const uint8_t* bb, size_t nb, uint64_t* ko, uint32_t* io, uint8_t* bo,
-                             hipStream_t stream) {
+                             hipStream_t stream, uint32_t* splits) {
     if (na + nb == 0) return hipSuccess;
     if (na + nb >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned g = (unsigned)((na + nb + MG_TILE - 1) / MG_TILE);
-    merge_runs_kernel<<<g, MG_THREADS, 0, stream>>>((const u64*)ka, ia, ba, (u32)na, (const u64*)kb, ib, bb, (u32)nb, (u64*)ko, io, bo);
+    if (splits) merge_splits_kernel<<<(g + 1 + 255) / 256, 256, 0, stream>>>((const u64*)ka, ia, (u32)na, (const u64*)kb, ib, (u32)nb, splits, g);
+    merge_runs_kernel<<<g, MG_THREADS, 0, stream>>>((const u64*)ka, ia, ba, (u32)na, (const u64*)kb, ib, bb, (u32)nb, (u64*)ko, io, bo, splits);
     return hipGetLastError();
 }
+size_t merge_runs_split_words(size_t n_total) { return (n_total + MG_TILE - 1) / MG_TILE + 1; }
 
 // A large device-to-device copy as a kernel: hipMemcpyAsync moved a sorted layer's 0.27 GB of index values into another layer (merge)
 // at 1.5 TB/s; four independent 16-byte loads per thread and step run at the memory's rate.  T: the widest type both pointers and the

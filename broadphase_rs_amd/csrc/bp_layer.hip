@@ -1004,6 +1004,7 @@ int sort_tree_by_merge(bp_layer* L, int* handled) {
     BP_TRY(ensure_dev(L, L->keys[dst], m * sizeof(uint64_t)));
     BP_TRY(ensure_dev(L, L->ids[dst], m * sizeof(uint32_t)));
     if (L->box_valid) BP_TRY(ensure_dev(L, L->box[dst], m));
+    BP_TRY(ensure_dev(L, L->skip, merge_runs_split_words(m) * sizeof(uint32_t)));  // (scratch: the tiles' merge-path splits)
     {
         ProfScope ps(L, BP_K_TREE_SORT);
         HIP_TRY(L, launch_merge_runs((const uint64_t*)L->keys[src].p, (const uint32_t*)L->ids[src].p,
@@ -1011,7 +1012,7 @@ int sort_tree_by_merge(bp_layer* L, int* handled) {
                                      (const uint64_t*)L->keys[src].p + n_head, (const uint32_t*)L->ids[src].p + n_head,
                                      L->box_valid ? (const uint8_t*)L->box[src].p + n_head : nullptr, n_tail,
                                      (uint64_t*)L->keys[dst].p, (uint32_t*)L->ids[dst].p,
-                                     L->box_valid ? (uint8_t*)L->box[dst].p : nullptr, L->stream));
+                                     L->box_valid ? (uint8_t*)L->box[dst].p : nullptr, L->stream, (uint32_t*)L->skip.p));
     }
     BP_TRY(sync_stream(L));
     L->cur = dst;
